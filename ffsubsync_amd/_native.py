@@ -1,0 +1,259 @@
+"""ctypes binding of ``libffsalign.so`` (the C ABI declared in ``include/ffsubsync_amd.h``).
+
+There is deliberately no fallback: if the HIP library is missing or no MI355X is visible, the
+product path raises -- it never degrades to a CPU implementation.
+"""
+import ctypes
+import os
+import threading
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_LIB_NAME = "libffsalign.so"
+_lib = None
+_lib_lock = threading.Lock()
+
+FFS_DTYPE_U8 = 0
+FFS_DTYPE_F32 = 1
+FLAG_EMPTY_WINDOW = 1
+FLAG_AMBIGUOUS = 2
+FLAG_FILTERED = 4
+FLAG_DIRECT = 8
+
+MAX_FFT_LENGTH = 1 << 24
+
+CAND_RESULT_DTYPE = np.dtype(
+    [("score", "<f8"), ("offset", "<i8"), ("score_f32", "<f4"), ("flags", "<i4")], align=True
+)
+PAIR_RESULT_DTYPE = np.dtype(
+    [("score", "<f8"), ("offset", "<i8"), ("best_cand", "<i4"), ("flags", "<i4")], align=True
+)
+assert CAND_RESULT_DTYPE.itemsize == 24 and PAIR_RESULT_DTYPE.itemsize == 24
+
+# every symbol include/ffsubsync_amd.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = (
+    "ffs_fft_length",
+    "ffs_plan_create",
+    "ffs_plan_destroy",
+    "ffs_plan_workspace_bytes",
+    "ffs_align_batch",
+    "ffs_correlate_full",
+    "ffs_vad_energy",
+    "ffs_speech_bounds",
+    "ffs_plan_profile",
+    "ffs_plan_profile_read",
+    "ffs_last_error",
+    "ffs_version",
+)
+KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore")
+
+
+class NativeError(RuntimeError):
+    """A call into libffsalign.so returned a negative FFS_E_* code."""
+
+    def __init__(self, code: int, message: str) -> None:
+        super().__init__("libffsalign error %d: %s" % (code, message))
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+
+
+def load():
+    """Load the shared library once; raise ImportError loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C ffsubsync_amd/csrc` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback." % path
+            )
+        lib = ctypes.CDLL(path)
+        c = ctypes
+        lib.ffs_fft_length.restype = c.c_int64
+        lib.ffs_fft_length.argtypes = [c.c_int64, c.c_int64]
+        lib.ffs_plan_create.restype = c.c_int
+        lib.ffs_plan_create.argtypes = [c.c_int, c.c_int64, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
+        lib.ffs_plan_destroy.restype = c.c_int
+        lib.ffs_plan_destroy.argtypes = [c.c_void_p]
+        lib.ffs_plan_workspace_bytes.restype = c.c_int64
+        lib.ffs_plan_workspace_bytes.argtypes = [c.c_void_p]
+        lib.ffs_align_batch.restype = c.c_int
+        lib.ffs_align_batch.argtypes = [
+            c.c_void_p, c.c_int, c.c_int, c.c_int,
+            c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+            c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p,
+        ]
+        lib.ffs_correlate_full.restype = c.c_int
+        lib.ffs_correlate_full.argtypes = [
+            c.c_void_p, c.c_int,
+            c.c_void_p, c.c_int64, c.c_double, c.c_double,
+            c.c_void_p, c.c_int64, c.c_double, c.c_double,
+            c.c_void_p, c.c_int64, c.c_double, c.c_double,
+            c.c_void_p, c.c_void_p, c.c_void_p,
+        ]
+        lib.ffs_vad_energy.restype = c.c_int
+        lib.ffs_vad_energy.argtypes = [c.c_void_p, c.c_int64, c.c_int, c.c_double, c.c_float, c.c_void_p, c.c_void_p]
+        lib.ffs_speech_bounds.restype = c.c_int
+        lib.ffs_speech_bounds.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        lib.ffs_plan_profile.restype = c.c_int
+        lib.ffs_plan_profile.argtypes = [c.c_void_p, c.c_int]
+        lib.ffs_plan_profile_read.restype = c.c_int
+        lib.ffs_plan_profile_read.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p]
+        lib.ffs_last_error.restype = c.c_char_p
+        lib.ffs_last_error.argtypes = []
+        lib.ffs_version.restype = c.c_int
+        lib.ffs_version.argtypes = []
+        _lib = lib
+        return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise NativeError(code, load().ffs_last_error().decode("utf-8", "replace"))
+
+
+def fft_length(ref_len: int, sub_len: int) -> int:
+    return int(load().ffs_fft_length(int(ref_len), int(sub_len)))
+
+
+def require_gpu():
+    """Return torch after checking a HIP device is visible (the product path needs one)."""
+    import torch
+
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "ffsubsync_amd needs an AMD Instinct GPU (ROCm/HIP device) -- none is visible and there is no CPU fallback"
+        )
+    return torch
+
+
+def current_stream_ptr(torch) -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class Plan:
+    """Owns one ``ffs_plan`` (twiddle tables + HBM workspace for one transform length)."""
+
+    def __init__(self, n_fft: int, pairs_in_flight: int = 2, max_cand: int = 8, device: Optional[int] = None) -> None:
+        torch = require_gpu()
+        self.lib = load()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.n_fft = int(n_fft)
+        self.pairs_in_flight = int(pairs_in_flight)
+        self.max_cand = int(max_cand)
+        handle = ctypes.c_void_p()
+        check(self.lib.ffs_plan_create(self.device, self.n_fft, self.pairs_in_flight, self.max_cand, ctypes.byref(handle)))
+        self.handle = handle
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.ffs_plan_workspace_bytes(self.handle))
+
+    def profile(self, enable: bool) -> None:
+        check(self.lib.ffs_plan_profile(self.handle, 1 if enable else 0))
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} accumulated since the last read (synchronises)."""
+        ms = np.zeros(len(KERNEL_NAMES), dtype=np.float64)
+        n = np.zeros(len(KERNEL_NAMES), dtype=np.int64)
+        check(self.lib.ffs_plan_profile_read(self.handle, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.ffs_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover - interpreter shutdown ordering
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def align_batch(self, n_pairs: int, n_cand: int, dtype: int, vec_ptr: np.ndarray, vec_len: np.ndarray,
+                    vec_lo: np.ndarray, vec_hi: np.ndarray, max_offset_samples: Optional[int],
+                    filter_max_offset: Optional[int], cand_out, pair_out, stream: Optional[int] = None) -> None:
+        """Asynchronous batched solve; ``cand_out``/``pair_out`` are uint8 CUDA tensors of
+        n_pairs*n_cand*24 and n_pairs*24 bytes.  Host arrays are consumed before returning."""
+        torch = require_gpu()
+        n_vec = n_pairs * (1 + n_cand)
+        vec_ptr = np.ascontiguousarray(vec_ptr, dtype=np.uint64)
+        vec_len = np.ascontiguousarray(vec_len, dtype=np.int64)
+        vec_lo = np.ascontiguousarray(vec_lo, dtype=np.float64)
+        vec_hi = np.ascontiguousarray(vec_hi, dtype=np.float64)
+        if not (vec_ptr.size == vec_len.size == vec_lo.size == vec_hi.size == n_vec):
+            raise ValueError("descriptor arrays must have n_pairs*(1+n_cand) entries")
+        if cand_out.numel() * cand_out.element_size() < n_pairs * n_cand * 24 or \
+                pair_out.numel() * pair_out.element_size() < n_pairs * 24:
+            raise ValueError("result buffers too small")
+        st = current_stream_ptr(torch) if stream is None else stream
+        check(self.lib.ffs_align_batch(
+            self.handle, n_pairs, n_cand, dtype,
+            vec_ptr.ctypes.data, vec_len.ctypes.data, vec_lo.ctypes.data, vec_hi.ctypes.data,
+            -1 if max_offset_samples is None else int(max_offset_samples),
+            -1 if filter_max_offset is None else int(filter_max_offset),
+            cand_out.data_ptr(), pair_out.data_ptr(), st,
+        ))
+
+    def correlate_full(self, dtype: int, ref, ref_levels, a, a_levels, b=None, b_levels=(0.0, 1.0)):
+        """Raw fp32 correlation arrays out_a[m], out_b[m] (m = lag mod n_fft) as CUDA tensors."""
+        torch = require_gpu()
+        out_a = torch.empty(self.n_fft, dtype=torch.float32, device=ref.device)
+        out_b = torch.empty(self.n_fft, dtype=torch.float32, device=ref.device) if b is not None else None
+        check(self.lib.ffs_correlate_full(
+            self.handle, dtype,
+            ref.data_ptr(), ref.numel(), float(ref_levels[0]), float(ref_levels[1]),
+            a.data_ptr(), a.numel(), float(a_levels[0]), float(a_levels[1]),
+            b.data_ptr() if b is not None else None, b.numel() if b is not None else 0,
+            float(b_levels[0]), float(b_levels[1]),
+            out_a.data_ptr(), out_b.data_ptr() if out_b is not None else None, current_stream_ptr(torch),
+        ))
+        return out_a, out_b
+
+
+_plans: Dict[Tuple[int, int, int, int], Plan] = {}
+_plans_lock = threading.Lock()
+
+
+def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Optional[int] = None) -> Plan:
+    """Process-wide plan cache keyed by (device, n_fft, pairs_in_flight, max_cand)."""
+    torch = require_gpu()
+    dev = torch.cuda.current_device() if device is None else int(device)
+    key = (dev, int(n_fft), int(pairs_in_flight), int(max_cand))
+    with _plans_lock:
+        plan = _plans.get(key)
+        if plan is None:
+            plan = Plan(n_fft, pairs_in_flight, max_cand, dev)
+            _plans[key] = plan
+        return plan
+
+
+def vad_energy(pcm, frame_len: int, threshold_db: float, non_speech_label: float):
+    """labels (float32 CUDA tensor) for an int16 CUDA tensor of mono PCM."""
+    torch = require_gpu()
+    n = pcm.numel()
+    n_frames = (n + frame_len - 1) // frame_len
+    labels = torch.empty(n_frames, dtype=torch.float32, device=pcm.device)
+    if n:
+        check(load().ffs_vad_energy(pcm.data_ptr(), n, int(frame_len), float(threshold_db), float(non_speech_label),
+                                    labels.data_ptr(), current_stream_ptr(torch)))
+    return labels
+
+
+def speech_bounds(frames):
+    """(first, last) index with frames > 0.5 for a float32 CUDA tensor, or (None, None)."""
+    torch = require_gpu()
+    out = torch.empty(2, dtype=torch.int64, device=frames.device)
+    check(load().ffs_speech_bounds(frames.data_ptr() if frames.numel() else None, frames.numel(), out.data_ptr(),
+                                   current_stream_ptr(torch)))
+    lo, hi = (int(v) for v in out.cpu())
+    return (None, None) if hi < 0 else (lo, hi)

@@ -1,0 +1,648 @@
+// ffs_kernels.h -- device kernels of the alignment hot path (gfx950).
+//
+// Cross-correlation of a reference activity vector with packed pairs of candidate vectors:
+//
+//   z = a' + i*b'  (two candidates share one complex transform; x' = 2x-1, aligners.py:55-57)
+//   out = FFT( FFT(z) * conj(FFT(r')) ) / N      =>  Re out[m] = sum_i a'[i] r'[i+m],
+//                                                     Im out[m] = sum_i b'[i] r'[i+m]
+//
+// which is the reference's `convolve` (aligners.py:70-74) re-indexed by m = d mod N with
+// d = N-1-S-k.  Both FFTs are forward transforms of length N = N1*N2 done in two HBM passes
+// each (four-step), and the inner two passes fuse into one kernel:
+//
+//   k_pass_a : columns n2: load/±1-map/zero-pad, length-N1 FFT over n1, twiddle W_N^(n2*k1)
+//              -> tile layout T[x/C][k1][x%C]                                  (write 8N bytes)
+//   k_mid    : rows k1: length-N2 FFT over n2 (= spectrum row), * conj(R)/N held in registers,
+//              length-N2 FFT over k2, twiddle W_N^(k1*m1) -> same tile layout, in place
+//                                                                  (read 8N + write 8N bytes)
+//   k_pass_c : columns m1: length-N1 FFT over k1 -> out[m1 + N2*m2]; lag-window mask and
+//              per-block argmax nominees; the correlation itself is never written (read 8N)
+//
+// followed by tiny kernels that gather the nominees of each candidate, re-evaluate them exactly
+// (integer counts / fp64) and take the max over candidates (aligners.py:154-167).
+#pragma once
+#include "ffs_fft.h"
+
+namespace ffsa {
+
+constexpr int KBLK = 6;   // nominees kept per pass-C block
+constexpr int KNOM = 16;  // nominees kept per candidate
+constexpr int RSEG = 8;   // segments each exact re-evaluation is split into
+
+struct XformDesc {  // one packed transform (slot 0 of a pair is the reference, b = null)
+    const void* a;
+    const void* b;
+    int32_t len_a, len_b;
+    float a0, a1, b0, b1;  // u8: mapped sample values x' for byte == 0 / != 0
+};
+
+struct CandDesc {  // one candidate (one FFTAligner solve)
+    const void* s;     // candidate samples
+    const void* r;     // its reference
+    int32_t S, R;
+    int32_t d_lo, d_hi;  // inclusive lag window (already intersected with [-S, Nref-1-S])
+    int32_t n_ref;       // the reference's transform length for (R, S)
+    int32_t flags;       // FFS_FLAG_EMPTY_WINDOW preset by the host
+    float margin;        // fp32 tie margin for nominee collection
+    float pad;
+    double s0, s1, r0, r1;  // mapped two-level values (fp64, as the reference computes them)
+};
+
+struct BlockNom {
+    float bmax;
+    int32_t cnt;
+    float val[KBLK];
+    int32_t d[KBLK];
+};
+
+struct NomList {
+    int32_t count;
+    int32_t flags;
+    float gmax;
+    int32_t pad;
+    int32_t d[KNOM];
+    float val[KNOM];
+};
+
+struct RescoreAcc {
+    unsigned int n11, n1x, nx1, pad;
+    double fsum;
+};
+
+struct CandResult {
+    double score;
+    long long offset;
+    float score_f32;
+    int32_t flags;
+};
+struct PairResult {
+    double score;
+    long long offset;
+    int32_t best_cand;
+    int32_t flags;
+};
+
+FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 == v2 && d1 > d2); }
+
+template <int DT>
+FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
+    if (n >= len) return 0.0f;
+    if (DT == 0) {
+        return (reinterpret_cast<const unsigned char*>(p)[n] != 0) ? v1 : v0;
+    } else {
+        return 2.0f * reinterpret_cast<const float*>(p)[n] - 1.0f;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// pass A.  grid = (N2/C, n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
+template <int L, int C, int DT>
+__global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
+                                                         int N2, long long N, const cf* __restrict__ tw,
+                                                         const cf* __restrict__ tb, const cf* __restrict__ ts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    const int c = threadIdx.x % C;
+    const int u = threadIdx.x / C;
+    const int tile = blockIdx.x;
+    const int n2 = tile * C + c;
+    const XformDesc d = descs[blockIdx.y];
+    cf v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int n = (u + LT * q) * N2 + n2;
+        v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
+        v[q].y = (d.b != nullptr) ? load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1) : 0.0f;
+    }
+    fft_regs<L>(v, lds, u, ColAddr<C>{c}, tw);
+    // v[q] = Y[k1 = u + LT*q][n2];  times W_N^(n2*k1) = tb[u][n2] * ts[q][n2]
+    const cf wb = tb[u * N2 + n2];
+    cf* out = work + (size_t)blockIdx.y * N;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const cf w = (q == 0) ? wb : cmul(wb, ts[q * N2 + n2]);
+        const int k1 = u + LT * q;
+        out[((size_t)tile * L + k1) * C + c] = cmul(v[q], w);
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// mid pass.  grid = (N1/ROWS, n_pairs); block = 256 threads; ROWS = 256/(L/16) rows per block.
+// Slot 0 of each pair is the reference transform; slots 1..n_slots-1 are transformed in place.
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                             float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
+                                             const cf* __restrict__ ts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    constexpr int ROWS = 256 / LT;
+    constexpr int ROW_STRIDE = L + L / 32;
+    const int row = threadIdx.x / LT;
+    const int u = threadIdx.x % LT;
+    const int k1 = blockIdx.x * ROWS + row;
+    const RowAddr addr{row * ROW_STRIDE};
+    const int C = 1 << log2C;
+    cf* base = work + (size_t)blockIdx.y * n_slots * N;
+
+    // element x of row k1 lives at ((x/C)*N1 + k1)*C + x%C
+    auto off = [&](int q) {
+        const int x = u + LT * q;
+        return ((x >> log2C) * N1 + k1) * C + (x & (C - 1));
+    };
+
+    cf rr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rr[q] = base[off(q)];
+    fft_regs<L>(rr, lds, u, addr, tw);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, -rr[q].y * inv_n);  // conj(R)/N
+
+    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    for (int s = 1; s < n_slots; ++s) {
+        cf* buf = base + (size_t)s * N;
+        cf v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = buf[off(q)];
+        // u is re-materialised per transform so the ~100 loop-invariant LDS addresses derived from it
+        // are recomputed (a few VALU ops each) instead of being kept live across the slot loop.
+        int ua = u, ub = u;
+        asm volatile("" : "+v"(ua), "+v"(ub));
+        fft_regs<L>(v, lds, ua, addr, tw);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], rr[q]);
+        fft_regs<L>(v, lds, ub, addr, tw);
+        const cf* tsl = pin(ts);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf w = (q == 0) ? wb : cmul(wb, tsl[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+            buf[off(q)] = cmul(v[q], w);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// pass C.  grid = (N2/C, n_transforms); same thread mapping as pass A.
+// cands[2*xf + {0,1}] describe the real / imaginary candidate of transform xf (S <= 0: absent).
+// grid.y enumerates the candidate transforms of the pairs in flight: ly = lp*n_packed + k uses work
+// slot lp*n_slots + 1 + k and candidates first_cand + lp*n_cand + {2k, 2k+1}.
+template <int L, int C, bool WRITE>
+__global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ work, int N2, long long N,
+                                                         const cf* __restrict__ tw, const CandDesc* __restrict__ cands,
+                                                         int first_cand, int n_cand, int n_packed, int n_slots,
+                                                         BlockNom* __restrict__ bnom, float* __restrict__ out_a,
+                                                         float* __restrict__ out_b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    constexpr int NT = LT * C;
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x;
+    const int c = tid % C;
+    const int u = tid / C;
+    const int tile = blockIdx.x;
+    const int ly = blockIdx.y;
+    const int lp = ly / n_packed, kp = ly % n_packed;
+    const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
+    cf v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
+    fft_regs<L>(v, lds, u, ColAddr<C>{c}, tw);
+    // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LT*q
+    const int m1 = tile * C + c;
+    if (WRITE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const size_t m = (size_t)m1 + (size_t)N2 * (u + LT * q);
+            if (out_a) out_a[m] = v[q].x;
+            if (out_b) out_b[m] = v[q].y;
+        }
+        return;
+    }
+
+    const int nN = (int)N;
+    float bv[2];
+    int bd[2];
+    float marg[2];
+    int S2[2], lo2[2], hi2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool present = (2 * kp + h) < n_cand;
+        const CandDesc& cd = cands[first_cand + lp * n_cand + (present ? 2 * kp + h : 0)];
+        S2[h] = cd.S;
+        lo2[h] = cd.d_lo;
+        hi2[h] = (present && !(cd.flags & 1)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
+        marg[h] = cd.margin;
+        bv[h] = -INFINITY;
+        bd[h] = INT32_MIN;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int m = m1 + N2 * (u + LT * q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = (m <= nN - 1 - S2[h]) ? m : m - nN;
+            const bool ok = (d >= lo2[h]) && (d <= hi2[h]);
+            const float val = h ? v[q].y : v[q].x;
+            if (ok && better(val, d, bv[h], bd[h])) {
+                bv[h] = val;
+                bd[h] = d;
+            }
+        }
+    }
+    // block argmax per candidate: wave shuffle, then across waves through LDS
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv[h], sft, 64);
+            const int od = __shfl_xor(bd[h], sft, 64);
+            if (better(ov, od, bv[h], bd[h])) {
+                bv[h] = ov;
+                bd[h] = od;
+            }
+        }
+    }
+    __syncthreads();  // FFT tile no longer needed; reuse LDS as scratch
+    float* s_val = reinterpret_cast<float*>(smem);              // [NW][2]
+    int* s_d = reinterpret_cast<int*>(smem + 256);              // [NW][2]
+    float* s_bmax = reinterpret_cast<float*>(smem + 512);       // [2]
+    int* s_cnt = reinterpret_cast<int*>(smem + 528);            // [2]
+    float* s_lval = reinterpret_cast<float*>(smem + 544);       // [2][KBLK]
+    int* s_ld = reinterpret_cast<int*>(smem + 544 + 64);        // [2][KBLK]
+    const int wave = tid / 64, lane = tid % 64;
+    if (lane == 0) {
+        s_val[wave * 2 + 0] = bv[0];
+        s_val[wave * 2 + 1] = bv[1];
+        s_d[wave * 2 + 0] = bd[0];
+        s_d[wave * 2 + 1] = bd[1];
+    }
+    __syncthreads();
+    if (tid < 2) {
+        float fv = -INFINITY;
+        int fd = INT32_MIN;
+        for (int w = 0; w < NW; ++w)
+            if (better(s_val[w * 2 + tid], s_d[w * 2 + tid], fv, fd)) {
+                fv = s_val[w * 2 + tid];
+                fd = s_d[w * 2 + tid];
+            }
+        s_bmax[tid] = fv;
+        s_cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float thr = s_bmax[h] - marg[h];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int m = m1 + N2 * (u + LT * q);
+            const int d = (m <= nN - 1 - S2[h]) ? m : m - nN;
+            const bool ok = (d >= lo2[h]) && (d <= hi2[h]);
+            const float val = h ? v[q].y : v[q].x;
+            if (ok && val >= thr) {
+                const int slot = atomicAdd(&s_cnt[h], 1);
+                if (slot < KBLK) {
+                    s_lval[h * KBLK + slot] = val;
+                    s_ld[h * KBLK + slot] = d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2) {
+        BlockNom& o = bnom[((size_t)ly * 2 + tid) * gridDim.x + tile];
+        o.bmax = s_bmax[tid];
+        o.cnt = s_cnt[tid];
+        for (int i = 0; i < KBLK; ++i) {
+            o.val[i] = s_lval[tid * KBLK + i];
+            o.d[i] = s_ld[tid * KBLK + i];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// nominee gather: one wave per candidate. cand index ci = first_cand + blockIdx.x maps to
+// block-nominee row (local transform, half) = (lx, h) given by cand_xf[ci - first_cand].
+__global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bnom, int tiles, int n_cand,
+                                                 int n_packed, const CandDesc* __restrict__ cands,
+                                                 NomList* __restrict__ noms, int first_cand) {
+    const int ci = first_cand + blockIdx.x;
+    const int lp = blockIdx.x / n_cand, jc = blockIdx.x % n_cand;
+    const int row = (lp * n_packed + jc / 2) * 2 + (jc & 1);
+    const CandDesc& cd = cands[ci];
+    NomList& nl = noms[ci];
+    const int lane = threadIdx.x;
+    if (cd.flags & 1) {
+        if (lane == 0) {
+            nl.count = 0;
+            nl.flags = 1;
+            nl.gmax = -INFINITY;
+        }
+        return;
+    }
+    const BlockNom* rows = bnom + (size_t)row * tiles;
+    float g = -INFINITY;
+    for (int t = lane; t < tiles; t += 64) g = fmaxf(g, rows[t].bmax);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) g = fmaxf(g, __shfl_xor(g, sft, 64));
+    __shared__ int s_count;
+    __shared__ int s_flags;
+    if (lane == 0) {
+        s_count = 0;
+        s_flags = 0;
+    }
+    __syncthreads();
+    const float thr = g - cd.margin;
+    for (int t = lane; t < tiles; t += 64) {
+        const BlockNom& b = rows[t];
+        if (b.bmax >= thr) {
+            if (b.cnt > KBLK) atomicOr(&s_flags, 2);
+            const int n = b.cnt < KBLK ? b.cnt : KBLK;
+            for (int i = 0; i < n; ++i) {
+                if (b.val[i] >= thr) {
+                    const int slot = atomicAdd(&s_count, 1);
+                    if (slot < KNOM) {
+                        nl.d[slot] = b.d[i];
+                        nl.val[slot] = b.val[i];
+                    } else {
+                        atomicOr(&s_flags, 2);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        nl.count = s_count < KNOM ? s_count : KNOM;
+        nl.flags = s_flags;
+        nl.gmax = g;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// exact re-evaluation of c(d) = sum_{i in overlap} s'[i] * r'[i+d] for every nominee.
+// grid = (RSEG, KNOM, n_cands); accumulates into acc[ci*KNOM + nominee].
+template <int DT>
+__global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
+                                                 RescoreAcc* __restrict__ acc, int first_cand) {
+    const int ci = first_cand + blockIdx.z;
+    const int ni = blockIdx.y;
+    const NomList& nl = noms[ci];
+    if (ni >= nl.count) return;
+    const CandDesc& cd = cands[ci];
+    const int d = nl.d[ni];
+    const int i0 = d < 0 ? -d : 0;
+    const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+    if (i1 <= i0) return;
+    const int len = i1 - i0;
+    const int seg = (len + RSEG - 1) / RSEG;
+    const int a = i0 + blockIdx.x * seg;
+    const int b = (a + seg) < i1 ? (a + seg) : i1;
+    RescoreAcc& out = acc[(size_t)ci * KNOM + ni];
+    if (DT == 0) {
+        const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
+        const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
+        unsigned int n11 = 0, n1x = 0, nx1 = 0;
+        for (int i = a + threadIdx.x; i < b; i += 256) {
+            const unsigned int sb = s[i] != 0, rb = r[i] != 0;
+            n11 += sb & rb;
+            n1x += sb;
+            nx1 += rb;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            n11 += __shfl_xor(n11, sft, 64);
+            n1x += __shfl_xor(n1x, sft, 64);
+            nx1 += __shfl_xor(nx1, sft, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&out.n11, n11);
+            atomicAdd(&out.n1x, n1x);
+            atomicAdd(&out.nx1, nx1);
+        }
+    } else {
+        const float* s = reinterpret_cast<const float*>(cd.s);
+        const float* r = reinterpret_cast<const float*>(cd.r) + d;
+        double sum = 0.0;
+        for (int i = a + threadIdx.x; i < b; i += 256) {
+            const double sv = 2.0 * (double)s[i] - 1.0, rv = 2.0 * (double)r[i] - 1.0;
+            sum += sv * rv;
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&out.fsum, sum);
+    }
+}
+
+FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
+    if (dt != 0) return a.fsum;
+    const int i0 = d < 0 ? -d : 0;
+    const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+    const long long ov = i1 > i0 ? (long long)(i1 - i0) : 0;
+    const long long n11 = a.n11, n10 = (long long)a.n1x - n11, n01 = (long long)a.nx1 - n11;
+    const long long n00 = ov - n11 - n10 - n01;
+    return (double)n11 * (cd.s1 * cd.r1) + (double)n10 * (cd.s1 * cd.r0) + (double)n01 * (cd.s0 * cd.r1) +
+           (double)n00 * (cd.s0 * cd.r0);
+}
+
+// one thread per candidate: best nominee by exact score (ties -> largest d = first k)
+__global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
+                                 const RescoreAcc* __restrict__ acc, CandResult* __restrict__ out, int n, int dt) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ci >= n) return;
+    const CandDesc& cd = cands[ci];
+    const NomList& nl = noms[ci];
+    CandResult r;
+    if ((cd.flags & 1) || nl.count == 0) {
+        // every lag masked: np.argmax of all -inf is k=0 (aligners.py:45-48)
+        r.score = -INFINITY;
+        r.offset = (long long)cd.n_ref - 1 - cd.S;
+        r.score_f32 = -INFINITY;
+        r.flags = 1;
+    } else {
+        double bs = -INFINITY;
+        int bd = INT32_MIN;
+        float bf = 0.f;
+        for (int i = 0; i < nl.count; ++i) {
+            const double sc = exact_score(cd, acc[(size_t)ci * KNOM + i], nl.d[i], dt);
+            if (sc > bs || (sc == bs && nl.d[i] > bd)) {
+                bs = sc;
+                bd = nl.d[i];
+                bf = nl.val[i];
+            }
+        }
+        r.score = bs;
+        r.offset = bd;
+        r.score_f32 = bf;
+        r.flags = nl.flags & 2;
+    }
+    out[ci] = r;
+}
+
+// one thread per pair: MaxScoreAligner.transform (aligners.py:154-167)
+__global__ void k_finalize_pairs(CandResult* __restrict__ cres, PairResult* __restrict__ out, int n_pairs, int n_cand,
+                                 long long filter_max) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    PairResult r;
+    r.score = 0;
+    r.offset = 0;
+    r.best_cand = -1;
+    r.flags = 0;
+    for (int j = 0; j < n_cand; ++j) {
+        CandResult& c = cres[(size_t)p * n_cand + j];
+        const long long ao = c.offset < 0 ? -c.offset : c.offset;
+        if (filter_max >= 0 && ao > filter_max) {
+            c.flags |= 4;
+            continue;
+        }
+        if (r.best_cand < 0 || c.score > r.score) {
+            r.score = c.score;
+            r.offset = c.offset;
+            r.best_cand = j;
+            r.flags = c.flags;
+        }
+    }
+    out[p] = r;
+}
+
+// --------------------------------------------------------------------------------------------
+// direct exact correlation for short inputs: one block per candidate, every lag of the window
+// evaluated exactly (integer counts / fp64 in index order), argmax with ties -> largest d.
+template <int DT>
+__global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ cands, CandResult* __restrict__ out) {
+    const int ci = blockIdx.x;
+    const CandDesc cd = cands[ci];
+    __shared__ double s_sc[256];
+    __shared__ int s_d[256];
+    double bs = -INFINITY;
+    int bd = INT32_MIN;
+    if (!(cd.flags & 1)) {
+        for (int d = cd.d_lo + (int)threadIdx.x; d <= cd.d_hi; d += 256) {
+            const int i0 = d < 0 ? -d : 0;
+            const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+            double sc;
+            if (DT == 0) {
+                const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
+                const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r);
+                RescoreAcc a;
+                a.n11 = a.n1x = a.nx1 = 0;
+                for (int i = i0; i < i1; ++i) {
+                    const unsigned int sb = s[i] != 0, rb = r[i + d] != 0;
+                    a.n11 += sb & rb;
+                    a.n1x += sb;
+                    a.nx1 += rb;
+                }
+                sc = exact_score(cd, a, d, 0);
+            } else {
+                const float* s = reinterpret_cast<const float*>(cd.s);
+                const float* r = reinterpret_cast<const float*>(cd.r);
+                sc = 0.0;
+                for (int i = i0; i < i1; ++i) sc += (2.0 * (double)s[i] - 1.0) * (2.0 * (double)r[i + d] - 1.0);
+            }
+            if (sc > bs || (sc == bs && d > bd)) {
+                bs = sc;
+                bd = d;
+            }
+        }
+    }
+    s_sc[threadIdx.x] = bs;
+    s_d[threadIdx.x] = bd;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            const double os = s_sc[threadIdx.x + st];
+            const int od = s_d[threadIdx.x + st];
+            if (os > s_sc[threadIdx.x] || (os == s_sc[threadIdx.x] && od > s_d[threadIdx.x])) {
+                s_sc[threadIdx.x] = os;
+                s_d[threadIdx.x] = od;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        CandResult r;
+        if (s_d[0] == INT32_MIN) {
+            r.score = -INFINITY;
+            r.offset = (long long)cd.n_ref - 1 - cd.S;
+            r.score_f32 = -INFINITY;
+            r.flags = 1 | 8;
+        } else {
+            r.score = s_sc[0];
+            r.offset = s_d[0];
+            r.score_f32 = (float)s_sc[0];
+            r.flags = 8;
+        }
+        out[ci] = r;
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// VAD frame-energy sweep.  One wave per frame per iteration; lanes read 16 B (8 samples) each.
+// speech  <=>  sum(x^2) >= thr_lin * n   (== 10*log10(mean x^2) >= thr_db, evaluated exactly in
+// integers/fp64), n = samples in the frame (the last frame may be short).
+__global__ __launch_bounds__(256) void k_vad_energy(const int16_t* __restrict__ pcm, long long n_samples, int frame_len,
+                                                    long long n_frames, double thr_lin, float non_speech,
+                                                    float* __restrict__ labels) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x / 64);
+    const long long nwaves = (long long)gridDim.x * (blockDim.x / 64);
+    const bool vec_ok = (frame_len % 8 == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+    for (long long f = wave0; f < n_frames; f += nwaves) {
+        const long long s0 = f * frame_len;
+        const long long s1 = (s0 + frame_len) < n_samples ? (s0 + frame_len) : n_samples;
+        const int n = (int)(s1 - s0);
+        unsigned long long acc = 0;
+        if (vec_ok && n == frame_len) {
+            const int nvec = frame_len / 8;
+            const int4* p = reinterpret_cast<const int4*>(pcm + s0);
+            for (int i = lane; i < nvec; i += 64) {
+                const int4 w = p[i];
+                const int ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int lo = (int)(short)(ws[k] & 0xffff), hi = ws[k] >> 16;
+                    acc += (unsigned long long)(lo * lo) + (unsigned long long)((long long)hi * hi);
+                }
+            }
+        } else {
+            for (int i = lane; i < n; i += 64) {
+                const long long x = pcm[s0 + i];
+                acc += (unsigned long long)(x * x);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+        if (lane == 0) labels[f] = ((double)acc >= thr_lin * (double)n) ? 1.0f : non_speech;
+    }
+}
+
+__global__ void k_bounds_init(long long* b) {
+    b[0] = 0x7fffffffffffffffLL;
+    b[1] = -1;
+}
+__global__ __launch_bounds__(256) void k_speech_bounds(const float* __restrict__ x, long long n, long long* b) {
+    long long lo = 0x7fffffffffffffffLL, hi = -1;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        if (x[i] > 0.5f) {
+            lo = lo < i ? lo : i;
+            hi = hi > i ? hi : i;
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const long long ol = __shfl_xor(lo, sft, 64), oh = __shfl_xor(hi, sft, 64);
+        lo = lo < ol ? lo : ol;
+        hi = hi > oh ? hi : oh;
+    }
+    if ((threadIdx.x & 63) == 0 && hi >= 0) {
+        atomicMin(reinterpret_cast<long long*>(&b[0]), lo);
+        atomicMax(reinterpret_cast<long long*>(&b[1]), hi);
+    }
+}
+__global__ void k_bounds_fix(long long* b) {
+    if (b[1] < 0) b[0] = -1;
+}
+
+}  // namespace ffsa

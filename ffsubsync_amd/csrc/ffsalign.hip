@@ -1,0 +1,628 @@
+// ffsalign.hip -- host side of libffsalign.so: plans, descriptor building, kernel dispatch and
+// the extern "C" entry points declared in include/ffsubsync_amd.h.
+//
+// Written for gfx950 (MI355X) only: hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ffsubsync_amd.h"
+#include "ffs_kernels.h"
+
+using namespace ffsa;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) return fail(FFS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
+constexpr int64_t kMaxFftN = 1 << 24;
+
+int ilog2(int64_t x) {
+    int p = 0;
+    while ((int64_t(1) << p) < x) ++p;
+    return p;
+}
+
+// column-tile width for a column transform of length L
+int tile_cols(int L) {
+    if (L <= 16) return 256;
+    if (L <= 128) return 4096 / L;
+    if (L <= 1024) return 16;
+    if (L == 2048) return 8;
+    return 4;
+}
+
+size_t col_lds_bytes(int L) {
+    size_t t = (L > 16) ? (size_t)L * tile_cols(L) * sizeof(cf) : 0;
+    return t < 1024 ? 1024 : t;
+}
+size_t row_lds_bytes(int L) {
+    const int rows = 256 / (L / 16);
+    return (size_t)rows * (L + L / 32) * sizeof(cf);
+}
+
+// stage tables of Shape<L>: [R1][16] then [R2][256], entry (r, jm) = exp(-2*pi*i*r*jm/(Ns*R))
+std::vector<cf> make_stage_tables(int L) {
+    const int LT = L / 16;
+    const int R1 = LT >= 16 ? 16 : LT;
+    const int R2 = L / (16 * R1);
+    std::vector<cf> t;
+    auto add = [&](int R, int Ns) {
+        for (int r = 0; r < R; ++r)
+            for (int jm = 0; jm < Ns; ++jm) {
+                const double a = -2.0 * M_PI * (double)r * (double)jm / ((double)Ns * (double)R);
+                t.push_back(make_float2((float)cos(a), (float)sin(a)));
+            }
+    };
+    if (R1 > 1) add(R1, 16);
+    if (R2 > 1) add(R2, 256);
+    if (t.empty()) t.push_back(make_float2(1.f, 0.f));
+    return t;
+}
+
+cf wn(int64_t N, int64_t p) {
+    p %= N;
+    const double a = -2.0 * M_PI * (double)p / (double)N;
+    return make_float2((float)cos(a), (float)sin(a));
+}
+
+}  // namespace
+
+struct ffs_plan {
+    int device = 0;
+    int64_t N = 0;
+    int N1 = 0, N2 = 0, C = 0, log2C = 0;
+    int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
+    bool direct_only = false;
+    // device tables
+    cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
+    cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
+    cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
+    cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
+    BlockNom* bnom = nullptr;                 // [pairs_in_flight*n_packed*2][tiles]
+    // per-call descriptor storage (grown on demand)
+    void* dev_desc = nullptr;
+    size_t dev_desc_bytes = 0;
+    void* host_desc = nullptr;                // pinned
+    size_t host_desc_bytes = 0;
+    hipEvent_t upload_done = nullptr;
+    int64_t workspace_bytes = 0;
+    // optional per-kernel event timing
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;            // reusable events
+    size_t ev_used = 0;
+    std::vector<std::pair<int, std::pair<hipEvent_t, hipEvent_t>>> ev_spans;  // (kernel id, (start, stop))
+};
+
+namespace {
+
+template <class T>
+int upload(T** dst, const std::vector<T>& src, int64_t* total) {
+    HIP_TRY(hipMalloc((void**)dst, src.size() * sizeof(T)));
+    HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    *total += (int64_t)(src.size() * sizeof(T));
+    return FFS_OK;
+}
+
+int ensure_desc(ffs_plan* p, size_t bytes) {
+    if (bytes <= p->dev_desc_bytes) return FFS_OK;
+    if (p->upload_done) HIP_TRY(hipEventSynchronize(p->upload_done));
+    if (p->dev_desc) HIP_TRY(hipFree(p->dev_desc));
+    if (p->host_desc) HIP_TRY(hipHostFree(p->host_desc));
+    p->dev_desc = nullptr;
+    p->host_desc = nullptr;
+    p->dev_desc_bytes = p->host_desc_bytes = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    HIP_TRY(hipMalloc(&p->dev_desc, cap));
+    HIP_TRY(hipHostMalloc(&p->host_desc, cap, hipHostMallocDefault));
+    p->dev_desc_bytes = p->host_desc_bytes = cap;
+    return FFS_OK;
+}
+
+hipEvent_t prof_event(ffs_plan* p) {
+    if (p->ev_used == p->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        p->ev_pool.push_back(e);
+    }
+    return p->ev_pool[p->ev_used++];
+}
+
+// RAII span: records start now and stop at scope exit when profiling is on
+struct ProfSpan {
+    ffs_plan* p;
+    hipStream_t st;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfSpan(ffs_plan* p_, hipStream_t st_, int id_) : p(p_), st(st_), id(id_) {
+        if (!p->profiling) return;
+        a = prof_event(p);
+        b = prof_event(p);
+        if (a && b) (void)hipEventRecord(a, st);
+    }
+    ~ProfSpan() {
+        if (a && b) {
+            (void)hipEventRecord(b, st);
+            p->ev_spans.push_back({id, {a, b}});
+        }
+    }
+};
+
+// ---- kernel dispatch -------------------------------------------------------------------------
+template <int L, int C, int DT>
+int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = col_lds_bytes(L);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_a<L, C, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(p->N2 / C, n_xf);
+    hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
+                       p->tw1, p->tbA, p->tsA);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+template <int DT>
+int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, hipStream_t st) {
+    switch (p->N1) {
+        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, st);
+        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, st);
+        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, st);
+        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, st);
+        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, st);
+        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, st);
+        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, st);
+        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, st);
+        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, st);
+    }
+    return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
+}
+
+template <int L>
+int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = row_lds_bytes(L);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mid<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    constexpr int ROWS = 256 / (L / 16);
+    dim3 grid(p->N1 / ROWS, n_pairs);
+    // work is laid out with max_slots per pair; the kernel strides by n_slots, so callers keep them equal
+    hipLaunchKernelGGL((k_mid<L>), grid, dim3(256), lds, st, p->work, p->N1, p->log2C, (long long)p->N, n_slots,
+                       (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
+    switch (p->N2) {
+        case 256: return launch_mid_inst<256>(p, n_pairs, n_slots, st);
+        case 512: return launch_mid_inst<512>(p, n_pairs, n_slots, st);
+        case 1024: return launch_mid_inst<1024>(p, n_pairs, n_slots, st);
+        case 2048: return launch_mid_inst<2048>(p, n_pairs, n_slots, st);
+        case 4096: return launch_mid_inst<4096>(p, n_pairs, n_slots, st);
+    }
+    return fail(FFS_E_INVALID, "unsupported row length %d", p->N2);
+}
+
+template <int L, int C, bool WRITE>
+int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
+                       int n_pairs, float* out_a, float* out_b, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = col_lds_bytes(L);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c<L, C, WRITE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(p->N2 / C, n_pairs * n_packed);
+    hipLaunchKernelGGL((k_pass_c<L, C, WRITE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
+                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+template <bool WRITE>
+int launch_pass_c(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
+                  int n_pairs, float* out_a, float* out_b, hipStream_t st) {
+#define FFS_PC(L, C) \
+    case L: return launch_pass_c_inst<L, C, WRITE>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, out_a, out_b, st)
+    switch (p->N1) {
+        FFS_PC(16, 256);
+        FFS_PC(32, 128);
+        FFS_PC(64, 64);
+        FFS_PC(128, 32);
+        FFS_PC(256, 16);
+        FFS_PC(512, 16);
+        FFS_PC(1024, 16);
+        FFS_PC(2048, 8);
+        FFS_PC(4096, 4);
+    }
+#undef FFS_PC
+    return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
+}
+
+// Python slice semantics of  x[:stop] = v  /  x[start:] = v  on a length-n array
+int64_t py_clamp(int64_t i, int64_t n) {
+    if (i < 0) i += n;
+    if (i < 0) i = 0;
+    if (i > n) i = n;
+    return i;
+}
+
+double mapped(double x) { return 2.0 * x - 1.0; }  // aligners.py:55-57
+
+struct VecView {
+    const void* ptr;
+    int64_t len;
+    double lo, hi;
+};
+
+// Fill the candidate descriptor for (ref, sub); returns a negative code on error.
+int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd) {
+    const int64_t R = ref.len, S = sub.len;
+    if (R <= 0 || S <= 0)
+        return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
+                    (long long)R, (long long)S);
+    const int64_t n_ref = ffs_fft_length(R, S);
+    if (R + S > p->N || n_ref > p->N)
+        return fail(FFS_E_TOO_LONG, "R+S=%lld needs transform length %lld > plan length %lld", (long long)(R + S),
+                    (long long)n_ref, (long long)p->N);
+    memset(cd, 0, sizeof *cd);
+    cd->s = sub.ptr;
+    cd->r = ref.ptr;
+    cd->S = (int32_t)S;
+    cd->R = (int32_t)R;
+    cd->n_ref = (int32_t)n_ref;
+    // lag window in k-space (aligners.py:31-43), then mapped to d = n_ref-1-S-k
+    int64_t kA = 0, kB = n_ref;
+    if (max_off >= 0) {
+        kA = py_clamp(n_ref - 1 - max_off - S, n_ref);
+        kB = py_clamp(n_ref - 1 + max_off - S, n_ref);
+    }
+    if (kA >= kB) {
+        cd->flags = FFS_FLAG_EMPTY_WINDOW;
+        cd->d_lo = 0;
+        cd->d_hi = -1;
+    } else {
+        cd->d_hi = (int32_t)(n_ref - 1 - S - kA);
+        cd->d_lo = (int32_t)(n_ref - S - kB);
+    }
+    cd->s0 = mapped(sub.lo);
+    cd->s1 = mapped(sub.hi);
+    cd->r0 = mapped(ref.lo);
+    cd->r1 = mapped(ref.hi);
+    const double as = fmax(fabs(cd->s0), fabs(cd->s1)), ar = fmax(fabs(cd->r0), fabs(cd->r1));
+    const double lg = (double)ilog2(p->N > 2 ? p->N : 2);
+    cd->margin = (float)(4.0 * 5.9604645e-08 * lg * sqrt((double)S * (double)R) * as * ar);
+    return FFS_OK;
+}
+
+void fill_xform(XformDesc* x, const VecView* a, const VecView* b) {
+    memset(x, 0, sizeof *x);
+    x->a = a->ptr;
+    x->len_a = (int32_t)a->len;
+    x->a0 = (float)mapped(a->lo);
+    x->a1 = (float)mapped(a->hi);
+    if (b) {
+        x->b = b->ptr;
+        x->len_b = (int32_t)b->len;
+        x->b0 = (float)mapped(b->lo);
+        x->b1 = (float)mapped(b->hi);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ffs_last_error(void) { return g_err.c_str(); }
+int ffs_version(void) { return 100; }
+
+int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len) {
+    if (ref_len <= 0 || sub_len <= 0) return 0;
+    // aligners.py:67-68: int(2 ** math.ceil(math.log(R + S, 2))) -- math.log(x, 2) is
+    // log(x)/log(2) in doubles, which is not exact at every power of two; keep the same quirk.
+    const double bits = log((double)(ref_len + sub_len)) / log(2.0);
+    return (int64_t)pow(2.0, ceil(bits));
+}
+
+int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand, ffs_plan** out) {
+    if (!out) return fail(FFS_E_INVALID, "out is null");
+    *out = nullptr;
+    if (n_fft < 2 || n_fft > kMaxFftN || (n_fft & (n_fft - 1)))
+        return fail(FFS_E_INVALID, "n_fft must be a power of two in [2, 2^24], got %lld", (long long)n_fft);
+    if (pairs_in_flight < 1 || max_cand < 1) return fail(FFS_E_INVALID, "pairs_in_flight and max_cand must be >= 1");
+    HIP_TRY(hipSetDevice(device));
+    ffs_plan* p = new ffs_plan();
+    p->device = device;
+    p->N = n_fft;
+    p->pairs_in_flight = pairs_in_flight;
+    p->max_cand = max_cand;
+    p->max_slots = 1 + (max_cand + 1) / 2;
+    HIP_TRY(hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
+    if (n_fft < kMinFftN) {
+        p->direct_only = true;
+        *out = p;
+        return FFS_OK;
+    }
+    const int lg = ilog2(n_fft);
+    const int lg2 = lg - 4 < 12 ? lg - 4 : 12;
+    p->N2 = 1 << lg2;
+    p->N1 = (int)(n_fft >> lg2);
+    p->C = tile_cols(p->N1);
+    p->log2C = ilog2(p->C);
+    const int64_t N = n_fft;
+    const int N1 = p->N1, N2 = p->N2, LT1 = N1 / 16, LT2 = N2 / 16;
+    int rc;
+    if ((rc = upload(&p->tw1, make_stage_tables(N1), &p->workspace_bytes))) return rc;
+    if ((rc = upload(&p->tw2, make_stage_tables(N2), &p->workspace_bytes))) return rc;
+    {
+        std::vector<cf> tb((size_t)LT1 * N2), ts((size_t)16 * N2);
+        for (int u = 0; u < LT1; ++u)
+            for (int n2 = 0; n2 < N2; ++n2) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * u);
+        for (int q = 0; q < 16; ++q)
+            for (int n2 = 0; n2 < N2; ++n2) ts[(size_t)q * N2 + n2] = wn(N, (int64_t)n2 * LT1 * q);
+        if ((rc = upload(&p->tbA, tb, &p->workspace_bytes))) return rc;
+        if ((rc = upload(&p->tsA, ts, &p->workspace_bytes))) return rc;
+    }
+    {
+        std::vector<cf> tb((size_t)N1 * LT2), ts((size_t)N1 * 16);
+        for (int k1 = 0; k1 < N1; ++k1) {
+            for (int u = 0; u < LT2; ++u) tb[(size_t)k1 * LT2 + u] = wn(N, (int64_t)k1 * u);
+            for (int q = 0; q < 16; ++q) ts[(size_t)k1 * 16 + q] = wn(N, (int64_t)k1 * LT2 * q);
+        }
+        if ((rc = upload(&p->tbM, tb, &p->workspace_bytes))) return rc;
+        if ((rc = upload(&p->tsM, ts, &p->workspace_bytes))) return rc;
+    }
+    const size_t work_bytes = (size_t)pairs_in_flight * p->max_slots * N * sizeof(cf);
+    HIP_TRY(hipMalloc((void**)&p->work, work_bytes));
+    p->workspace_bytes += (int64_t)work_bytes;
+    const size_t bn_bytes = (size_t)pairs_in_flight * (p->max_slots - 1) * 2 * (N2 / p->C) * sizeof(BlockNom);
+    HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
+    p->workspace_bytes += (int64_t)bn_bytes;
+    *out = p;
+    return FFS_OK;
+}
+
+int ffs_plan_destroy(ffs_plan* p) {
+    if (!p) return FFS_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(p->tw1);
+    (void)hipFree(p->tw2);
+    (void)hipFree(p->tbA);
+    (void)hipFree(p->tsA);
+    (void)hipFree(p->tbM);
+    (void)hipFree(p->tsM);
+    (void)hipFree(p->work);
+    (void)hipFree(p->bnom);
+    (void)hipFree(p->dev_desc);
+    if (p->host_desc) (void)hipHostFree(p->host_desc);
+    if (p->upload_done) (void)hipEventDestroy(p->upload_done);
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    delete p;
+    return FFS_OK;
+}
+
+int64_t ffs_plan_workspace_bytes(const ffs_plan* p) { return p ? p->workspace_bytes : 0; }
+
+int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void* const* vec_ptr,
+                    const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
+                    int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                    void* hip_stream) {
+    if (!p) return fail(FFS_E_INVALID, "plan is null");
+    if (n_pairs < 0 || n_cand < 1 || n_cand > p->max_cand)
+        return fail(FFS_E_INVALID, "n_cand=%d outside [1, plan max_cand=%d]", n_cand, p->max_cand);
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32) return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
+    if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
+        return fail(FFS_E_INVALID, "null argument");
+    if (n_pairs == 0) return FFS_OK;
+    static_assert(sizeof(CandResult) == sizeof(ffs_cand_result), "ABI struct mismatch");
+    static_assert(sizeof(PairResult) == sizeof(ffs_pair_result), "ABI struct mismatch");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(p->device));
+
+    const int n_packed = (n_cand + 1) / 2;
+    const int n_slots = 1 + n_packed;
+    const size_t n_cands = (size_t)n_pairs * n_cand;
+    const size_t n_xf = (size_t)n_pairs * n_slots;
+    // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
+    const size_t o_cand = 0;
+    const size_t o_xf = o_cand + n_cands * sizeof(CandDesc);
+    const size_t host_bytes = o_xf + n_xf * sizeof(XformDesc);
+    const size_t o_nom = (host_bytes + 255) & ~(size_t)255;
+    const size_t o_acc = o_nom + n_cands * sizeof(NomList);
+    const size_t total = o_acc + n_cands * KNOM * sizeof(RescoreAcc);
+    int rc;
+    if ((rc = ensure_desc(p, total))) return rc;
+    HIP_TRY(hipEventSynchronize(p->upload_done));  // previous call's upload has left the pinned buffer
+    char* hb = (char*)p->host_desc;
+    CandDesc* hc = (CandDesc*)(hb + o_cand);
+    XformDesc* hx = (XformDesc*)(hb + o_xf);
+    const int stride = 1 + n_cand;
+    for (int pi = 0; pi < n_pairs; ++pi) {
+        const size_t b = (size_t)pi * stride;
+        VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
+        std::vector<VecView> subs(n_cand);
+        for (int j = 0; j < n_cand; ++j) {
+            subs[j] = VecView{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
+            if (!ref.ptr || !subs[j].ptr) {
+                if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
+            }
+            if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
+        }
+        fill_xform(&hx[(size_t)pi * n_slots], &ref, nullptr);
+        for (int k = 0; k < n_packed; ++k)
+            fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
+    }
+    char* db = (char*)p->dev_desc;
+    HIP_TRY(hipMemcpyAsync(db, hb, host_bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(p->upload_done, st));
+    const CandDesc* dc = (const CandDesc*)(db + o_cand);
+    const XformDesc* dx = (const XformDesc*)(db + o_xf);
+    NomList* dn = (NomList*)(db + o_nom);
+    RescoreAcc* da = (RescoreAcc*)(db + o_acc);
+    CandResult* cres = (CandResult*)cand_out_dev;
+    PairResult* pres = (PairResult*)pair_out_dev;
+
+    if (p->direct_only) {
+        if (dtype == FFS_DTYPE_U8)
+            hipLaunchKernelGGL((k_direct<0>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres);
+        else
+            hipLaunchKernelGGL((k_direct<1>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres);
+        HIP_TRY(hipGetLastError());
+    } else {
+        HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc), st));
+        const int tiles = p->N2 / p->C;
+        for (int p0 = 0; p0 < n_pairs; p0 += p->pairs_in_flight) {
+            const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
+            const int first_cand = p0 * n_cand;
+            {
+                ProfSpan sp(p, st, FFS_K_PASS_A);
+                if (dtype == FFS_DTYPE_U8)
+                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * n_slots, np * n_slots, st);
+                else
+                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * n_slots, np * n_slots, st);
+            }
+            if (rc) return rc;
+            {
+                ProfSpan sp(p, st, FFS_K_MID);
+                rc = launch_mid(p, np, n_slots, st);
+            }
+            if (rc) return rc;
+            {
+                ProfSpan sp(p, st, FFS_K_PASS_C);
+                rc = launch_pass_c<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, st);
+            }
+            if (rc) return rc;
+            {
+                ProfSpan sp(p, st, FFS_K_NOMINEES);
+                hipLaunchKernelGGL(k_nominees, dim3(np * n_cand), dim3(64), 0, st, p->bnom, tiles, n_cand, n_packed, dc,
+                                   dn, first_cand);
+            }
+            HIP_TRY(hipGetLastError());
+            {
+                ProfSpan sp(p, st, FFS_K_RESCORE);
+                if (dtype == FFS_DTYPE_U8)
+                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, KNOM, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                                       first_cand);
+                else
+                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, KNOM, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                                       first_cand);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
+                           (int)n_cands, dtype);
+        HIP_TRY(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
+                       (long long)filter_max_offset);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_len, double ref_lo, double ref_hi,
+                       const void* a_dev, int64_t a_len, double a_lo, double a_hi, const void* b_dev, int64_t b_len,
+                       double b_lo, double b_hi, float* out_a_dev, float* out_b_dev, void* hip_stream) {
+    if (!p || p->direct_only) return fail(FFS_E_INVALID, "plan has no FFT path (n_fft < %lld)", (long long)kMinFftN);
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32) return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
+    if (!ref_dev || !a_dev || ref_len <= 0 || a_len <= 0) return fail(FFS_E_EMPTY, "empty reference or candidate");
+    if (ref_len > p->N || a_len > p->N || (b_dev && b_len > p->N)) return fail(FFS_E_TOO_LONG, "vector longer than n_fft");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    if ((rc = ensure_desc(p, 4096))) return rc;
+    HIP_TRY(hipEventSynchronize(p->upload_done));
+    XformDesc* hx = (XformDesc*)p->host_desc;
+    VecView r{ref_dev, ref_len, ref_lo, ref_hi}, a{a_dev, a_len, a_lo, a_hi}, b{b_dev, b_len, b_lo, b_hi};
+    fill_xform(&hx[0], &r, nullptr);
+    fill_xform(&hx[1], &a, b_dev ? &b : nullptr);
+    HIP_TRY(hipMemcpyAsync(p->dev_desc, hx, 2 * sizeof(XformDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(p->upload_done, st));
+    const XformDesc* dx = (const XformDesc*)p->dev_desc;
+    if (dtype == FFS_DTYPE_U8)
+        rc = launch_pass_a<0>(p, dx, 2, st);
+    else
+        rc = launch_pass_a<1>(p, dx, 2, st);
+    if (rc) return rc;
+    if ((rc = launch_mid(p, 1, 2, st))) return rc;
+    return launch_pass_c<true>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, st);
+}
+
+int ffs_plan_profile(ffs_plan* p, int enable) {
+    if (!p) return fail(FFS_E_INVALID, "plan is null");
+    p->profiling = enable != 0;
+    return FFS_OK;
+}
+
+int ffs_plan_profile_read(ffs_plan* p, double* ms_total, int64_t* launches) {
+    if (!p || !ms_total || !launches) return fail(FFS_E_INVALID, "null argument");
+    for (auto& sp : p->ev_spans) {
+        HIP_TRY(hipEventSynchronize(sp.second.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sp.second.first, sp.second.second));
+        ms_total[sp.first] += (double)ms;
+        launches[sp.first] += 1;
+    }
+    p->ev_spans.clear();
+    p->ev_used = 0;
+    return FFS_OK;
+}
+
+int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len, double energy_threshold_db,
+                   float non_speech_label, float* labels_dev, void* hip_stream) {
+    if (n_samples < 0 || frame_len < 1) return fail(FFS_E_INVALID, "bad n_samples/frame_len");
+    if (n_samples == 0) return FFS_OK;
+    if (!pcm_dev || !labels_dev) return fail(FFS_E_INVALID, "null device pointer");
+    const long long n_frames = (n_samples + frame_len - 1) / frame_len;
+    const double thr_lin = pow(10.0, energy_threshold_db / 10.0);
+    long long blocks = (n_frames + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_vad_energy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, pcm_dev,
+                       (long long)n_samples, frame_len, n_frames, thr_lin, non_speech_label, labels_dev);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev, void* hip_stream) {
+    if (!bounds_dev || (n_frames > 0 && !frames_dev) || n_frames < 0) return fail(FFS_E_INVALID, "bad argument");
+    hipStream_t st = (hipStream_t)hip_stream;
+    hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(1), 0, st, (long long*)bounds_dev);
+    if (n_frames > 0) {
+        long long blocks = (n_frames + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_speech_bounds, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, (long long)n_frames,
+                           (long long*)bounds_dev);
+    }
+    hipLaunchKernelGGL(k_bounds_fix, dim3(1), dim3(1), 0, st, (long long*)bounds_dev);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+}  // extern "C"

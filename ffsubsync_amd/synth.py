@@ -1,0 +1,117 @@
+"""Seeded synthetic workloads for the alignment hot path.
+
+Speech-like activity vectors at 100 Hz and the subtitle tracks derived from them, rasterised with
+the reference's own conventions (SubtitleScaler + SubtitleSpeechTransformer,
+ffsubsync/subtitle_transformers.py:35-47, speech_transformers.py:957-980): start =
+int(round(t0*sr)), end = start + int(round(dur*sr)), length int(max_end*sr)+2, amplitude
+min(1/ratio, 1).  Run lists come from ``numpy.random.RandomState(seed)`` on the host; only the
+rasterisation runs where the data is needed (numpy, or torch on the GPU for the benchmark batch).
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from .constants import SAMPLE_RATE, candidate_ratios
+
+
+@dataclass
+class PairSpec:
+    """Interval lists (frame indices) of one (reference, candidates) problem."""
+
+    seed: int
+    ref_len: int
+    ref_starts: np.ndarray
+    ref_ends: np.ndarray
+    cand_len: List[int]
+    cand_starts: List[np.ndarray]
+    cand_ends: List[np.ndarray]
+    cand_amp: List[float]
+    ratios: List[float]
+    true_offset_samples: int
+    true_ratio_index: int
+
+
+def _speech_runs(rng: np.random.RandomState, duration_s: float):
+    """Alternate gaps U[0.2, 8] s and speech runs U[0.5, 6] s until the duration is used up."""
+    n_max = int(duration_s / 0.7) + 8
+    gaps = rng.uniform(0.2, 8.0, n_max)
+    runs = rng.uniform(0.5, 6.0, n_max)
+    ends = np.cumsum(gaps + runs)
+    starts = ends - runs
+    keep = ends < duration_s
+    return starts[keep], ends[keep]
+
+
+def make_pair_spec(seed: int, duration_s: float = 7200.0, ratios: Optional[Sequence[float]] = None,
+                   max_true_offset_s: float = 55.0, sample_rate: int = SAMPLE_RATE) -> PairSpec:
+    ratios = list(candidate_ratios() if ratios is None else ratios)
+    rng = np.random.RandomState(seed)
+    t0, t1 = _speech_runs(rng, duration_s)
+    ref_len = int(round(duration_s * sample_rate))
+    rs = np.rint(t0 * sample_rate).astype(np.int64)
+    re = np.minimum(rs + np.rint((t1 - t0) * sample_rate).astype(np.int64), ref_len)
+    true_offset_s = float(np.round(rng.uniform(-max_true_offset_s, max_true_offset_s), 2))
+    true_idx = int(rng.randint(len(ratios)))
+    true_ratio = ratios[true_idx]
+    keep = rng.rand(t0.size) > 0.15
+    js = rng.uniform(-0.1, 0.1, t0.size)
+    je = rng.uniform(-0.1, 0.1, t0.size)
+    # subtitle clock: t_ref = t_sub * true_ratio + true_offset
+    s0 = (t0 + js - true_offset_s) / true_ratio
+    s1 = (t1 + je - true_offset_s) / true_ratio
+    ok = keep & (s0 >= 0.0) & (s1 > s0)
+    s0, s1 = s0[ok], s1[ok]
+    cand_len, cand_starts, cand_ends, cand_amp = [], [], [], []
+    for ratio in ratios:
+        a0, a1 = s0 * ratio, s1 * ratio  # SubtitleScaler (subtitle_transformers.py:35-47)
+        n = int(a1.max() * sample_rate) + 2 if a1.size else 2  # speech_transformers.py:962
+        st = np.rint(a0 * sample_rate).astype(np.int64)
+        en = np.minimum(st + np.rint((a1 - a0) * sample_rate).astype(np.int64), n)
+        cand_len.append(n)
+        cand_starts.append(st)
+        cand_ends.append(en)
+        cand_amp.append(min(1.0 / ratio, 1.0))  # speech_transformers.py:977
+    return PairSpec(seed, ref_len, rs, re, cand_len, cand_starts, cand_ends, cand_amp, ratios,
+                    int(round(true_offset_s * sample_rate)), true_idx)
+
+
+def rasterize(n: int, starts: np.ndarray, ends: np.ndarray) -> np.ndarray:
+    """0/1 uint8 vector with [start, end) set for every interval (union on overlap)."""
+    delta = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(delta, np.clip(starts, 0, n), 1)
+    np.add.at(delta, np.clip(ends, 0, n), -1)
+    return (np.cumsum(delta[:-1]) > 0).astype(np.uint8)
+
+
+def pair_arrays(spec: PairSpec):
+    """(ref01 uint8, [cand01 uint8 ...]) on the host."""
+    ref = rasterize(spec.ref_len, spec.ref_starts, spec.ref_ends)
+    cands = [rasterize(n, s, e) for n, s, e in zip(spec.cand_len, spec.cand_starts, spec.cand_ends)]
+    return ref, cands
+
+
+def pair_float_arrays(spec: PairSpec):
+    """The float64 arrays the reference pipeline would hand the aligner: reference 0/1,
+    candidate j in {0, min(1/ratio_j, 1)}."""
+    ref, cands = pair_arrays(spec)
+    return ref.astype(float), [c.astype(float) * a for c, a in zip(cands, spec.cand_amp)]
+
+
+def simple_pair(n_ref: int, n_sub: int, offset: int, seed: int = 0, density: float = 0.4, flip: float = 0.05):
+    """A random 0/1 reference and a noisy copy of a window of it, so that the best offset is
+    ``offset``: sub[i] ~ ref[i + offset].  (BASELINE config 1: n=60000, offset=+3720.)"""
+    rng = np.random.RandomState(seed)
+    # piecewise-constant 'speech' so neighbouring lags are not independent
+    seg = np.maximum(1, rng.geometric(1.0 / 150.0, size=n_ref // 50 + 16))
+    vals = (rng.rand(seg.size) < density).astype(np.uint8)
+    ref = np.repeat(vals, seg)[:n_ref]
+    if ref.size < n_ref:
+        ref = np.concatenate([ref, np.zeros(n_ref - ref.size, np.uint8)])
+    idx = np.arange(n_sub) + offset
+    ok = (idx >= 0) & (idx < n_ref)
+    sub = np.zeros(n_sub, np.uint8)
+    sub[ok] = ref[idx[ok]]
+    noise = rng.rand(n_sub) < flip
+    sub = np.where(noise, 1 - sub, sub).astype(np.uint8)
+    return ref, sub

@@ -1,0 +1,147 @@
+/*
+ * ffsubsync_amd.h -- C ABI of libffsalign.so, the MI355X (gfx950) implementation of
+ * ffsubsync's alignment hot path.
+ *
+ * The reference (smacke/ffsubsync) is pure Python and has no FFI of its own for this path;
+ * each entry point below names the reference interface (file:line under
+ * /root/reference/ffsubsync/) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative FFS_E_* code; nothing throws across
+ *     the ABI; ffs_last_error() returns a thread-local message for the last failure.
+ *   - "_dev" pointers are device (HBM) addresses owned by the caller (e.g. torch tensors'
+ *     data_ptr()); all other pointers are host memory.  `hip_stream` is a hipStream_t
+ *     (0 = the null stream).  Calls are asynchronous with respect to the host unless stated;
+ *     results land in caller-owned device buffers in stream order.
+ *   - a plan owns its twiddle tables and workspace in HBM and may be used by one host thread
+ *     at a time.
+ */
+#ifndef FFSUBSYNC_AMD_H
+#define FFSUBSYNC_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFS_OK 0
+#define FFS_E_INVALID (-1) /* bad argument */
+#define FFS_E_HIP (-2)     /* a HIP runtime call failed */
+#define FFS_E_NOMEM (-3)
+#define FFS_E_TOO_LONG (-4) /* R+S exceeds the plan's transform length */
+#define FFS_E_EMPTY (-5)    /* empty reference or candidate (aligners.py:58-66) */
+
+/* element types of the activity vectors */
+#define FFS_DTYPE_U8 0  /* two-level signal: byte==0 -> lo, byte!=0 -> hi  */
+#define FFS_DTYPE_F32 1 /* arbitrary float samples (lo/hi = bounds, used for the tie margin) */
+
+/* result flags */
+#define FFS_FLAG_EMPTY_WINDOW 1 /* every lag masked: score=-inf, offset=N-1-S (aligners.py:45-48) */
+#define FFS_FLAG_AMBIGUOUS 2    /* more near-ties than the nominee list holds; best of list returned */
+#define FFS_FLAG_FILTERED 4     /* |offset| > filter_max_offset: dropped by MaxScoreAligner.transform */
+#define FFS_FLAG_DIRECT 8       /* solved by the exact direct-correlation kernel (short inputs) */
+
+typedef struct ffs_plan ffs_plan;
+
+/* One FFTAligner solve: FFTAligner.best_score_ / best_offset_ (aligners.py:45-48). */
+typedef struct ffs_cand_result {
+    double score;    /* correlation at `offset`, re-evaluated exactly (integer counts for
+                        two-level inputs, fp64 dot product for float inputs) */
+    int64_t offset;  /* samples; subtitle must be shifted by +offset/sample_rate seconds */
+    float score_f32; /* the fp32 FFT's value at that lag (diagnostic) */
+    int32_t flags;
+} ffs_cand_result;
+
+/* One MaxScoreAligner solve: the winning ((score, offset), candidate) (aligners.py:154-167). */
+typedef struct ffs_pair_result {
+    double score;
+    int64_t offset;
+    int32_t best_cand; /* index into the pair's candidate list; -1 = none survived the filter */
+    int32_t flags;
+} ffs_pair_result;
+
+/* Smallest transform length the reference would use for these lengths:
+ * 2**ceil(log2(R+S)) (aligners.py:67-68).  Returns 0 if either length is <= 0. */
+int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len);
+
+/* Create a plan for transform length n_fft (power of two, 2 <= n_fft <= 2^24) on `device`.
+ * pairs_in_flight: how many (reference, candidates) problems share one sweep of the
+ * A/mid/C kernels (sizes the workspace: pairs_in_flight * (1+ceil(max_cand/2)) * n_fft * 8 B).
+ * Replaces: the per-call np.fft plan + temporaries of FFTAligner.fit (aligners.py:67-74). */
+int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand, ffs_plan** out);
+int ffs_plan_destroy(ffs_plan* plan);
+int64_t ffs_plan_workspace_bytes(const ffs_plan* plan);
+
+/* Batched MaxScoreAligner(FFTAligner).fit(...).transform() over n_pairs independent problems,
+ * each one reference vector and n_cand candidate vectors (aligners.py:50-80, 131-167).
+ *
+ * Vectors are listed pair-major: index p*(1+n_cand) is pair p's reference, the next n_cand
+ * entries its candidates.  vec_ptr[i] is a DEVICE pointer to vec_len[i] elements of `dtype`;
+ * vec_lo/vec_hi give the two sample values of a FFS_DTYPE_U8 vector *before* the reference's
+ * 2*x-1 map (aligners.py:55-57), e.g. (0, 1) for a 0/1 vector or (0, 1/ratio) for a subtitle
+ * track rasterised at a framerate ratio > 1 (speech_transformers.py:977).
+ *
+ * max_offset_samples: FFTAligner(max_offset_samples) lag window, -1 = None; the window is the
+ *   reference's, including Python negative-slice semantics (aligners.py:31-43).
+ * filter_max_offset: MaxScoreAligner.max_offset_samples used to drop candidates
+ *   (aligners.py:156-159), -1 = None.
+ * cand_out_dev[n_pairs*n_cand], pair_out_dev[n_pairs]: device buffers, written in stream order.
+ * All (R, S) must satisfy R+S <= plan n_fft.  Host arrays may be freed after return. */
+int ffs_align_batch(ffs_plan* plan, int n_pairs, int n_cand, int dtype,
+                    const void* const* vec_ptr, const int64_t* vec_len,
+                    const double* vec_lo, const double* vec_hi,
+                    int64_t max_offset_samples, int64_t filter_max_offset,
+                    ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                    void* hip_stream);
+
+/* Full correlation of one reference with one or two candidates (b_dev may be NULL):
+ *   out_x_dev[m] = sum_i x'[i] * ref'[(i + m) mod n_fft],  m in [0, n_fft)
+ * i.e. the reference's `convolve` array (aligners.py:74) with convolve[k] = out[(N-1-S-k) mod N].
+ * Used by the parity tests to compare the raw fp32 correlation against np.fft. */
+int ffs_correlate_full(ffs_plan* plan, int dtype,
+                       const void* ref_dev, int64_t ref_len, double ref_lo, double ref_hi,
+                       const void* a_dev, int64_t a_len, double a_lo, double a_hi,
+                       const void* b_dev, int64_t b_len, double b_lo, double b_hi,
+                       float* out_a_dev, float* out_b_dev, void* hip_stream);
+
+/* Frame-energy voice-activity sweep over s16le mono PCM resident in HBM.
+ * labels_dev[f] = (10*log10(mean(x^2) over frame f) >= energy_threshold_db) ? 1.0f
+ *                                                                           : non_speech_label
+ * for f in [0, ceil(n_samples/frame_len)); the last frame may be short.  Replaces the
+ * per-frame Python loop of the detector closures (speech_transformers.py:133-150, 169-181)
+ * with the AudioEnergyValidator rule (threshold 50 dB in the reference, :124). */
+int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len,
+                   double energy_threshold_db, float non_speech_label,
+                   float* labels_dev, void* hip_stream);
+
+/* ComputeSpeechFrameBoundariesMixin.fit_boundaries (speech_transformers.py:310-317):
+ * bounds_dev[0] = first index with frames[i] > 0.5, bounds_dev[1] = last such index;
+ * both -1 when there is none. */
+int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev,
+                      void* hip_stream);
+
+/* Per-kernel timing with HIP events recorded on the caller's stream around every launch of the
+ * hot kernels (used by bench.py for the roofline figures).  Kernel ids: */
+#define FFS_K_PASS_A 0   /* load/map/pad + column FFT + twiddle                    */
+#define FFS_K_MID 1      /* row FFT * conj(ref spectrum), row FFT, twiddle (in place) */
+#define FFS_K_PASS_C 2   /* column FFT + lag-window mask + block argmax nominees    */
+#define FFS_K_NOMINEES 3 /* nominee gather per candidate                            */
+#define FFS_K_RESCORE 4  /* exact re-evaluation of nominee lags                     */
+#define FFS_K_COUNT 5
+int ffs_plan_profile(ffs_plan* plan, int enable);
+/* Synchronises the recorded events, adds their durations to ms_total[FFS_K_COUNT] /
+ * launches[FFS_K_COUNT] (caller-zeroed or accumulating) and clears the recording. */
+int ffs_plan_profile_read(ffs_plan* plan, double* ms_total, int64_t* launches);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* ffs_last_error(void);
+
+/* Library/ABI version (major*10000 + minor*100 + patch). */
+int ffs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFSUBSYNC_AMD_H */

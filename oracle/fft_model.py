@@ -1,0 +1,129 @@
+"""TEST INFRASTRUCTURE ONLY -- numpy model of the device FFT decomposition.
+
+This is not the product path and not the reference algorithm: it is an index-math
+model of the four-step, register-radix Stockham pipeline implemented by the HIP
+kernels in ``ffsubsync_amd/csrc`` (pass A -> mid -> pass C), written so that every
+index formula, twiddle table and HBM tile layout can be checked against
+``numpy.fft`` on the CPU before the same formulas are transcribed to HIP.
+
+Only ``tests/`` may import this module.
+"""
+import numpy as np
+
+E = 16  # complex elements held per thread
+
+
+def radices(L):
+    """Stage radices for a length-L transform (first stage always 16)."""
+    assert L >= 16 and (L & (L - 1)) == 0 and L <= 4096
+    out = []
+    rem = L
+    while rem > 1:
+        r = min(16, rem)
+        out.append(r)
+        rem //= r
+    return out
+
+
+def stage_twiddles(L):
+    """Per-stage DIT twiddle tables, layout [r][j % Ns] (fp64 -> complex64)."""
+    tabs = []
+    Ns = 1
+    for R in radices(L):
+        jm = np.arange(Ns)[None, :]
+        r = np.arange(R)[:, None]
+        tabs.append(np.exp(-2j * np.pi * r * jm / (Ns * R)).astype(np.complex64))
+        Ns *= R
+    return tabs
+
+
+def stockham_fft(x, dtype=np.complex64):
+    """Forward DFT along axis 0 of x[L, ...] using the device stage structure.
+
+    Every thread u (< L/16) holds positions u + (L/16)*q, q<16, in registers; a stage of
+    radix R runs nb=16/R butterflies b on register slots q = b + r*nb and scatters element
+    (b, r) to position (j/Ns)*Ns*R + j%Ns + r*Ns with j = u + (L/16)*b.
+    """
+    L = x.shape[0]
+    cur = x.astype(dtype)
+    tabs = stage_twiddles(L)
+    Ns = 1
+    u = np.arange(L // E)
+    for s, R in enumerate(radices(L)):
+        nb = E // R
+        nxt = np.empty_like(cur)
+        for b in range(nb):
+            j = u + (L // E) * b
+            v = np.stack([cur[u + (L // E) * (b + r * nb)] for r in range(R)])  # [R, threads, ...]
+            tw = tabs[s][:, j % Ns]  # [R, threads]
+            v = v * tw.reshape(tw.shape + (1,) * (v.ndim - 2))
+            k = np.arange(R)
+            W = np.exp(-2j * np.pi * np.outer(k, k) / R).astype(dtype)
+            v = np.tensordot(W, v, axes=(1, 0))
+            base = (j // Ns) * Ns * R + (j % Ns)
+            for r in range(R):
+                nxt[base + r * Ns] = v[r]
+        cur = nxt
+        Ns *= R
+    return cur
+
+
+def split_n(N):
+    """N = N1 * N2 (N1: column length of pass A/C, N2: row length of the mid pass)."""
+    p = int(np.log2(N))
+    assert 1 << p == N and p >= 8
+    p2 = min(12, p - 4)
+    return 1 << (p - p2), 1 << p2
+
+
+def tile_offset(x, k1, N1, C=16):
+    """Element offset of (x, k1) in the tiled layout [x/C][k1][x%C] (x = n2 or m1)."""
+    return ((x // C) * N1 + k1) * C + (x % C)
+
+
+def inter_twiddle(N, a, b):
+    """W_N^(a*b) via the base/step tables the kernels use (both fp32-rounded)."""
+    w = lambda p: np.exp(-2j * np.pi * (p % N) / N).astype(np.complex64)
+    return w(a * b)
+
+
+def correlate_model(ref_pm, sa_pm, sb_pm, N):
+    """out[m] = sum_i (sa[i] + 1j*sb[i]) * ref[(i+m) % N] through the A/mid/C pipeline."""
+    N1, N2 = split_n(N)
+    z = np.zeros(N, np.complex64)
+    z[: len(sa_pm)] = sa_pm
+    if sb_pm is not None:
+        z[: len(sb_pm)] += 1j * np.asarray(sb_pm)
+    r = np.zeros(N, np.complex64)
+    r[: len(ref_pm)] = ref_pm
+
+    def pass_a(x):
+        # columns n2: FFT over n1 of x[N2*n1 + n2], times W_N^(n2*k1); tiled store
+        X = x.reshape(N1, N2)
+        Y = stockham_fft(X)  # [k1, n2]
+        k1 = np.arange(N1)[:, None]
+        n2 = np.arange(N2)[None, :]
+        Y = Y * inter_twiddle(N, n2, k1)
+        T = np.empty(N, np.complex64)
+        T[tile_offset(n2, k1, N1)] = Y
+        return T
+
+    def mid_rows(T):
+        k1 = np.arange(N1)[:, None]
+        n2 = np.arange(N2)[None, :]
+        rows = T[tile_offset(n2, k1, N1)]  # [k1, n2]
+        return stockham_fft(rows.T).T  # [k1, k2] = X[k1 + N1*k2]
+
+    Rspec = np.conj(mid_rows(pass_a(r))) / N  # conj(R)/N in [k1][k2]
+    Z = mid_rows(pass_a(z))
+    P = Z * Rspec
+    Y2 = stockham_fft(P.T).T  # [k1, m1]
+    k1 = np.arange(N1)[:, None]
+    m1 = np.arange(N2)[None, :]
+    Y2 = Y2 * inter_twiddle(N, k1, m1)
+    T2 = np.empty(N, np.complex64)
+    T2[tile_offset(m1, k1, N1)] = Y2
+    # pass C: columns m1, FFT over k1 -> out[m1 + N2*m2]
+    cols = T2[tile_offset(m1, k1, N1)]  # [k1, m1]
+    O = stockham_fft(cols)  # [m2, m1]
+    return O.reshape(N)  # index m2*N2 + m1

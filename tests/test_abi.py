@@ -1,0 +1,53 @@
+"""libffsalign.so loads on a CPU-only box and exports every symbol include/ffsubsync_amd.h declares
+(no compute calls here)."""
+import ctypes
+import math
+import os
+import re
+
+import pytest
+
+from ffsubsync_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "ffsubsync_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ffs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_is_built():
+    assert os.path.exists(_native.library_path()), "run __graft_entry__.build() first"
+
+
+def test_exports_every_declared_symbol():
+    lib = ctypes.CDLL(_native.library_path())
+    syms = _header_symbols()
+    assert set(syms) == set(_native.EXPORTED_SYMBOLS)
+    for s in syms:
+        assert getattr(lib, s) is not None
+
+
+def test_host_only_entry_points():
+    lib = _native.load()
+    assert lib.ffs_version() >= 100
+    assert _native.fft_length(0, 5) == 0
+    for x in list(range(2, 3000)) + [2 ** k + d for k in range(4, 25) for d in (-1, 0, 1)]:
+        # aligners.py:67-68
+        assert _native.fft_length(x - 1, 1) == int(2 ** math.ceil(math.log(x, 2)))
+
+
+def test_bad_arguments_are_reported_not_thrown():
+    lib = _native.load()
+    handle = ctypes.c_void_p()
+    rc = lib.ffs_plan_create(0, 1000, 1, 7, ctypes.byref(handle))  # not a power of two
+    assert rc == -1 and b"power of two" in lib.ffs_last_error()
+    with pytest.raises(_native.NativeError):
+        _native.check(rc)
+
+
+def test_result_struct_layouts():
+    assert _native.CAND_RESULT_DTYPE.fields["offset"][1] == 8 and _native.CAND_RESULT_DTYPE.fields["flags"][1] == 20
+    assert _native.PAIR_RESULT_DTYPE.fields["best_cand"][1] == 16

@@ -1,0 +1,222 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against the CPU oracle
+and against the committed outputs of the unmodified reference.  Need a real MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+from oracle import aligners_oracle as orc
+from oracle import vad_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "aligner_golden.json")))
+SMALL = golden_cases.build_cases(include_large=False)
+SCORE_RTOL = 1e-5  # north-star tolerance for float correlation scores
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def _direct_corr(ref_pm, s_pm, N):
+    a = np.zeros(N)
+    a[: len(s_pm)] = s_pm
+    b = np.zeros(N)
+    b[: len(ref_pm)] = ref_pm
+    return np.real(np.fft.ifft(np.conj(np.fft.fft(a)) * np.fft.fft(b)))
+
+
+@pytest.mark.parametrize("log2n", [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+def test_raw_correlation_u8_matches_fp64(torch, log2n):
+    """Every (N1, N2) kernel instantiation: full fp32 correlation vs numpy complex128."""
+    from ffsubsync_amd import _native
+
+    N = 1 << log2n
+    rng = np.random.RandomState(log2n)
+    R, Sa, Sb = N // 2 - 5, N // 2 - 77, N // 3 + 1
+    ref = (rng.rand(R) < 0.35).astype(np.uint8)
+    a = (rng.rand(Sa) < 0.35).astype(np.uint8)
+    b = (rng.rand(Sb) < 0.6).astype(np.uint8)
+    plan = _native.Plan(N, 1, 2)
+    d = lambda x: torch.from_numpy(x).cuda()
+    out_a, out_b = plan.correlate_full(_native.FFS_DTYPE_U8, d(ref), (0, 1), d(a), (0, 1), d(b), (0.0, 0.96))
+    torch.cuda.synchronize()
+    ea = _direct_corr(2.0 * ref - 1, 2.0 * a - 1, N)
+    eb = _direct_corr(2.0 * ref - 1, 2.0 * (0.96 * b) - 1, N)
+    tol = 4 * 6e-8 * log2n * np.sqrt(R * Sa)  # the nominee margin the library uses
+    err_a = np.abs(out_a.cpu().numpy() - ea).max()
+    err_b = np.abs(out_b.cpu().numpy() - eb).max()
+    print("N=2^%d max abs err a=%.4g b=%.4g (margin %.4g)" % (log2n, err_a, err_b, tol))
+    assert err_a < tol / 2 and err_b < tol / 2
+    plan.close()
+
+
+def test_raw_correlation_f32_single_candidate(torch):
+    from ffsubsync_amd import _native
+
+    N = 1 << 16
+    rng = np.random.RandomState(3)
+    ref = rng.rand(30000).astype(np.float32)
+    a = rng.rand(29000).astype(np.float32)
+    plan = _native.Plan(N, 1, 2)
+    out_a, out_b = plan.correlate_full(_native.FFS_DTYPE_F32, torch.from_numpy(ref).cuda(), (0, 1),
+                                       torch.from_numpy(a).cuda(), (0, 1))
+    assert out_b is None
+    e = _direct_corr(2.0 * ref.astype(float) - 1, 2.0 * a.astype(float) - 1, N)
+    assert np.abs(out_a.cpu().numpy() - e).max() < 0.05
+    plan.close()
+
+
+def _check_case(name, c, g, FFTAligner, MaxScoreAligner, FailedToFindAlignmentException):
+    for cand, exp in zip(c["cands"], g["per_candidate"]):
+        al = FFTAligner(max_offset_samples=c["max_offset"])
+        score, offset = al.fit_transform(c["ref"], cand, get_score=True)
+        assert offset == exp["offset"], (name, score, offset, exp)
+        assert isinstance(offset, int) and al.best_offset_ == offset
+        if exp["score"] == "-inf":
+            assert score == -np.inf
+        else:
+            assert score == pytest.approx(float(exp["score"]), rel=SCORE_RTOL, abs=1e-6)
+    cands = list(c["cands"])
+    (score, offset), winner = MaxScoreAligner(FFTAligner(max_offset_samples=c["max_offset"])).fit_transform(c["ref"], cands)
+    bu = g["best_unfiltered"]
+    assert winner is cands[bu["index"]] and offset == bu["offset"]
+    if "best_filtered" in g:
+        bf = g["best_filtered"]
+        msa = MaxScoreAligner(FFTAligner, None, 100, c["max_offset"] // 100)
+        if "raises" in bf:
+            with pytest.raises(FailedToFindAlignmentException, match="Synchronization failed"):
+                msa.fit_transform(c["ref"], cands)
+        else:
+            (score, offset), winner = msa.fit_transform(c["ref"], cands)
+            assert winner is cands[bf["index"]] and offset == bf["offset"]
+            assert score == pytest.approx(float(bf["score"]), rel=SCORE_RTOL)
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_golden_cases_through_the_dropin_classes(torch, name):
+    from ffsubsync_amd.aligners import FailedToFindAlignmentException, FFTAligner, MaxScoreAligner
+
+    _check_case(name, SMALL[name], GOLD["cases"][name], FFTAligner, MaxScoreAligner, FailedToFindAlignmentException)
+
+
+def test_reference_kats_and_call_styles(torch):
+    """reference tests/test_alignment.py:7-27, verbatim call styles."""
+    from ffsubsync_amd.aligners import FailedToFindAlignmentException, FFTAligner, MaxScoreAligner
+
+    for s1, s2, true_offset in [("111001", "11001", -1), ("1001", "1001", 0), ("10010", "01001", 1)]:
+        assert FFTAligner().fit_transform(s2, s1) == true_offset
+        assert MaxScoreAligner(FFTAligner).fit_transform(s2, s1)[0][1] == true_offset
+        assert MaxScoreAligner(FFTAligner()).fit_transform(s2, s1)[0][1] == true_offset
+    for r, s in [(np.array([]), np.array([1, 0, 1])), (np.array([1, 0, 1]), np.array([])), (np.array([]), np.array([]))]:
+        with pytest.raises(FailedToFindAlignmentException, match="empty speech data"):
+            FFTAligner().fit(r, s)
+
+
+def test_headline_shape_2h_seven_ratios(torch):
+    """BASELINE configs 2/3 shape: 2 h @ 100 Hz, N = 2^21, 7 ratios, max_offset 6000 -- offsets and
+    winner bit-identical to the reference, scores within 1e-5."""
+    from ffsubsync_amd.aligners import FailedToFindAlignmentException, FFTAligner, MaxScoreAligner
+
+    large = {k: v for k, v in golden_cases.build_cases(include_large=True).items() if k not in SMALL}
+    for name, c in large.items():
+        _check_case(name, c, GOLD["cases"][name], FFTAligner, MaxScoreAligner, FailedToFindAlignmentException)
+
+
+def test_scores_are_exact_integers_for_binary_inputs(torch):
+    from ffsubsync_amd.aligners import FFTAligner
+
+    c = SMALL["config1_6000"]
+    score, offset = FFTAligner(6000).fit_transform(c["ref"], c["cands"][0], get_score=True)
+    assert offset == 3720 and float(score) == 50498.0
+
+
+def test_gss_through_the_dropin(torch):
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+
+    ref, sub = golden_cases.gss_case()
+    ratios = []
+
+    def maker(r):
+        ratios.append(r)
+        return golden_cases.ScaledPipe(sub, r)
+
+    msa = MaxScoreAligner(FFTAligner(max_offset_samples=6000))
+    msa.fit(ref, [maker])
+    (score, offset), pipe = msa.transform()
+    g = GOLD["gss"]
+    assert [repr(r) for r in ratios] == g["ratios"]
+    assert repr(pipe.ratio) == g["final_ratio"] and offset == g["offset"]
+    assert score == pytest.approx(float(g["score"]), rel=SCORE_RTOL)
+
+
+def test_batch_api_against_oracle(torch):
+    """Throughput path: several 15-minute problems in one ffs_align_batch call, generated on the
+    GPU, checked pair by pair against the CPU oracle on the same vectors."""
+    from ffsubsync_amd import batch, synth
+
+    specs = [synth.make_pair_spec(100 + i, duration_s=900.0) for i in range(5)]
+    db = batch.build_device_batch(specs)
+    host = db.data.cpu().numpy()
+    for p, sp in enumerate(specs):  # GPU rasteriser == numpy rasteriser
+        ref, cands = synth.pair_arrays(sp)
+        assert np.array_equal(host[db.offs[p, 0]: db.offs[p, 0] + db.lens[p, 0]], ref)
+        assert np.array_equal(host[db.offs[p, 3]: db.offs[p, 3] + db.lens[p, 3]], cands[2])
+    al = batch.BatchAligner(db.required_fft_length(), 7, max_offset_samples=6000, pairs_in_flight=2)
+    cres, pres = al.solve(db)
+    for p, sp in enumerate(specs):
+        fref, fc = synth.pair_float_arrays(sp)
+        for j in range(7):
+            s, o = orc.fft_align(fref, fc[j], 6000)
+            assert cres[p, j]["offset"] == o
+            assert cres[p, j]["score"] == pytest.approx(s, rel=SCORE_RTOL)
+            assert not (cres[p, j]["flags"] & 2)
+        (s, o), idx = orc.max_score_align(fref, fc, 6000)
+        assert (pres[p]["best_cand"], pres[p]["offset"]) == (idx, o)
+        assert idx == sp.true_ratio_index
+    # idempotence + sub-range solve give the same records
+    cres2, pres2 = al.solve(db, 1, 4)
+    assert np.array_equal(pres2, pres[1:4]) and np.array_equal(cres2, cres[1:4])
+
+
+def test_vad_energy_and_bounds(torch):
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.speech_transformers import (ComputeSpeechFrameBoundariesMixin, PCMSpeechTransformer,
+                                                    _make_energy_detector)
+
+    pcm, state = vo.synth_pcm(480 * 20000 + 123, seed=5)
+    # boundary frames: exactly at threshold, one below, silent, full-scale
+    pcm[:480] = 0
+    pcm[480:960] = 0
+    pcm[480:780] = 400
+    pcm[960:1440] = 0
+    pcm[960:1260] = 400
+    pcm[960] = 399
+    pcm[1440:1920] = -32768
+    exp = vo.detect_fast(pcm, non_speech_label=0.0)
+    det = _make_energy_detector(100, 48000, 0.0)
+    got = det(pcm.tobytes())
+    assert got.dtype == np.float64 and np.array_equal(got, exp)
+    assert list(got[:4]) == [0.0, 1.0, 0.0, 1.0]
+    got2 = _make_energy_detector(100, 48000, -1.0)(np.frombuffer(pcm.tobytes(), np.uint8))
+    assert np.array_equal(got2, vo.detect_fast(pcm, non_speech_label=-1.0))
+    # unaligned start / odd frame length take the scalar path
+    lab = _native.vad_energy(torch.from_numpy(pcm).cuda()[3:], 441, 50.0, 0.0).cpu().numpy()
+    assert np.array_equal(lab, vo.detect_fast(pcm[3:], 100, 44100))
+    # chunk loop == oracle chunk loop
+    t = PCMSpeechTransformer("energy", 100, 48000, 0.0).fit(pcm)
+    assert np.array_equal(t.transform(), vo.chunked_detect(pcm))
+    m = ComputeSpeechFrameBoundariesMixin().fit_boundaries(exp)
+    assert (m.start_frame_, m.end_frame_) == orc.speech_boundaries(exp) and m.num_frames == m.end_frame_ - m.start_frame_
+    z = ComputeSpeechFrameBoundariesMixin().fit_boundaries(np.zeros(1000))
+    assert z.start_frame_ is None and z.num_frames is None
+    with pytest.raises(ValueError, match="Unable to detect speech"):
+        PCMSpeechTransformer().fit(b"")

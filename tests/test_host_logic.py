@@ -1,0 +1,147 @@
+"""Host-side logic that needs no GPU: sklearn shim, golden-section search, generators, sharding and
+the MaxScoreAligner control flow (driven with a CPU stand-in for the base aligner)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+from ffsubsync_amd import synth
+from ffsubsync_amd.aligners import FailedToFindAlignmentException, MaxScoreAligner
+from ffsubsync_amd.batch import shard_bounds
+from ffsubsync_amd.golden_section_search import gss
+from ffsubsync_amd.sklearn_shim import Pipeline, TransformerMixin, make_pipeline
+from oracle import aligners_oracle as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "aligner_golden.json")))
+
+
+class OracleBackedAligner(TransformerMixin):
+    """Duck-typed base aligner (no _solve_many): exercises MaxScoreAligner's generic per-candidate
+    path, the one a foreign aligner object would take."""
+
+    def __init__(self, max_offset_samples=None):
+        self.max_offset_samples = max_offset_samples
+
+    def fit(self, ref, sub, get_score=False):
+        self.res = orc.fft_align(ref, sub, self.max_offset_samples)
+        self.get_score_ = get_score
+        return self
+
+    def transform(self, *_):
+        return self.res if self.get_score_ else self.res[1]
+
+
+class Add(TransformerMixin):
+    def __init__(self, k):
+        self.k = k
+
+    def fit(self, X, *_):
+        self.seen_ = X
+        return self
+
+    def transform(self, X):
+        return X + self.k
+
+
+def test_pipeline_contract():
+    pipe = Pipeline([("a", Add(1)), ("b", Add(10))])
+    assert pipe.fit_transform(5) == 16
+    assert pipe.fit(5) is pipe and pipe.transform(5) == 16  # transform is a property returning a callable
+    assert pipe.named_steps["b"].k == 10 and pipe[-1].k == 10 and pipe["a"].k == 1 and len(pipe[:1]) == 1
+    mp = make_pipeline(Add(1), Add(2))
+    assert [n for n, _ in mp.steps] == ["add-1", "add-2"]
+    with pytest.raises(ValueError):
+        Pipeline([("a", Add(1)), ("a", Add(2))])
+
+
+def test_gss_matches_reference_trace():
+    ref, sub = golden_cases.gss_case()
+    seen = []
+
+    def objective(ratio, last):
+        seen.append((ratio, last))
+        return -orc.fft_align(ref, golden_cases.scaled(sub, ratio), 6000)[0]
+
+    lo, hi = gss(objective, 0.9, 1.1)
+    assert [repr(x) for x, _ in seen] == GOLD["gss"]["ratios"]
+    assert [last for _, last in seen].count(True) == 1 and seen[-1][1]
+    assert hi - lo <= 1.1e-4
+    a, b = gss(lambda x, last: (x - 2) ** 2, 1, 5, 1e-5)
+    assert [repr(a), repr(b)] == GOLD["gss_doc_example"]
+    with pytest.raises(TypeError):  # the reference calls f(d, flag) directly on one branch (:69)
+        gss(lambda x: -x, 1, 5, 1e-5)
+
+
+def test_max_score_aligner_control_flow():
+    c = golden_cases.build_cases(include_large=False)["sparse2"]
+    g = GOLD["cases"]["sparse2"]
+    cands = list(c["cands"])
+    msa = MaxScoreAligner(OracleBackedAligner, None, 100, 60)
+    assert msa.max_offset_samples == 6000 and msa.base_aligner.max_offset_samples == 6000
+    (score, offset), winner = msa.fit_transform(c["ref"], cands)
+    assert winner is cands[g["best_filtered"]["index"]] and offset == g["best_filtered"]["offset"]
+    assert len(msa._scores) == 7
+    msa.fit(c["ref"], cands[:2])  # _scores is append-only across fits (aligners.py:109, 144)
+    assert len(msa._scores) == 9
+    # an instance keeps its own window and disables filtering (aligners.py:104-108)
+    inst = MaxScoreAligner(OracleBackedAligner(max_offset_samples=10))
+    assert inst.max_offset_samples is None
+    # nothing within the limit -> the reference's error message
+    c0 = golden_cases.build_cases(include_large=False)["mask_all"]
+    with pytest.raises(FailedToFindAlignmentException, match="Synchronization failed"):
+        MaxScoreAligner(OracleBackedAligner, None, 100, 0).fit_transform(c0["ref"], list(c0["cands"]))
+
+
+def test_max_score_aligner_gss_records_only_last():
+    ref, sub = golden_cases.gss_case()
+    msa = MaxScoreAligner(OracleBackedAligner(max_offset_samples=6000))
+    ratios = []
+
+    def maker(r):
+        ratios.append(r)
+        return golden_cases.ScaledPipe(sub, r)
+
+    msa.fit(ref, [maker])
+    (score, offset), pipe = msa.transform()
+    assert len(msa._scores) == 1 and len(ratios) == len(GOLD["gss"]["ratios"])
+    assert repr(pipe.ratio) == GOLD["gss"]["final_ratio"] and offset == GOLD["gss"]["offset"]
+
+
+def test_synth_generator_properties():
+    spec = synth.make_pair_spec(3, duration_s=900.0)
+    ref, cands = synth.pair_arrays(spec)
+    assert ref.dtype == np.uint8 and ref.size == 90000 and 0.2 < ref.mean() < 0.6
+    assert len(cands) == 7 and all(c.size == n for c, n in zip(cands, spec.cand_len))
+    assert spec.cand_amp[0] == 1.0 and spec.cand_amp[1] == pytest.approx(23.976 / 24.0)
+    fref, fc = synth.pair_float_arrays(spec)
+    (score, offset), idx = orc.max_score_align(fref, fc, 6000)
+    assert idx == spec.true_ratio_index and abs(offset - spec.true_offset_samples) <= 15
+    # uniqueness of the winner: oracle top-2 gap > 0.5
+    conv, S = orc.convolve_full(fref, fc[idx])
+    m = orc.mask_extreme_offsets(conv, S, 6000)
+    top2 = np.sort(m[np.isfinite(m)])[-2:]
+    assert top2[1] - top2[0] > 0.5
+    assert synth.make_pair_spec(3, duration_s=900.0).ref_starts.tolist() == spec.ref_starts.tolist()
+
+
+def test_shard_bounds_cover_everything():
+    for n in (0, 1, 7, 1024, 1030):
+        for w in (1, 2, 4, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) <= (n + w - 1) // w
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ffsubsync_amd.aligners import FFTAligner
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FFTAligner().fit("1001", "1001")
