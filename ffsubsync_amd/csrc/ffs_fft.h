@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+
 namespace ffsa {
 
 typedef float2 cf;
@@ -115,97 +117,222 @@ struct Shape {
     static constexpr int LT = L / 16;                      // threads per transform
     static constexpr int R1 = (LT >= 16) ? 16 : LT;        // second-stage radix (1 = absent)
     static constexpr int R2 = L / (16 * R1);               // third-stage radix (1 = absent)
-    static constexpr int TW1 = 0;                          // offset of stage-1 table [R1][16]
-    static constexpr int TW2 = R1 * 16;                    // offset of stage-2 table [R2][256]
-    static constexpr int TW_TOTAL = R1 * 16 + (R2 > 1 ? R2 * 256 : 0);
+    // Stage tables (host: make_stage_tables).  A radix-16 stage stores only the six powers
+    // w^1, w^2, w^3, w^4, w^8, w^12 per butterfly index ([6][NS]); smaller radices store w^r, [R][NS].
+    static constexpr int ROWS1 = (R1 == 16) ? 6 : R1;
+    static constexpr int ROWS2 = (R2 == 16) ? 6 : R2;
+    static constexpr int TW1 = 0;
+    static constexpr int TW2 = ROWS1 * 16;
 };
 
+// Per-thread twiddle registers of one twiddled stage.  For a fixed thread the butterfly indices
+// j = u + LT*b never change, so the values are loaded once, up front, and reused by every
+// transform the thread takes part in.
+template <int L, int R, int NS>
+struct StageTw {
+    static constexpr int NB = 16 / R;
+    static constexpr int COUNT = (R == 16) ? 6 : (R > 1 ? (R - 1) * NB : 1);
+    cf w[COUNT];
+    FFS_DEV void load(const cf* __restrict__ tab, int u) {
+        constexpr int LT = L / 16;
+        if constexpr (R == 16) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = tab[i * NS + (u & (NS - 1))];
+        } else if constexpr (R > 1) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 1; r < R; ++r) w[b * (R - 1) + (r - 1)] = tab[r * NS + ((u + LT * b) & (NS - 1))];
+        }
+    }
+};
+
+template <int L>
+struct TwRegs {
+    typedef Shape<L> S;
+    StageTw<L, S::R1, 16> s1;
+    StageTw<L, S::R2, 256> s2;
+    FFS_DEV void load(const cf* __restrict__ tw, int u) {
+        if constexpr (S::R1 > 1) s1.load(tw + S::TW1, u);
+        if constexpr (S::R2 > 1) s2.load(tw + S::TW2, u);
+    }
+};
+
+// Radix-16 butterfly with the stage twiddles w^r folded in as w^(4a) * w^b (r = 4a + b):
+// inputs t[4a+b] *= w^(4a), DFT4 over a, outputs *= w^b and the constant W16^(b*k1), DFT4 over b.
+// Six per-thread twiddles instead of fifteen (24 complex multiplies instead of 15).
+FFS_DEV void bfly16_twiddled(cf* t, const cf* w /* w1 w2 w3 w4 w8 w12 */) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[4 + b] = cmul(t[4 + b], w[3]);
+        t[8 + b] = cmul(t[8 + b], w[4]);
+        t[12 + b] = cmul(t[12 + b], w[5]);
+        dft4(t[b], t[4 + b], t[8 + b], t[12 + b]);
+    }
+    // slot b + 4*k1 holds A_b[k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        t[4 * k1 + 1] = cmul(t[4 * k1 + 1], w[0]);
+        t[4 * k1 + 2] = cmul(t[4 * k1 + 2], w[1]);
+        t[4 * k1 + 3] = cmul(t[4 * k1 + 3], w[2]);
+    }
+    t[5] = cmul(t[5], mk(FFS_COS_PI_8, -FFS_SIN_PI_8));
+    t[6] = cmul(t[6], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));
+    t[7] = cmul(t[7], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));
+    t[9] = cmul(t[9], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));
+    t[10] = cmul_negi(t[10]);
+    t[11] = cmul(t[11], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));
+    t[13] = cmul(t[13], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));
+    t[14] = cmul(t[14], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));
+    t[15] = cmul(t[15], mk(-FFS_COS_PI_8, FFS_SIN_PI_8));
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(t[4 * k1], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3]);
+}
+
 // One Stockham stage on registers: NB = 16/R butterflies per thread; butterfly b works on
-// register slots b + r*NB and has butterfly index j = u + (L/16)*b.  tw is laid out [r][j % NS].
-template <int L, int R, int NS, bool TWIDDLE>
-FFS_DEV void stage_compute(cf (&v)[16], int u, const cf* __restrict__ tw) {
+// register slots b + r*NB and has butterfly index j = u + (L/16)*b.
+template <int L, int R, int NS>
+FFS_DEV void stage_compute(cf (&v)[16], const StageTw<L, R, NS>& tw) {
     constexpr int NB = 16 / R;
-    constexpr int LT = L / 16;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         cf t[R];
-        const int jm = (u + LT * b) & (NS - 1);
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            t[r] = v[b + r * NB];
-            if (TWIDDLE && r > 0) t[r] = cmul(t[r], tw[r * NS + jm]);
+        for (int r = 0; r < R; ++r) t[r] = v[b + r * NB];
+        if constexpr (R == 16) {
+            bfly16_twiddled(t, tw.w);
+        } else {
+#pragma unroll
+            for (int r = 1; r < R; ++r) t[r] = cmul(t[r], tw.w[b * (R - 1) + (r - 1)]);
+            Bfly<R>::run(t);
         }
-        Bfly<R>::run(t);
 #pragma unroll
         for (int r = 0; r < R; ++r) v[b + r * NB] = t[Bfly<R>::slot_of(r)];
     }
 }
 
+// First stage: one untwiddled radix-16 butterfly per thread.
+FFS_DEV void stage_first(cf (&v)[16]) {
+    cf t[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r] = v[r];
+    Bfly<16>::run(t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = t[Bfly<16>::slot_of(r)];
+}
+
+// LDS addressing.  Every access of the transform touches positions of one of two shapes:
+//   gather : p = u + LT*q                       (q compile-time)
+//   scatter: p = (j/NS)*NS*R + j%NS + r*NS      (j = u + LT*b; b, r compile-time)
+// An Addr type turns them into LDS element indices as  thread-dependent base + compile-time
+// constant, so each ds_read/ds_write uses one base VGPR and an immediate offset.
+
+// Tile of C interleaved column transforms (column c of the block): index = p*C + c.
+template <int L, int C>
+struct ColAddr {
+    int uc;  // u*C + c
+    int c;
+    FFS_DEV ColAddr(int u, int c_) : uc(u * C + c_), c(c_) {}
+    template <int Q>
+    FFS_DEV int gather() const {
+        return uc + (L / 16) * Q * C;
+    }
+    template <int R, int NS, int B, int RR>
+    FFS_DEV int scatter(int u) const {
+        constexpr int LT = L / 16;
+        if constexpr (NS == 1) {
+            // p = j*R + r with j = u + LT*B:  p*C + c = (uc - c)*R + c + (LT*B*R + r)*C
+            return (uc - c) * R + c + (LT * B * R + RR) * C;
+        } else {
+            const int j = u + LT * B;
+            return ((j / NS) * (NS * R) + (j & (NS - 1)) + RR * NS) * C + c;
+        }
+    }
+};
+
+// One row transform per LT threads, padded by one element per 16 (index p + p/16): conflict-free
+// for the stride-16 scatter of the first stage (ds_write_b64 serves 16 lanes per cycle) and
+// separable into base + constant because LT is a multiple of 16 for every row length >= 256.
+template <int L>
+struct RowAddr {
+    static_assert(L >= 256, "row transforms need L >= 256");
+    static constexpr int LT = L / 16;
+    static constexpr int ROW_ELEMS = L + L / 16;
+    int gbase;   // row_base + u + u/16
+    int s0base;  // row_base + 17*u
+    int row_base, u_lo, u_hi;
+    FFS_DEV RowAddr(int row_base_, int u) : row_base(row_base_), u_lo(u & 15), u_hi(u >> 4) {
+        gbase = row_base + u + (u >> 4);
+        s0base = row_base + 17 * u;
+    }
+    template <int Q>
+    FFS_DEV int gather() const {
+        return gbase + LT * Q + (LT / 16) * Q;
+    }
+    template <int R, int NS, int B, int RR>
+    FFS_DEV int scatter(int) const {
+        if constexpr (NS == 1) {
+            static_assert(B == 0 && R == 16, "first stage is one radix-16 butterfly per thread");
+            return s0base + RR;  // p = 16u + r  ->  p + p/16 = 17u + r
+        } else if constexpr (NS == 16) {
+            // j = u + LT*B, j/16 = u_hi + (LT/16)*B, j%16 = u_lo; p = (j/16)*16R + j%16 + 16r
+            // p/16 = (j/16)*R + r
+            return row_base + u_lo + u_hi * (17 * R) + (LT / 16) * B * (17 * R) + 17 * RR;
+        } else {
+            static_assert(NS == 256, "unexpected stage");
+            // j = u + LT*B, p = (j/256)*256R + j%256 + 256r; LT is a multiple of 16 so p/16 splits
+            const int j_hi = (u_hi + (LT / 16) * B) >> 4;              // j / 256
+            const int j_mid = (u_hi + (LT / 16) * B) & 15;             // (j / 16) % 16
+            return row_base + u_lo + j_mid * 17 + j_hi * (272 * R) + 272 * RR;
+        }
+    }
+};
+
+template <int L, int R, int NS, int B, class Addr, int... RR>
+FFS_DEV void scatter_row(const cf (&v)[16], cf* lds, int u, const Addr& addr, std::integer_sequence<int, RR...>) {
+    constexpr int NB = 16 / R;
+    ((lds[addr.template scatter<R, NS, B, RR>(u)] = v[B + RR * NB]), ...);
+}
+template <int L, int R, int NS, class Addr, int... B>
+FFS_DEV void stage_scatter_impl(const cf (&v)[16], cf* lds, int u, const Addr& addr, std::integer_sequence<int, B...>) {
+    (scatter_row<L, R, NS, B>(v, lds, u, addr, std::make_integer_sequence<int, R>{}), ...);
+}
 // Scatter stage outputs to their Stockham positions: element (b, r) -> (j/NS)*NS*R + j%NS + r*NS.
 template <int L, int R, int NS, class Addr>
 FFS_DEV void stage_scatter(const cf (&v)[16], cf* lds, int u, const Addr& addr) {
-    constexpr int NB = 16 / R;
-    constexpr int LT = L / 16;
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-        const int j = u + LT * b;
-        const int base = (j / NS) * (NS * R) + (j & (NS - 1));
-#pragma unroll
-        for (int r = 0; r < R; ++r) lds[addr(base + r * NS)] = v[b + r * NB];
-    }
+    stage_scatter_impl<L, R, NS>(v, lds, u, addr, std::make_integer_sequence<int, 16 / R>{});
 }
 
+template <class Addr, int... Q>
+FFS_DEV void stage_gather_impl(cf (&v)[16], const cf* lds, const Addr& addr, std::integer_sequence<int, Q...>) {
+    ((v[Q] = lds[addr.template gather<Q>()]), ...);
+}
 template <int L, class Addr>
-FFS_DEV void stage_gather(cf (&v)[16], const cf* lds, int u, const Addr& addr) {
-    constexpr int LT = L / 16;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = lds[addr(u + LT * q)];
+FFS_DEV void stage_gather(cf (&v)[16], const cf* lds, int, const Addr& addr) {
+    stage_gather_impl(v, lds, addr, std::make_integer_sequence<int, 16>{});
 }
 
 // Forward DFT of length L over the LT threads that share `addr`'s LDS region.
 // In: v[q] = x[u + LT*q].  Out: v[q] = X[u + LT*q].  All threads of the block must call it
-// (it contains __syncthreads()).  tw = Shape<L> stage tables.
-// Keep the (uniform) table pointer opaque at this program point: the twiddle loads that depend on
-// it cannot be hoisted above it, which bounds how many table values are live at once.
-FFS_DEV const cf* pin(const cf* p) {
-    asm volatile("" : "+s"(p));
-    return p;
-}
-
+// (it contains __syncthreads()).  tw = this thread's preloaded stage twiddles.
 template <int L, class Addr>
-FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, const Addr& addr, const cf* __restrict__ tw) {
+FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, const Addr& addr, const TwRegs<L>& tw) {
     typedef Shape<L> S;
-    stage_compute<L, 16, 1, false>(v, u, nullptr);
+    stage_first(v);
     if constexpr (S::R1 > 1) {
         __syncthreads();  // previous readers of this LDS region are done
-        const cf* tw1 = pin(tw + S::TW1);  // stage-1 table loads overlap the exchange
         stage_scatter<L, 16, 1>(v, lds, u, addr);
         __syncthreads();
         stage_gather<L>(v, lds, u, addr);
-        stage_compute<L, S::R1, 16, true>(v, u, tw1);
+        stage_compute<L, S::R1, 16>(v, tw.s1);
         if constexpr (S::R2 > 1) {
             __syncthreads();
-            const cf* tw2 = pin(tw + S::TW2);
             stage_scatter<L, S::R1, 16>(v, lds, u, addr);
             __syncthreads();
             stage_gather<L>(v, lds, u, addr);
-            stage_compute<L, S::R2, 256, true>(v, u, tw2);
+            stage_compute<L, S::R2, 256>(v, tw.s2);
         }
     }
 }
-
-// LDS addressing for a tile of C interleaved column transforms: element p of column c.
-template <int C>
-struct ColAddr {
-    int c;
-    FFS_DEV int operator()(int p) const { return p * C + c; }
-};
-
-// LDS addressing for one row transform per LT threads; one pad element per 32 keeps the
-// stride-16 scatter of the first stage off a single bank.
-struct RowAddr {
-    int base;
-    FFS_DEV int operator()(int p) const { return base + p + (p >> 5); }
-};
 
 }  // namespace ffsa

@@ -27,7 +27,7 @@ namespace ffsa {
 
 constexpr int KBLK = 6;   // nominees kept per pass-C block
 constexpr int KNOM = 16;  // nominees kept per candidate
-constexpr int RSEG = 8;   // segments each exact re-evaluation is split into
+constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference, b = null)
     const void* a;
@@ -65,8 +65,8 @@ struct NomList {
 };
 
 struct RescoreAcc {
-    unsigned int n11, n1x, nx1, pad;
-    double fsum;
+    unsigned int n11, n1x, nx1, pad;  // two-level inputs: exact integer counts (atomics are exact)
+    double part[RSEG];                // float inputs: one fp64 partial per segment, summed in order
 };
 
 struct CandResult {
@@ -108,6 +108,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     const int tile = blockIdx.x;
     const int n2 = tile * C + c;
     const XformDesc d = descs[blockIdx.y];
+    // every table value this thread needs is requested up front, together with the inputs
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf wq[16];  // W_N^(n2*k1), k1 = u + LT*q:  tb[u][n2] * ts[q][n2]
+    wq[0] = tb[u * N2 + n2];
+#pragma unroll
+    for (int q = 1; q < 16; ++q) wq[q] = ts[q * N2 + n2];
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -115,13 +122,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
         v[q].y = (d.b != nullptr) ? load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1) : 0.0f;
     }
-    fft_regs<L>(v, lds, u, ColAddr<C>{c}, tw);
-    // v[q] = Y[k1 = u + LT*q][n2];  times W_N^(n2*k1) = tb[u][n2] * ts[q][n2]
-    const cf wb = tb[u * N2 + n2];
+    fft_regs<L>(v, lds, u, ColAddr<L, C>(u, c), twr);
+    // v[q] = Y[k1 = u + LT*q][n2]
     cf* out = work + (size_t)blockIdx.y * N;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const cf w = (q == 0) ? wb : cmul(wb, ts[q * N2 + n2]);
+        const cf w = (q == 0) ? wq[0] : cmul(wq[0], wq[q]);
         const int k1 = u + LT * q;
         out[((size_t)tile * L + k1) * C + c] = cmul(v[q], w);
     }
@@ -130,32 +136,42 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 // --------------------------------------------------------------------------------------------
 // mid pass.  grid = (N1/ROWS, n_pairs); block = 256 threads; ROWS = 256/(L/16) rows per block.
 // Slot 0 of each pair is the reference transform; slots 1..n_slots-1 are transformed in place.
-template <int L>
-__global__ __launch_bounds__(256, 2) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
-                                             float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
-                                             const cf* __restrict__ ts) {
+// SEP: L/16 >= C, so element u + LT*q of a row sits at  off0 + q*(LT*N1)  (one 32-bit lane offset
+// plus a wave-uniform stride) instead of needing sixteen independent 64-bit addresses.
+template <int L, bool SEP>
+__global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                                float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
+                                                const cf* __restrict__ ts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
     constexpr int ROWS = 256 / LT;
-    constexpr int ROW_STRIDE = L + L / 32;
+    constexpr int ROW_STRIDE = RowAddr<L>::ROW_ELEMS;
     const int row = threadIdx.x / LT;
     const int u = threadIdx.x % LT;
     const int k1 = blockIdx.x * ROWS + row;
-    const RowAddr addr{row * ROW_STRIDE};
+    const RowAddr<L> addr(row * ROW_STRIDE, u);
     const int C = 1 << log2C;
     cf* base = work + (size_t)blockIdx.y * n_slots * N;
 
-    // element x of row k1 lives at ((x/C)*N1 + k1)*C + x%C
-    auto off = [&](int q) {
-        const int x = u + LT * q;
-        return ((x >> log2C) * N1 + k1) * C + (x & (C - 1));
+    // element x = u + LT*q of row k1 lives at ((x/C)*N1 + k1)*C + x%C
+    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
+    const size_t qstride = (size_t)LT * N1;
+    auto at = [&](cf* buf, int q) -> cf& {
+        if constexpr (SEP) {
+            return (buf + q * qstride)[off0];
+        } else {
+            const int x = u + LT * q;
+            return buf[((x >> log2C) * N1 + k1) * C + (x & (C - 1))];
+        }
     };
 
+    TwRegs<L> twr;
+    twr.load(tw, u);
     cf rr[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rr[q] = base[off(q)];
-    fft_regs<L>(rr, lds, u, addr, tw);
+    for (int q = 0; q < 16; ++q) rr[q] = at(base, q);
+    fft_regs<L>(rr, lds, u, addr, twr);
 #pragma unroll
     for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, -rr[q].y * inv_n);  // conj(R)/N
 
@@ -164,20 +180,15 @@ __global__ __launch_bounds__(256, 2) void k_mid(cf* __restrict__ work, int N1, i
         cf* buf = base + (size_t)s * N;
         cf v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = buf[off(q)];
-        // u is re-materialised per transform so the ~100 loop-invariant LDS addresses derived from it
-        // are recomputed (a few VALU ops each) instead of being kept live across the slot loop.
-        int ua = u, ub = u;
-        asm volatile("" : "+v"(ua), "+v"(ub));
-        fft_regs<L>(v, lds, ua, addr, tw);
+        for (int q = 0; q < 16; ++q) v[q] = at(buf, q);
+        fft_regs<L>(v, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], rr[q]);
-        fft_regs<L>(v, lds, ub, addr, tw);
-        const cf* tsl = pin(ts);
+        fft_regs<L>(v, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wb : cmul(wb, tsl[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            buf[off(q)] = cmul(v[q], w);
+            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+            at(buf, q) = cmul(v[q], w);
         }
     }
 }
@@ -205,10 +216,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     const int ly = blockIdx.y;
     const int lp = ly / n_packed, kp = ly % n_packed;
     const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
+    TwRegs<L> twr;
+    twr.load(tw, u);
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
-    fft_regs<L>(v, lds, u, ColAddr<C>{c}, tw);
+    fft_regs<L>(v, lds, u, ColAddr<L, C>(u, c), twr);
     // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LT*q
     const int m1 = tile * C + c;
     if (WRITE) {
@@ -381,62 +394,107 @@ __global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bn
 }
 
 // --------------------------------------------------------------------------------------------
-// exact re-evaluation of c(d) = sum_{i in overlap} s'[i] * r'[i+d] for every nominee.
-// grid = (RSEG, KNOM, n_cands); accumulates into acc[ci*KNOM + nominee].
+// exact re-evaluation of c(d) = sum_{i in overlap} s'[i] * r'[i+d] for every nominee of a candidate.
+// grid = (RSEG, n_cands): block x takes the x-th contiguous segment of the overlap and streams it
+// 16 bytes per lane per step (unaligned dwordx4 loads; the reference side is shifted by d).
+// Two-level inputs: three integer counts (n11, n1x, nx1) via byte-flag popcounts; float inputs:
+// fp64 dot product.  Partial sums are added to acc[ci*KNOM + nominee] with atomics.
+FFS_DEV unsigned nz_flags(unsigned w) {  // bit 7 of every byte that is non-zero
+    return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
                                                  RescoreAcc* __restrict__ acc, int first_cand) {
-    const int ci = first_cand + blockIdx.z;
-    const int ni = blockIdx.y;
+    const int ci = first_cand + blockIdx.y;
     const NomList& nl = noms[ci];
-    if (ni >= nl.count) return;
+    const int count = nl.count;
+    if (count <= 0) return;
     const CandDesc& cd = cands[ci];
-    const int d = nl.d[ni];
-    const int i0 = d < 0 ? -d : 0;
-    const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
-    if (i1 <= i0) return;
-    const int len = i1 - i0;
-    const int seg = (len + RSEG - 1) / RSEG;
-    const int a = i0 + blockIdx.x * seg;
-    const int b = (a + seg) < i1 ? (a + seg) : i1;
-    RescoreAcc& out = acc[(size_t)ci * KNOM + ni];
-    if (DT == 0) {
-        const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
-        const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
-        unsigned int n11 = 0, n1x = 0, nx1 = 0;
-        for (int i = a + threadIdx.x; i < b; i += 256) {
-            const unsigned int sb = s[i] != 0, rb = r[i] != 0;
-            n11 += sb & rb;
-            n1x += sb;
-            nx1 += rb;
-        }
+    constexpr int VEC = (DT == 0) ? 16 : 4;  // elements per 16-byte load
+    for (int ni = 0; ni < count; ++ni) {
+        const int d = nl.d[ni];
+        const int i0 = d < 0 ? -d : 0;
+        const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+        if (i1 <= i0) continue;
+        int seg = (i1 - i0 + (int)gridDim.x - 1) / (int)gridDim.x;
+        seg = (seg + VEC - 1) / VEC * VEC;
+        const int a = i0 + (int)blockIdx.x * seg;
+        const int b = (a + seg) < i1 ? (a + seg) : i1;
+        if (a >= b) continue;
+        RescoreAcc& out = acc[(size_t)ci * KNOM + ni];
+        if (DT == 0) {
+            const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
+            const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
+            unsigned int n11 = 0, n1x = 0, nx1 = 0;
+            for (int i = a + VEC * (int)threadIdx.x; i < b; i += VEC * 256) {
+                if (i + VEC <= b) {
+                    uint4 sv, rv;
+                    __builtin_memcpy(&sv, s + i, 16);
+                    __builtin_memcpy(&rv, r + i, 16);
+                    const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            n11 += __shfl_xor(n11, sft, 64);
-            n1x += __shfl_xor(n1x, sft, 64);
-            nx1 += __shfl_xor(nx1, sft, 64);
-        }
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&out.n11, n11);
-            atomicAdd(&out.n1x, n1x);
-            atomicAdd(&out.nx1, nx1);
-        }
-    } else {
-        const float* s = reinterpret_cast<const float*>(cd.s);
-        const float* r = reinterpret_cast<const float*>(cd.r) + d;
-        double sum = 0.0;
-        for (int i = a + threadIdx.x; i < b; i += 256) {
-            const double sv = 2.0 * (double)s[i] - 1.0, rv = 2.0 * (double)r[i] - 1.0;
-            sum += sv * rv;
-        }
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned fs = nz_flags(sw[k]), fr = nz_flags(rw[k]);
+                        n11 += __popc(fs & fr);
+                        n1x += __popc(fs);
+                        nx1 += __popc(fr);
+                    }
+                } else {
+                    for (int k = i; k < b; ++k) {
+                        const unsigned sb = s[k] != 0, rb = r[k] != 0;
+                        n11 += sb & rb;
+                        n1x += sb;
+                        nx1 += rb;
+                    }
+                }
+            }
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&out.fsum, sum);
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                n11 += __shfl_xor(n11, sft, 64);
+                n1x += __shfl_xor(n1x, sft, 64);
+                nx1 += __shfl_xor(nx1, sft, 64);
+            }
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&out.n11, n11);
+                atomicAdd(&out.n1x, n1x);
+                atomicAdd(&out.nx1, nx1);
+            }
+        } else {
+            const float* s = reinterpret_cast<const float*>(cd.s);
+            const float* r = reinterpret_cast<const float*>(cd.r) + d;
+            double sum = 0.0;
+            for (int i = a + VEC * (int)threadIdx.x; i < b; i += VEC * 256) {
+                if (i + VEC <= b) {
+                    float4 sv, rv;
+                    __builtin_memcpy(&sv, s + i, 16);
+                    __builtin_memcpy(&rv, r + i, 16);
+                    sum += (2.0 * (double)sv.x - 1.0) * (2.0 * (double)rv.x - 1.0);
+                    sum += (2.0 * (double)sv.y - 1.0) * (2.0 * (double)rv.y - 1.0);
+                    sum += (2.0 * (double)sv.z - 1.0) * (2.0 * (double)rv.z - 1.0);
+                    sum += (2.0 * (double)sv.w - 1.0) * (2.0 * (double)rv.w - 1.0);
+                } else {
+                    for (int k = i; k < b; ++k) sum += (2.0 * (double)s[k] - 1.0) * (2.0 * (double)r[k] - 1.0);
+                }
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+            // fixed-order combine of the four waves: the result does not depend on scheduling
+            __shared__ double s_part[4];
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) out.part[blockIdx.x] = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+        }
     }
 }
 
 FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
-    if (dt != 0) return a.fsum;
+    if (dt != 0) {
+        double sum = 0.0;
+        for (int i = 0; i < RSEG; ++i) sum += a.part[i];
+        return sum;
+    }
     const int i0 = d < 0 ? -d : 0;
     const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
     const long long ov = i1 > i0 ? (long long)(i1 - i0) : 0;

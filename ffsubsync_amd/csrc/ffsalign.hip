@@ -60,19 +60,24 @@ size_t col_lds_bytes(int L) {
 }
 size_t row_lds_bytes(int L) {
     const int rows = 256 / (L / 16);
-    return (size_t)rows * (L + L / 32) * sizeof(cf);
+    return (size_t)rows * (L + L / 16) * sizeof(cf);
 }
 
-// stage tables of Shape<L>: [R1][16] then [R2][256], entry (r, jm) = exp(-2*pi*i*r*jm/(Ns*R))
+// stage tables of Shape<L>: stage 1 (Ns = 16) then stage 2 (Ns = 256).  A radix-16 stage stores the
+// six powers e in {1,2,3,4,8,12} of w = exp(-2*pi*i*jm/(Ns*16)) as [6][Ns]; a smaller radix R stores
+// w^r as [R][Ns].
 std::vector<cf> make_stage_tables(int L) {
     const int LT = L / 16;
     const int R1 = LT >= 16 ? 16 : LT;
     const int R2 = L / (16 * R1);
     std::vector<cf> t;
     auto add = [&](int R, int Ns) {
-        for (int r = 0; r < R; ++r)
+        static const int pw16[6] = {1, 2, 3, 4, 8, 12};
+        const int rows = (R == 16) ? 6 : R;
+        for (int i = 0; i < rows; ++i)
             for (int jm = 0; jm < Ns; ++jm) {
-                const double a = -2.0 * M_PI * (double)r * (double)jm / ((double)Ns * (double)R);
+                const int e = (R == 16) ? pw16[i] : i;
+                const double a = -2.0 * M_PI * (double)e * (double)jm / ((double)Ns * (double)R);
                 t.push_back(make_float2((float)cos(a), (float)sin(a)));
             }
     };
@@ -202,31 +207,34 @@ int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, hipStream
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
 
-template <int L>
+template <int L, bool SEP>
 int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
     static bool attr_done = false;
     const size_t lds = row_lds_bytes(L);
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_mid<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mid<L, SEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     constexpr int ROWS = 256 / (L / 16);
     dim3 grid(p->N1 / ROWS, n_pairs);
-    // work is laid out with max_slots per pair; the kernel strides by n_slots, so callers keep them equal
-    hipLaunchKernelGGL((k_mid<L>), grid, dim3(256), lds, st, p->work, p->N1, p->log2C, (long long)p->N, n_slots,
+    hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2C, (long long)p->N, n_slots,
                        (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
+    const bool sep = (p->N2 / 16) >= p->C;
+#define FFS_MID(L) \
+    case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, st)
     switch (p->N2) {
-        case 256: return launch_mid_inst<256>(p, n_pairs, n_slots, st);
-        case 512: return launch_mid_inst<512>(p, n_pairs, n_slots, st);
-        case 1024: return launch_mid_inst<1024>(p, n_pairs, n_slots, st);
-        case 2048: return launch_mid_inst<2048>(p, n_pairs, n_slots, st);
-        case 4096: return launch_mid_inst<4096>(p, n_pairs, n_slots, st);
+        FFS_MID(256);
+        FFS_MID(512);
+        FFS_MID(1024);
+        FFS_MID(2048);
+        FFS_MID(4096);
     }
+#undef FFS_MID
     return fail(FFS_E_INVALID, "unsupported row length %d", p->N2);
 }
 
@@ -318,7 +326,8 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
     cd->r1 = mapped(ref.hi);
     const double as = fmax(fabs(cd->s0), fabs(cd->s1)), ar = fmax(fabs(cd->r0), fabs(cd->r1));
     const double lg = (double)ilog2(p->N > 2 ? p->N : 2);
-    cd->margin = (float)(4.0 * 5.9604645e-08 * lg * sqrt((double)S * (double)R) * as * ar);
+    // measured max fp32 error is ~0.02 of eps*log2(N)*sqrt(S*R)*|s||r| (N = 2^12..2^22); nominate within 0.5x
+    cd->margin = (float)(0.5 * 5.9604645e-08 * lg * sqrt((double)S * (double)R) * as * ar);
     return FFS_OK;
 }
 
@@ -529,11 +538,9 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
                 if (dtype == FFS_DTYPE_U8)
-                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, KNOM, np * n_cand), dim3(256), 0, st, dc, dn, da,
-                                       first_cand);
+                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
                 else
-                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, KNOM, np * n_cand), dim3(256), 0, st, dc, dn, da,
-                                       first_cand);
+                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
             }
             HIP_TRY(hipGetLastError());
         }

@@ -41,7 +41,18 @@ def main():
         per = []
         for cand in c["cands"]:
             score, offset = FFTAligner(max_offset_samples=c["max_offset"]).fit_transform(c["ref"], cand, get_score=True)
-            per.append({"score": fnum(score), "offset": int(offset)})
+            # uniqueness of the winner (offsets are only defined when the top-2 gap > 0.5)
+            al = FFTAligner(max_offset_samples=c["max_offset"])
+            r_, s_ = [list(map(int, x)) if isinstance(x, str) else x for x in (c["ref"], cand)]
+            r_, s_ = 2 * np.array(r_).astype(float) - 1, 2 * np.array(s_).astype(float) - 1
+            n_ = int(2 ** np.ceil(np.log2(len(r_) + len(s_))))
+            conv = np.real(np.fft.ifft(np.fft.fft(np.append(np.zeros(n_ - len(s_)), s_)) *
+                                       np.fft.fft(np.flip(np.append(r_, np.zeros(n_ - len(r_))), 0))))
+            m = al._eliminate_extreme_offsets_from_solutions(conv, s_)
+            fin = np.sort(m[np.isfinite(m)])
+            gap = float(fin[-1] - fin[-2]) if fin.size >= 2 else float("inf")
+            assert gap > 0.5, (name, gap)
+            per.append({"score": fnum(score), "offset": int(offset), "top2_gap": repr(gap)})
         entry = {"max_offset": c["max_offset"], "per_candidate": per,
                  "digest": golden_cases.digest([np.array(list(map(int, c["ref"]))) if isinstance(c["ref"], str) else c["ref"]]
                                                  + [np.array(list(map(int, s))) if isinstance(s, str) else s for s in c["cands"]])}

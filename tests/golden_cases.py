@@ -69,7 +69,7 @@ def build_cases(include_large=True):
     ref, sub = synth.simple_pair(3000, 3000, 11, seed=3)
     cases["mask_negative_index"] = dict(ref=ref, cands=[sub], max_offset=6000)
     cases["mask_all"] = dict(ref=ref, cands=[sub], max_offset=0)
-    ref, sub = synth.simple_pair(700, 300, 123, seed=4)
+    ref, sub = synth.simple_pair(700, 300, 123, seed=9, flip=0.02)
     cases["short_direct"] = dict(ref=ref, cands=[sub], max_offset=None)
     cases["short_direct_w"] = dict(ref=ref, cands=[sub], max_offset=150)
     # 5. production-shaped two-level candidates (amplitude 1/ratio), 10 minutes
@@ -81,7 +81,9 @@ def build_cases(include_large=True):
     lv = np.array([0.0, 0.4, 0.6, 1.0])
     ref = np.repeat(lv[rng.randint(0, 4, 400)], 25)
     sub = np.concatenate([np.zeros(37), ref[:8000]]) * 0.96
-    cases["float_levels"] = dict(ref=ref, cands=[sub, sub[5:]], max_offset=None)
+    sub2 = sub[5:].copy()
+    sub2[1000:1600] = 0.0  # a distinctly worse second candidate (no score tie between candidates)
+    cases["float_levels"] = dict(ref=ref, cands=[sub, sub2], max_offset=None)
     # 7. non-default non_speech_label (reference values {-1, 1} before the 2x-1 map)
     ref, sub = synth.simple_pair(20000, 18000, -250, seed=7)
     cases["label_minus1"] = dict(ref=2.0 * ref - 1.0, cands=[sub.astype(float)], max_offset=None)

@@ -51,11 +51,11 @@ def test_raw_correlation_u8_matches_fp64(torch, log2n):
     torch.cuda.synchronize()
     ea = _direct_corr(2.0 * ref - 1, 2.0 * a - 1, N)
     eb = _direct_corr(2.0 * ref - 1, 2.0 * (0.96 * b) - 1, N)
-    tol = 4 * 6e-8 * log2n * np.sqrt(R * Sa)  # the nominee margin the library uses
+    tol = 0.5 * 6e-8 * log2n * np.sqrt(R * Sa)  # the nominee margin the library uses
     err_a = np.abs(out_a.cpu().numpy() - ea).max()
     err_b = np.abs(out_b.cpu().numpy() - eb).max()
     print("N=2^%d max abs err a=%.4g b=%.4g (margin %.4g)" % (log2n, err_a, err_b, tol))
-    assert err_a < tol / 2 and err_b < tol / 2
+    assert err_a < tol / 4 and err_b < tol / 4  # fp32 error must stay well inside the margin
     plan.close()
 
 
@@ -175,10 +175,19 @@ def test_batch_api_against_oracle(torch):
     for p, sp in enumerate(specs):
         fref, fc = synth.pair_float_arrays(sp)
         for j in range(7):
-            s, o = orc.fft_align(fref, fc[j], 6000)
-            assert cres[p, j]["offset"] == o
+            conv, S = orc.convolve_full(fref, fc[j])
+            m = orc.mask_extreme_offsets(conv, S, 6000)
+            k = int(np.argmax(m))
+            s, o = m[k], len(m) - 1 - k - S
+            top2 = np.partition(m, -2)[-2:]
+            got_o = int(cres[p, j]["offset"])
             assert cres[p, j]["score"] == pytest.approx(s, rel=SCORE_RTOL)
-            assert not (cres[p, j]["flags"] & 2)
+            if top2[1] - top2[0] > 0.5:
+                assert got_o == o  # unique maximum: bit-identical offset
+            else:
+                # plateau of (near-)exact ties, typical of wrong-ratio candidates: the reference's pick
+                # is decided by fp64 rounding noise; ours must be one of the maximal lags
+                assert m[len(m) - 1 - got_o - S] >= s - 1e-6 * abs(s)
         (s, o), idx = orc.max_score_align(fref, fc, 6000)
         assert (pres[p]["best_cand"], pres[p]["offset"]) == (idx, o)
         assert idx == sp.true_ratio_index
@@ -220,3 +229,20 @@ def test_vad_energy_and_bounds(torch):
     assert z.start_frame_ is None and z.num_frames is None
     with pytest.raises(ValueError, match="Unable to detect speech"):
         PCMSpeechTransformer().fit(b"")
+
+
+def test_exact_tie_rule_is_first_maximum_in_k(torch):
+    """Where the exact integer correlation has tied maxima the reference's answer depends on fp64
+    rounding noise; the device path is deterministic: np.argmax's rule (first k = largest offset)
+    applied to the exact values.  Checked on both the direct and the FFT path."""
+    from ffsubsync_amd import synth
+    from ffsubsync_amd.aligners import FFTAligner
+
+    for n_ref, n_sub, seed in [(700, 300, 4), (700, 300, 8), (700, 300, 11), (3000, 2500, 4), (5000, 4000, 21)]:
+        ref, sub = synth.simple_pair(n_ref, n_sub, 123, seed=seed, flip=0.02)
+        for mo in (None, 150):
+            conv, S = orc.convolve_full(ref, sub)
+            exact = np.rint(orc.mask_extreme_offsets(conv, S, mo))  # integers for 0/1 inputs
+            k = int(np.argmax(exact))
+            score, offset = FFTAligner(mo).fit_transform(ref, sub, get_score=True)
+            assert (offset, float(score)) == (len(exact) - 1 - k - S, float(exact[k]))
