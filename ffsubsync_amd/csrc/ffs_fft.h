@@ -233,6 +233,7 @@ struct ColAddr {
     int uc;  // u*C + c
     int c;
     FFS_DEV ColAddr(int u, int c_) : uc(u * C + c_), c(c_) {}
+    FFS_DEV void refresh() {}
     template <int Q>
     FFS_DEV int gather() const {
         return uc + (L / 16) * Q * C;
@@ -265,6 +266,7 @@ struct RowAddr {
         gbase = row_base + u + (u >> 4);
         s0base = row_base + 17 * u;
     }
+    FFS_DEV void refresh() {}
     template <int Q>
     FFS_DEV int gather() const {
         return gbase + LT * Q + (LT / 16) * Q;
@@ -316,8 +318,9 @@ FFS_DEV void stage_gather(cf (&v)[16], const cf* lds, int, const Addr& addr) {
 // In: v[q] = x[u + LT*q].  Out: v[q] = X[u + LT*q].  All threads of the block must call it
 // (it contains __syncthreads()).  tw = this thread's preloaded stage twiddles.
 template <int L, class Addr>
-FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, const Addr& addr, const TwRegs<L>& tw) {
+FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& tw) {
     typedef Shape<L> S;
+    addr.refresh();
     stage_first(v);
     if constexpr (S::R1 > 1) {
         __syncthreads();  // previous readers of this LDS region are done

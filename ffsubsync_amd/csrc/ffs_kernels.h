@@ -29,7 +29,7 @@ constexpr int KBLK = 6;   // nominees kept per pass-C block
 constexpr int KNOM = 16;  // nominees kept per candidate
 constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
-struct XformDesc {  // one packed transform (slot 0 of a pair is the reference, b = null)
+struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
     const void* a;
     const void* b;
     int32_t len_a, len_b;
@@ -84,14 +84,19 @@ struct PairResult {
 
 FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 == v2 && d1 > d2); }
 
+// Branch-free sample fetch: the load is always issued (index clamped to element 0, so the sixteen
+// loads of a thread are in flight together) and the zero padding is applied by a select.
 template <int DT>
 FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
-    if (n >= len) return 0.0f;
+    const bool in = n < len;
+    const int idx = in ? n : 0;
+    float val;
     if (DT == 0) {
-        return (reinterpret_cast<const unsigned char*>(p)[n] != 0) ? v1 : v0;
+        val = (reinterpret_cast<const unsigned char*>(p)[idx] != 0) ? v1 : v0;
     } else {
-        return 2.0f * reinterpret_cast<const float*>(p)[n] - 1.0f;
+        val = 2.0f * reinterpret_cast<const float*>(p)[idx] - 1.0f;
     }
+    return in ? val : 0.0f;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -120,9 +125,10 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     for (int q = 0; q < 16; ++q) {
         const int n = (u + LT * q) * N2 + n2;
         v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
-        v[q].y = (d.b != nullptr) ? load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1) : 0.0f;
+        v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
     }
-    fft_regs<L>(v, lds, u, ColAddr<L, C>(u, c), twr);
+    ColAddr<L, C> addr(u, c);
+    fft_regs<L>(v, lds, u, addr, twr);
     // v[q] = Y[k1 = u + LT*q][n2]
     cf* out = work + (size_t)blockIdx.y * N;
 #pragma unroll
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     const int row = threadIdx.x / LT;
     const int u = threadIdx.x % LT;
     const int k1 = blockIdx.x * ROWS + row;
-    const RowAddr<L> addr(row * ROW_STRIDE, u);
+    RowAddr<L> addr(row * ROW_STRIDE, u);
     const int C = 1 << log2C;
     cf* base = work + (size_t)blockIdx.y * n_slots * N;
 
@@ -221,7 +227,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
-    fft_regs<L>(v, lds, u, ColAddr<L, C>(u, c), twr);
+    ColAddr<L, C> addr(u, c);
+    fft_regs<L>(v, lds, u, addr, twr);
     // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LT*q
     const int m1 = tile * C + c;
     if (WRITE) {

@@ -337,6 +337,7 @@ void fill_xform(XformDesc* x, const VecView* a, const VecView* b) {
     x->len_a = (int32_t)a->len;
     x->a0 = (float)mapped(a->lo);
     x->a1 = (float)mapped(a->hi);
+    x->b = a->ptr;  // absent second candidate: any valid address with length 0 (reads are clamped)
     if (b) {
         x->b = b->ptr;
         x->len_b = (int32_t)b->len;
