@@ -200,8 +200,119 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 }
 
 // --------------------------------------------------------------------------------------------
-// pass C.  grid = (N2/C, n_transforms); same thread mapping as pass A.
-// cands[2*xf + {0,1}] describe the real / imaginary candidate of transform xf (S <= 0: absent).
+// Lag-window bookkeeping shared by both pass-C variants.
+struct WinParams {
+    int S[2], lo[2], hi[2];
+    float marg[2];
+};
+
+FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand) {
+    WinParams w;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool present = (2 * kp + h) < n_cand;
+        const CandDesc& cd = cands[cand0 + (present ? 2 * kp + h : 0)];
+        w.S[h] = cd.S;
+        w.lo[h] = cd.d_lo;
+        w.hi[h] = (present && !(cd.flags & 1)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
+        w.marg[h] = cd.margin;
+    }
+    return w;
+}
+
+// Per-block argmax + near-tie nominees of the NV values each thread holds: v[q].x belongs to the
+// real-part candidate, v[q].y to the imaginary-part one, at circular lag m_of(q) (< 0: no value).
+// Ordering: larger value wins, ties go to the larger offset d (= np.argmax's first index in k).
+template <int NV, int NW, class MOf>
+FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, unsigned char* smem, int tid,
+                            BlockNom* __restrict__ out_a, BlockNom* __restrict__ out_b) {
+    float bv[2] = {-INFINITY, -INFINITY};
+    int bd[2] = {INT32_MIN, INT32_MIN};
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int m = m_of(q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
+            const float val = h ? v[q].y : v[q].x;
+            if (ok && better(val, d, bv[h], bd[h])) {
+                bv[h] = val;
+                bd[h] = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv[h], sft, 64);
+            const int od = __shfl_xor(bd[h], sft, 64);
+            if (better(ov, od, bv[h], bd[h])) {
+                bv[h] = ov;
+                bd[h] = od;
+            }
+        }
+    }
+    __syncthreads();  // callers are done with their LDS data; reuse it as scratch
+    float* s_val = reinterpret_cast<float*>(smem);         // [NW][2]
+    int* s_d = reinterpret_cast<int*>(smem + 256);         // [NW][2]
+    float* s_bmax = reinterpret_cast<float*>(smem + 512);  // [2]
+    int* s_cnt = reinterpret_cast<int*>(smem + 528);       // [2]
+    float* s_lval = reinterpret_cast<float*>(smem + 544);  // [2][KBLK]
+    int* s_ld = reinterpret_cast<int*>(smem + 544 + 64);   // [2][KBLK]
+    const int wave = tid / 64, lane = tid % 64;
+    if (lane == 0) {
+        s_val[wave * 2 + 0] = bv[0];
+        s_val[wave * 2 + 1] = bv[1];
+        s_d[wave * 2 + 0] = bd[0];
+        s_d[wave * 2 + 1] = bd[1];
+    }
+    __syncthreads();
+    if (tid < 2) {
+        float fv = -INFINITY;
+        int fd = INT32_MIN;
+        for (int w = 0; w < NW; ++w)
+            if (better(s_val[w * 2 + tid], s_d[w * 2 + tid], fv, fd)) {
+                fv = s_val[w * 2 + tid];
+                fd = s_d[w * 2 + tid];
+            }
+        s_bmax[tid] = fv;
+        s_cnt[tid] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const float thr = s_bmax[h] - wp.marg[h];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const int m = m_of(q);
+            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
+            const float val = h ? v[q].y : v[q].x;
+            if (ok && val >= thr) {
+                const int slot = atomicAdd(&s_cnt[h], 1);
+                if (slot < KBLK) {
+                    s_lval[h * KBLK + slot] = val;
+                    s_ld[h * KBLK + slot] = d;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2) {
+        BlockNom& o = tid ? *out_b : *out_a;
+        o.bmax = s_bmax[tid];
+        o.cnt = s_cnt[tid];
+        for (int i = 0; i < KBLK; ++i) {
+            o.val[i] = s_lval[tid * KBLK + i];
+            o.d[i] = s_ld[tid * KBLK + i];
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// pass C.  grid = (N2/C, n_candidate_transforms); same thread mapping as pass A.
 // grid.y enumerates the candidate transforms of the pairs in flight: ly = lp*n_packed + k uses work
 // slot lp*n_slots + 1 + k and candidates first_cand + lp*n_cand + {2k, 2k+1}.
 template <int L, int C, bool WRITE>
@@ -240,105 +351,97 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
         }
         return;
     }
+    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    block_nominees<16, NW>(
+        v, [&](int q) { return m1 + N2 * (u + LT * q); }, wp, (int)N, smem, tid,
+        &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
+}
 
-    const int nN = (int)N;
-    float bv[2];
-    int bd[2];
-    float marg[2];
-    int S2[2], lo2[2], hi2[2];
+// --------------------------------------------------------------------------------------------
+// pass C, pruned to the output bins the lag window can reach.  The last pass produces
+// out[m1 + N2*m2]; a window of +-max_offset lags only ever touches a few values of m2 (four of 512
+// for +-6000 lags at N = 2^21), so instead of the full length-N1 column transform each needed bin is
+// evaluated directly, out[m2] = sum_k1 Y[k1] * W_N1^(k1*m2): one streaming read of the tile, a
+// handful of multiply-adds per element, no LDS exchange of the data.  Used when the union of bins
+// over the call's candidates has at most MAXBINS entries; otherwise k_pass_c runs.
+constexpr int MAXBINS = 8;
+struct BinList {
+    int n;
+    int b[MAXBINS];  // signed bin offsets (m2 or m2 - N1)
+};
+
+template <int L, int C>
+__global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __restrict__ work, int N2, long long N,
+                                                                const cf* __restrict__ twn1,
+                                                                const CandDesc* __restrict__ cands, int first_cand,
+                                                                int n_cand, int n_packed, int n_slots,
+                                                                BlockNom* __restrict__ bnom, BinList bins) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int LT = L / 16;
+    constexpr int NT = LT * C;
+    constexpr int NW = NT / 64;
+    constexpr int UPW = (C < 64) ? (64 / C) : 1;  // distinct u per wave
+    constexpr int NG = LT / UPW;                   // partial sums per (bin, column)
+    cf* s_tw = reinterpret_cast<cf*>(smem + 1024);                     // [L]   W_L^k
+    cf* s_part = reinterpret_cast<cf*>(smem + 1024 + L * sizeof(cf));  // [MAXBINS][NG][C]
+    const int tid = threadIdx.x;
+    const int c = tid % C;
+    const int u = tid / C;
+    const int tile = blockIdx.x;
+    const int ly = blockIdx.y;
+    const int lp = ly / n_packed, kp = ly % n_packed;
+    const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
+    cf v[16];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool present = (2 * kp + h) < n_cand;
-        const CandDesc& cd = cands[first_cand + lp * n_cand + (present ? 2 * kp + h : 0)];
-        S2[h] = cd.S;
-        lo2[h] = cd.d_lo;
-        hi2[h] = (present && !(cd.flags & 1)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
-        marg[h] = cd.margin;
-        bv[h] = -INFINITY;
-        bd[h] = INT32_MIN;
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int m = m1 + N2 * (u + LT * q);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int d = (m <= nN - 1 - S2[h]) ? m : m - nN;
-            const bool ok = (d >= lo2[h]) && (d <= hi2[h]);
-            const float val = h ? v[q].y : v[q].x;
-            if (ok && better(val, d, bv[h], bd[h])) {
-                bv[h] = val;
-                bd[h] = d;
-            }
-        }
-    }
-    // block argmax per candidate: wave shuffle, then across waves through LDS
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            const float ov = __shfl_xor(bv[h], sft, 64);
-            const int od = __shfl_xor(bd[h], sft, 64);
-            if (better(ov, od, bv[h], bd[h])) {
-                bv[h] = ov;
-                bd[h] = od;
-            }
-        }
-    }
-    __syncthreads();  // FFT tile no longer needed; reuse LDS as scratch
-    float* s_val = reinterpret_cast<float*>(smem);              // [NW][2]
-    int* s_d = reinterpret_cast<int*>(smem + 256);              // [NW][2]
-    float* s_bmax = reinterpret_cast<float*>(smem + 512);       // [2]
-    int* s_cnt = reinterpret_cast<int*>(smem + 528);            // [2]
-    float* s_lval = reinterpret_cast<float*>(smem + 544);       // [2][KBLK]
-    int* s_ld = reinterpret_cast<int*>(smem + 544 + 64);        // [2][KBLK]
-    const int wave = tid / 64, lane = tid % 64;
-    if (lane == 0) {
-        s_val[wave * 2 + 0] = bv[0];
-        s_val[wave * 2 + 1] = bv[1];
-        s_d[wave * 2 + 0] = bd[0];
-        s_d[wave * 2 + 1] = bd[1];
-    }
+    for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
+    for (int i = tid; i < L; i += NT) s_tw[i] = twn1[i];
     __syncthreads();
-    if (tid < 2) {
-        float fv = -INFINITY;
-        int fd = INT32_MIN;
-        for (int w = 0; w < NW; ++w)
-            if (better(s_val[w * 2 + tid], s_d[w * 2 + tid], fv, fd)) {
-                fv = s_val[w * 2 + tid];
-                fd = s_d[w * 2 + tid];
-            }
-        s_bmax[tid] = fv;
-        s_cnt[tid] = 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const float thr = s_bmax[h] - marg[h];
+    const int lane = tid % 64;
+    for (int i = 0; i < bins.n; ++i) {
+        const int b = bins.b[i];
+        cf a = mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int m = m1 + N2 * (u + LT * q);
-            const int d = (m <= nN - 1 - S2[h]) ? m : m - nN;
-            const bool ok = (d >= lo2[h]) && (d <= hi2[h]);
-            const float val = h ? v[q].y : v[q].x;
-            if (ok && val >= thr) {
-                const int slot = atomicAdd(&s_cnt[h], 1);
-                if (slot < KBLK) {
-                    s_lval[h * KBLK + slot] = val;
-                    s_ld[h * KBLK + slot] = d;
-                }
+            const cf w = s_tw[((u + LT * q) * b) & (L - 1)];
+            a.x = fmaf(v[q].x, w.x, fmaf(-v[q].y, w.y, a.x));
+            a.y = fmaf(v[q].x, w.y, fmaf(v[q].y, w.x, a.y));
+        }
+        if constexpr (C < 64) {
+#pragma unroll
+            for (int sft = C; sft < 64; sft <<= 1) {  // lanes with equal c hold different u
+                a.x += __shfl_xor(a.x, sft, 64);
+                a.y += __shfl_xor(a.y, sft, 64);
             }
+            if (lane < C) s_part[(i * NG + u / UPW) * C + c] = a;
+        } else {
+            s_part[(i * NG + u) * C + c] = a;
         }
     }
     __syncthreads();
-    if (tid < 2) {
-        BlockNom& o = bnom[((size_t)ly * 2 + tid) * gridDim.x + tile];
-        o.bmax = s_bmax[tid];
-        o.cnt = s_cnt[tid];
-        for (int i = 0; i < KBLK; ++i) {
-            o.val[i] = s_lval[tid * KBLK + i];
-            o.d[i] = s_ld[tid * KBLK + i];
+    // thread t finishes (bin, column) pairs t, t + NT, ...  (more than one only when LT < MAXBINS)
+    constexpr int NVF = (LT >= MAXBINS) ? 1 : (MAXBINS / LT);
+    cf val[NVF];
+    int mm[NVF];
+#pragma unroll
+    for (int j = 0; j < NVF; ++j) {
+        val[j] = mk(0.f, 0.f);
+        mm[j] = -1;
+        const int idx = tid + j * NT;
+        if (idx < bins.n * C) {
+            const int i = idx / C, cc = idx % C;
+            for (int g = 0; g < NG; ++g) {
+                const cf p = s_part[(i * NG + g) * C + cc];
+                val[j].x += p.x;
+                val[j].y += p.y;
+            }
+            const int m2 = (bins.b[i] + L) & (L - 1);
+            mm[j] = tile * C + cc + N2 * m2;
         }
     }
+    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    block_nominees<NVF, NW>(
+        val, [&](int j) { return mm[j]; }, wp, (int)N, smem, tid, &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile],
+        &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -101,10 +102,12 @@ struct ffs_plan {
     int N1 = 0, N2 = 0, C = 0, log2C = 0;
     int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
     bool direct_only = false;
+    bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
     cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
+    cf* twn1 = nullptr;                       // W_N1^k, k < N1 (pruned pass C)
     cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
     BlockNom* bnom = nullptr;                 // [pairs_in_flight*n_packed*2][tiles]
     // per-call descriptor storage (grown on demand)
@@ -274,6 +277,70 @@ int launch_pass_c(const ffs_plan* p, const CandDesc* cands, int first_cand, int 
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
 
+size_t pruned_lds_bytes(int L) {
+    const int C = tile_cols(L), LT = L / 16;
+    const int upw = C < 64 ? 64 / C : 1;
+    return 1024 + (size_t)L * sizeof(cf) + (size_t)MAXBINS * (LT / upw) * C * sizeof(cf);
+}
+
+template <int L, int C>
+int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed,
+                              int n_slots, int n_pairs, const BinList& bins, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = pruned_lds_bytes(L);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c_pruned<L, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    dim3 grid(p->N2 / C, n_pairs * n_packed);
+    hipLaunchKernelGGL((k_pass_c_pruned<L, C>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
+                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int launch_pass_c_pruned(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
+                         int n_pairs, const BinList& bins, hipStream_t st) {
+#define FFS_PCP(L, C) \
+    case L: return launch_pass_c_pruned_inst<L, C>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, st)
+    switch (p->N1) {
+        FFS_PCP(16, 256);
+        FFS_PCP(32, 128);
+        FFS_PCP(64, 64);
+        FFS_PCP(128, 32);
+        FFS_PCP(256, 16);
+        FFS_PCP(512, 16);
+        FFS_PCP(1024, 16);
+        FFS_PCP(2048, 8);
+        FFS_PCP(4096, 4);
+    }
+#undef FFS_PCP
+    return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
+}
+
+// Output bins m2 = m / N2 of the last pass that the lag window [d_lo, d_hi] of a candidate touches
+// (m = d for d >= 0, m = d + N for d < 0), as signed offsets in (-N1/2, N1/2].
+void add_bins(const ffs_plan* p, const CandDesc& cd, std::vector<int>* bins, bool* overflow) {
+    if (cd.flags & FFS_FLAG_EMPTY_WINDOW) return;
+    auto add_range = [&](int64_t m_lo, int64_t m_hi) {
+        for (int64_t m2 = m_lo / p->N2; m2 <= m_hi / p->N2; ++m2) {
+            int b = (int)m2;
+            if (b > p->N1 / 2) b -= p->N1;
+            bool seen = false;
+            for (int x : *bins) seen |= (x == b);
+            if (!seen) {
+                if ((int)bins->size() >= MAXBINS) {
+                    *overflow = true;
+                    return;
+                }
+                bins->push_back(b);
+            }
+        }
+    };
+    if (cd.d_hi >= 0) add_range(cd.d_lo > 0 ? cd.d_lo : 0, cd.d_hi);
+    if (!*overflow && cd.d_lo < 0) add_range(p->N + cd.d_lo, p->N + (cd.d_hi < -1 ? cd.d_hi : -1));
+}
+
 // Python slice semantics of  x[:stop] = v  /  x[start:] = v  on a length-n array
 int64_t py_clamp(int64_t i, int64_t n) {
     if (i < 0) i += n;
@@ -375,6 +442,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->max_cand = max_cand;
     p->max_slots = 1 + (max_cand + 1) / 2;
     HIP_TRY(hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
+    {
+        const char* e = getenv("FFS_DISABLE_PRUNED_PASS_C");
+        p->allow_pruned = !(e && e[0] == '1');
+    }
     if (n_fft < kMinFftN) {
         p->direct_only = true;
         *out = p;
@@ -409,6 +480,11 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if ((rc = upload(&p->tbM, tb, &p->workspace_bytes))) return rc;
         if ((rc = upload(&p->tsM, ts, &p->workspace_bytes))) return rc;
     }
+    {
+        std::vector<cf> t((size_t)N1);
+        for (int k = 0; k < N1; ++k) t[k] = wn(N1, k);
+        if ((rc = upload(&p->twn1, t, &p->workspace_bytes))) return rc;
+    }
     const size_t work_bytes = (size_t)pairs_in_flight * p->max_slots * N * sizeof(cf);
     HIP_TRY(hipMalloc((void**)&p->work, work_bytes));
     p->workspace_bytes += (int64_t)work_bytes;
@@ -429,6 +505,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->tsA);
     (void)hipFree(p->tbM);
     (void)hipFree(p->tsM);
+    (void)hipFree(p->twn1);
     (void)hipFree(p->work);
     (void)hipFree(p->bnom);
     (void)hipFree(p->dev_desc);
@@ -490,6 +567,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
         for (int k = 0; k < n_packed; ++k)
             fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
     }
+    // last-pass bins reachable by any lag window of this call (pruned pass C when there are few)
+    std::vector<int> bin_set;
+    bool bins_overflow = p->direct_only;
+    for (size_t i = 0; i < n_cands && !bins_overflow; ++i) add_bins(p, hc[i], &bin_set, &bins_overflow);
+    BinList bins;
+    memset(&bins, 0, sizeof bins);
+    bins.n = (int)bin_set.size();
+    for (int i = 0; i < bins.n; ++i) bins.b[i] = bin_set[i];
+    const bool pruned = p->allow_pruned && !bins_overflow && bins.n > 0 && bins.n * 2 <= p->N1;
     char* db = (char*)p->dev_desc;
     HIP_TRY(hipMemcpyAsync(db, hb, host_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(p->upload_done, st));
@@ -527,7 +613,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_PASS_C);
-                rc = launch_pass_c<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, st);
+                rc = pruned ? launch_pass_c_pruned(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, st)
+                            : launch_pass_c<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, st);
             }
             if (rc) return rc;
             {

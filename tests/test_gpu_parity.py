@@ -246,3 +246,21 @@ def test_exact_tie_rule_is_first_maximum_in_k(torch):
             k = int(np.argmax(exact))
             score, offset = FFTAligner(mo).fit_transform(ref, sub, get_score=True)
             assert (offset, float(score)) == (len(exact) - 1 - k - S, float(exact[k]))
+
+
+def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
+    """With a lag window the last pass only evaluates the output bins the window can reach; the
+    result records must be identical to those of the full column transform."""
+    from ffsubsync_amd import batch, synth
+
+    specs = [synth.make_pair_spec(200 + i, duration_s=1200.0) for i in range(3)]
+    db = batch.build_device_batch(specs)
+    n_fft = db.required_fft_length()
+    pruned = batch.BatchAligner(n_fft, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+    monkeypatch.setenv("FFS_DISABLE_PRUNED_PASS_C", "1")
+    full = batch.BatchAligner(n_fft, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+    assert np.array_equal(pruned[0]["offset"], full[0]["offset"]) and np.array_equal(pruned[0]["score"], full[0]["score"])
+    assert np.array_equal(pruned[1], full[1])
+    assert np.abs(pruned[0]["score_f32"] - full[0]["score_f32"]).max() < 0.05
+    for p, sp in enumerate(specs):
+        assert pruned[1][p]["best_cand"] == sp.true_ratio_index
