@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
-    ap.add_argument("--pairs-in-flight", type=int, default=4)
+    ap.add_argument("--pairs-in-flight", type=int, default=16)
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     return ap.parse_args()
