@@ -35,6 +35,9 @@ def parse():
     ap.add_argument("--pairs-in-flight", type=int, default=16)
     ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--full-length", action="store_true",
+                    help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
+                         "alias-free length the lag window allows")
     return ap.parse_args()
 
 
@@ -63,7 +66,9 @@ def main():
     P = args.pairs
     specs = [synth.make_pair_spec(rank * P + i, duration_s=args.duration) for i in range(P)]
     db = batch.build_device_batch(specs)
-    n_fft = db.required_fft_length()
+    n_ref = db.required_fft_length(None)  # the reference's N = 2^ceil(log2(R+S)) (aligners.py:67-68)
+    # the +-6000 lag window lets the device use the shortest alias-free transform (ffs_plan_length)
+    n_fft = n_ref if args.full_length else db.required_fft_length(6000)
     aligner = batch.BatchAligner(n_fft, n_cand, max_offset_samples=6000, pairs_in_flight=args.pairs_in_flight)
     cand_out = torch.empty(P * n_cand * 24, dtype=torch.uint8, device="cuda")
     pair_out = torch.empty(P * 24, dtype=torch.uint8, device="cuda")
@@ -124,17 +129,18 @@ def main():
         "config": {
             "workload": "configs[2]: %d x %.0f s@100 Hz pairs per GPU, MaxScoreAligner over 7 framerate ratios, "
                         "max_offset_samples=6000" % (P, args.duration),
-            "n_fft": n_fft,
+            "n_fft_reference": n_ref,
+            "n_fft_device": n_fft,
             "pairs_per_gpu": P,
             "pairs_in_flight": args.pairs_in_flight,
             "parallelism": "pairs sharded by rank, all-gather of 24 B/pair results" if world > 1 else "single GPU",
         },
         "offset_match": {"pairs_matching_ground_truth": truth_ok, "pairs": P, "ambiguous_flags": ambiguous},
         "solve_normaliser": {
-            "bytes_per_solve": 168 * n_fft,
-            "achieved_GBps": solves_per_s * 168 * n_fft / 1e9,
-            "frac_of_8TBps_per_gpu": solves_per_s * 168 * n_fft / (HBM_PEAK * world),
-            "frac_of_copy_ceiling_per_gpu": solves_per_s * 168 * n_fft / (HBM_COPY_CEILING * world),
+            "bytes_per_solve": 168 * n_ref,
+            "achieved_GBps": solves_per_s * 168 * n_ref / 1e9,
+            "frac_of_8TBps_per_gpu": solves_per_s * 168 * n_ref / (HBM_PEAK * world),
+            "frac_of_copy_ceiling_per_gpu": solves_per_s * 168 * n_ref / (HBM_COPY_CEILING * world),
         },
     }
 
@@ -149,7 +155,7 @@ def main():
             pairs_per_launch = P * args.steps / n
             entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
             if k in share:
-                alg = share[k] * n_fft * pairs_per_launch
+                alg = share[k] * n_ref * pairs_per_launch
                 entry["algorithmic_bytes_per_launch"] = alg
                 entry["achieved_GBps"] = alg / (ms / n * 1e-3) / 1e9
             per_kernel[k] = entry

@@ -34,6 +34,7 @@ assert CAND_RESULT_DTYPE.itemsize == 24 and PAIR_RESULT_DTYPE.itemsize == 24
 # every symbol include/ffsubsync_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = (
     "ffs_fft_length",
+    "ffs_plan_length",
     "ffs_plan_create",
     "ffs_plan_destroy",
     "ffs_plan_workspace_bytes",
@@ -80,6 +81,8 @@ def load():
         c = ctypes
         lib.ffs_fft_length.restype = c.c_int64
         lib.ffs_fft_length.argtypes = [c.c_int64, c.c_int64]
+        lib.ffs_plan_length.restype = c.c_int64
+        lib.ffs_plan_length.argtypes = [c.c_int64, c.c_int64, c.c_int64]
         lib.ffs_plan_create.restype = c.c_int
         lib.ffs_plan_create.argtypes = [c.c_int, c.c_int64, c.c_int, c.c_int, c.POINTER(c.c_void_p)]
         lib.ffs_plan_destroy.restype = c.c_int
@@ -123,6 +126,13 @@ def check(code: int) -> None:
 
 def fft_length(ref_len: int, sub_len: int) -> int:
     return int(load().ffs_fft_length(int(ref_len), int(sub_len)))
+
+
+def plan_length(ref_len: int, sub_len: int, max_offset_samples: Optional[int]) -> int:
+    """Transform length the device needs: the reference's N without a lag window, possibly shorter
+    (alias-free for the windowed lags) with one."""
+    mo = -1 if max_offset_samples is None else int(max_offset_samples)
+    return int(load().ffs_plan_length(int(ref_len), int(sub_len), mo))
 
 
 def require_gpu():

@@ -53,7 +53,7 @@ class _Vec:
 
 
 def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Optional[int],
-                filter_max_offset: Optional[int] = None):
+                filter_max_offset: Optional[int] = None, full_length: bool = False):
     """Solve a list of (reference, [candidates]) problems, all with the same candidate count, in one
     native batch.  Returns (cand_results, pair_results) as numpy structured arrays."""
     torch = _native.require_gpu()
@@ -75,7 +75,10 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
                     "(reference length=%d, subtitle length=%d); "
                     "the reference or subtitles may contain no detectable speech" % (len(ref), len(s))
                 )
-            n_fft = max(n_fft, _native.fft_length(len(ref), len(s)))
+            # full_length: always the reference's own N; otherwise the (possibly shorter) alias-free
+            # length for the lag window -- results are identical either way
+            n_fft = max(n_fft, _native.fft_length(len(ref), len(s)) if full_length
+                        else _native.plan_length(len(ref), len(s), max_offset_samples))
     if n_fft > _native.MAX_FFT_LENGTH:
         raise ValueError("inputs too long for the device transform (N=%d > 2^24)" % n_fft)
     all_two_level = all(v.two_level for v in vecs)

@@ -33,11 +33,13 @@ class DeviceBatch:
     def n_cand(self) -> int:
         return self.offs.shape[1] - 1
 
-    def required_fft_length(self) -> int:
+    def required_fft_length(self, max_offset_samples: Optional[int] = None) -> int:
+        """Plan length for the whole batch: the reference's N = 2^ceil(log2(R+S)) without a lag window,
+        the alias-free (possibly shorter) length with one (``_native.plan_length``)."""
         n = 2
         for p in range(self.n_pairs):
             for j in range(1, self.offs.shape[1]):
-                n = max(n, _native.fft_length(int(self.lens[p, 0]), int(self.lens[p, j])))
+                n = max(n, _native.plan_length(int(self.lens[p, 0]), int(self.lens[p, j]), max_offset_samples))
         return n
 
 

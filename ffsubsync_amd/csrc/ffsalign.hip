@@ -357,6 +357,26 @@ struct VecView {
     double lo, hi;
 };
 
+// The reference's lag window for (R, S): allowed k in [kA, kB) of its length-n_ref convolve array
+// (aligners.py:31-43), returned as inclusive lags [d_lo, d_hi] (d = n_ref-1-S-k); false if empty.
+bool lag_window(int64_t R, int64_t S, int64_t n_ref, int64_t max_off, int64_t* d_lo, int64_t* d_hi) {
+    int64_t kA = 0, kB = n_ref;
+    if (max_off >= 0) {
+        kA = py_clamp(n_ref - 1 - max_off - S, n_ref);
+        kB = py_clamp(n_ref - 1 + max_off - S, n_ref);
+    }
+    if (kA >= kB) return false;
+    *d_hi = n_ref - 1 - S - kA;
+    *d_lo = n_ref - S - kB;
+    return true;
+}
+
+int64_t next_pow2(int64_t x) {
+    int64_t n = 2;
+    while (n < x) n <<= 1;
+    return n;
+}
+
 // Fill the candidate descriptor for (ref, sub); returns a negative code on error.
 int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd) {
     const int64_t R = ref.len, S = sub.len;
@@ -364,28 +384,24 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
         return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
                     (long long)R, (long long)S);
     const int64_t n_ref = ffs_fft_length(R, S);
-    if (R + S > p->N || n_ref > p->N)
-        return fail(FFS_E_TOO_LONG, "R+S=%lld needs transform length %lld > plan length %lld", (long long)(R + S),
-                    (long long)n_ref, (long long)p->N);
+    const int64_t n_need = ffs_plan_length(R, S, max_off);
+    if (n_need > p->N)
+        return fail(FFS_E_TOO_LONG, "R=%lld S=%lld needs transform length %lld > plan length %lld", (long long)R,
+                    (long long)S, (long long)n_need, (long long)p->N);
     memset(cd, 0, sizeof *cd);
     cd->s = sub.ptr;
     cd->r = ref.ptr;
     cd->S = (int32_t)S;
     cd->R = (int32_t)R;
     cd->n_ref = (int32_t)n_ref;
-    // lag window in k-space (aligners.py:31-43), then mapped to d = n_ref-1-S-k
-    int64_t kA = 0, kB = n_ref;
-    if (max_off >= 0) {
-        kA = py_clamp(n_ref - 1 - max_off - S, n_ref);
-        kB = py_clamp(n_ref - 1 + max_off - S, n_ref);
-    }
-    if (kA >= kB) {
+    int64_t d_lo = 0, d_hi = -1;
+    if (!lag_window(R, S, n_ref, max_off, &d_lo, &d_hi)) {
         cd->flags = FFS_FLAG_EMPTY_WINDOW;
         cd->d_lo = 0;
         cd->d_hi = -1;
     } else {
-        cd->d_hi = (int32_t)(n_ref - 1 - S - kA);
-        cd->d_lo = (int32_t)(n_ref - S - kB);
+        cd->d_lo = (int32_t)d_lo;
+        cd->d_hi = (int32_t)d_hi;
     }
     cd->s0 = mapped(sub.lo);
     cd->s1 = mapped(sub.hi);
@@ -426,6 +442,21 @@ int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len) {
     // log(x)/log(2) in doubles, which is not exact at every power of two; keep the same quirk.
     const double bits = log((double)(ref_len + sub_len)) / log(2.0);
     return (int64_t)pow(2.0, ceil(bits));
+}
+
+int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_samples) {
+    const int64_t n_ref = ffs_fft_length(ref_len, sub_len);
+    if (n_ref == 0 || max_offset_samples < 0) return n_ref;
+    int64_t d_lo, d_hi;
+    if (!lag_window(ref_len, sub_len, n_ref, max_offset_samples, &d_lo, &d_hi)) return 2;  // nothing to evaluate
+    // lags d in [d_lo, d_hi] of a length-n circular correlation equal the linear ones iff
+    // d - n <= -S and d + n >= R for all of them; the kernels also need S <= n and d_hi <= n-1-S.
+    int64_t need = sub_len + d_hi + 1;
+    if (ref_len - d_lo + 1 > need) need = ref_len - d_lo + 1;
+    if (sub_len > need) need = sub_len;
+    if (ref_len > need) need = ref_len;
+    const int64_t n = next_pow2(need);
+    return n < n_ref ? n : n_ref;
 }
 
 int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand, ffs_plan** out) {

@@ -66,6 +66,14 @@ typedef struct ffs_pair_result {
  * 2**ceil(log2(R+S)) (aligners.py:67-68).  Returns 0 if either length is <= 0. */
 int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len);
 
+/* Smallest power-of-two transform length a plan needs for one (reference, candidate) solve.
+ * Without a lag window this is ffs_fft_length (the full linear correlation).  With
+ * max_offset_samples >= 0 only lags inside the reference's window [d_lo, d_hi] are ever looked at,
+ * and a circular correlation of any length n >= max(S + d_hi, R - d_lo) + 1 reproduces those lags
+ * exactly (no aliasing reaches them), so a shorter transform gives bit-identical results:
+ * 2^20 instead of 2^21 for 2 h @ 100 Hz inputs with the default +-6000 window. */
+int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_samples);
+
 /* Create a plan for transform length n_fft (power of two, 2 <= n_fft <= 2^24) on `device`.
  * pairs_in_flight: how many (reference, candidates) problems share one sweep of the
  * A/mid/C kernels (sizes the workspace: pairs_in_flight * (1+ceil(max_cand/2)) * n_fft * 8 B).
@@ -88,7 +96,8 @@ int64_t ffs_plan_workspace_bytes(const ffs_plan* plan);
  * filter_max_offset: MaxScoreAligner.max_offset_samples used to drop candidates
  *   (aligners.py:156-159), -1 = None.
  * cand_out_dev[n_pairs*n_cand], pair_out_dev[n_pairs]: device buffers, written in stream order.
- * All (R, S) must satisfy R+S <= plan n_fft.  Host arrays may be freed after return. */
+ * Every (R, S) must satisfy ffs_plan_length(R, S, max_offset_samples) <= plan n_fft.
+ * Host arrays may be freed after return. */
 int ffs_align_batch(ffs_plan* plan, int n_pairs, int n_cand, int dtype,
                     const void* const* vec_ptr, const int64_t* vec_len,
                     const double* vec_lo, const double* vec_hi,

@@ -39,6 +39,22 @@ def test_host_only_entry_points():
         assert _native.fft_length(x - 1, 1) == int(2 ** math.ceil(math.log(x, 2)))
 
 
+def test_plan_length_never_exceeds_reference_length():
+    import numpy as np
+
+    rng = np.random.RandomState(0)
+    for _ in range(2000):
+        r, s = int(rng.randint(1, 900000)), int(rng.randint(1, 900000))
+        mo = [None, 0, 100, 6000, 10 ** 7][rng.randint(5)]
+        n_ref, n = _native.fft_length(r, s), _native.plan_length(r, s, mo)
+        assert n <= n_ref and (n & (n - 1)) == 0
+        if mo is None:
+            assert n == n_ref
+        elif n > 2:
+            assert n >= max(r, s)  # both vectors fit without wrapping onto themselves
+    assert _native.plan_length(720000, 750751, 6000) == 1 << 20
+
+
 def test_bad_arguments_are_reported_not_thrown():
     lib = _native.load()
     handle = ctypes.c_void_p()

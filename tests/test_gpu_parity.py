@@ -170,7 +170,8 @@ def test_batch_api_against_oracle(torch):
         ref, cands = synth.pair_arrays(sp)
         assert np.array_equal(host[db.offs[p, 0]: db.offs[p, 0] + db.lens[p, 0]], ref)
         assert np.array_equal(host[db.offs[p, 3]: db.offs[p, 3] + db.lens[p, 3]], cands[2])
-    al = batch.BatchAligner(db.required_fft_length(), 7, max_offset_samples=6000, pairs_in_flight=2)
+    assert db.required_fft_length(6000) <= db.required_fft_length(None)
+    al = batch.BatchAligner(db.required_fft_length(6000), 7, max_offset_samples=6000, pairs_in_flight=2)
     cres, pres = al.solve(db)
     for p, sp in enumerate(specs):
         fref, fc = synth.pair_float_arrays(sp)
@@ -255,7 +256,7 @@ def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
 
     specs = [synth.make_pair_spec(200 + i, duration_s=1200.0) for i in range(3)]
     db = batch.build_device_batch(specs)
-    n_fft = db.required_fft_length()
+    n_fft = db.required_fft_length(6000)
     pruned = batch.BatchAligner(n_fft, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
     monkeypatch.setenv("FFS_DISABLE_PRUNED_PASS_C", "1")
     full = batch.BatchAligner(n_fft, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
@@ -264,3 +265,27 @@ def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
     assert np.abs(pruned[0]["score_f32"] - full[0]["score_f32"]).max() < 0.05
     for p, sp in enumerate(specs):
         assert pruned[1][p]["best_cand"] == sp.true_ratio_index
+
+
+def test_window_shortened_transform_equals_full_length(torch):
+    """With a lag window the plan may use a transform shorter than the reference's N (no aliasing
+    reaches the windowed lags, ffs_plan_length): every result record must equal the full-length one."""
+    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd.aligners import _as_array, _Vec, solve_pairs
+
+    assert _native.plan_length(720000, 750751, 6000) == 1 << 20 and _native.fft_length(720000, 750751) == 1 << 21
+    for name in ("config1_6000", "pipeline_10min", "mask100", "mask_negative_index", "sparse2"):
+        c = SMALL[name]
+        pair = [(_Vec(_as_array(c["ref"])), [_Vec(_as_array(s)) for s in c["cands"]])]
+        short = solve_pairs(pair, c["max_offset"], c["max_offset"])
+        full = solve_pairs(pair, c["max_offset"], c["max_offset"], full_length=True)
+        assert np.array_equal(short[0]["offset"], full[0]["offset"]) and np.array_equal(short[0]["score"], full[0]["score"])
+        assert np.array_equal(short[1], full[1])
+    specs = [synth.make_pair_spec(300 + i, duration_s=2400.0) for i in range(3)]
+    db = batch.build_device_batch(specs)
+    n_short, n_full = db.required_fft_length(6000), db.required_fft_length(None)
+    assert n_short < n_full
+    a = batch.BatchAligner(n_short, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+    b = batch.BatchAligner(n_full, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+    assert np.array_equal(a[0]["offset"], b[0]["offset"]) and np.array_equal(a[0]["score"], b[0]["score"])
+    assert np.array_equal(a[1], b[1])
