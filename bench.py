@@ -32,15 +32,65 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
-    ap.add_argument("--pairs-in-flight", type=int, default=32)
+    ap.add_argument("--pairs-in-flight", type=int, default=64)
     ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    ap.add_argument("--no-vad", action="store_true", help="skip the VAD frame-energy sweep figures")
     ap.add_argument("--skip-full-length-record", action="store_true",
                     help="do not append the secondary full-length measurement (used by the PMC runs)")
     ap.add_argument("--full-length", action="store_true",
                     help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
                          "alias-free length the lag window allows")
     return ap.parse_args()
+
+
+def vad_figures(torch, _native, minutes=90.0, iters=20):
+    """Second kernel of the hot path: frame-energy VAD sweep over one 90-minute 48 kHz s16le file
+    resident in HBM (BASELINE config 5 shape: 259.2 M samples, 518 MB).  Algorithmic bytes =
+    2*n_samples + 4*n_frames."""
+    from oracle import vad_oracle as vo
+
+    frame = 480
+    n_frames = int(minutes * 60 * 100)
+    n = n_frames * frame
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    seg = torch.randint(0, 2, (n_frames // 50 + 1,), generator=g, device="cuda").repeat_interleave(50)[:n_frames].bool()
+    sigma = torch.where(seg, 3000.0, 30.0).repeat_interleave(frame)
+    pcm = (torch.randn(n, generator=g, device="cuda") * sigma).round().clamp(-32768, 32767).to(torch.int16)
+    del sigma
+    labels = _native.vad_energy(pcm, frame, 50.0, 0.0)
+    ok = bool(torch.equal(labels > 0.5, seg))
+    # bit-exact vs the CPU oracle on the first 100 s chunk (the reference's buffer size)
+    head = pcm[: frame * 10000].cpu().numpy()
+    ok_oracle = bool((labels[:10000].cpu().numpy() == vo.detect_fast(head)).all())
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _native.vad_energy(pcm, frame, 50.0, 0.0)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(iters):
+        _native.vad_energy(pcm, frame, 50.0, 0.0)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / iters
+    bytes_ = 2 * n + 4 * n_frames
+    t1 = time.perf_counter()
+    cpu_n = frame * 10000 * 3
+    vo.chunked_detect(pcm[:cpu_n].cpu().numpy())
+    cpu_s = time.perf_counter() - t1
+    lo, hi = _native.speech_bounds(labels)
+    return {
+        "workload": "one %.0f-min 48 kHz s16le file in HBM (%d samples, %d frames)" % (minutes, n, n_frames),
+        "kernel": "k_vad_energy",
+        "ms_per_file": ms,
+        "audio_hours_per_s": minutes / 60.0 / (ms * 1e-3),
+        "achieved_GBps": bytes_ / (ms * 1e-3) / 1e9,
+        "frac_of_8TBps": bytes_ / (ms * 1e-3) / HBM_PEAK,
+        "labels_match_generator": ok,
+        "labels_match_cpu_oracle_first_chunk": ok_oracle,
+        "speech_bounds": [lo, hi],
+        "cpu_oracle_audio_hours_per_s": (cpu_n / 48000.0 / 3600.0) / cpu_s,
+    }
 
 
 def main():
@@ -240,6 +290,9 @@ def main():
             "host_cpus": os.cpu_count(),
         }
         result["offset_match"]["gpu_equals_cpu_oracle_on_sample"] = bool(agree)
+
+    if rank == 0 and world == 1 and not args.no_vad:
+        result["vad"] = vad_figures(torch, _native)
 
     if rank == 0:
         print(json.dumps(result))
