@@ -82,6 +82,36 @@ struct PairResult {
     int32_t flags;
 };
 
+// Overflow pool: every in-window lag within the tie margin of a candidate whose nominee lists
+// overflowed (flat-topped correlation peaks) is appended here and re-evaluated exactly.
+struct PoolHeader {
+    unsigned int count;     // entries appended (may exceed capacity)
+    unsigned int capacity;
+    unsigned int pad0, pad1;
+};
+struct PoolEntry {
+    int32_t ci;
+    int32_t d;
+    float val;
+    int32_t pad;
+    double score;
+};
+constexpr int POOL_D_BIAS = 1 << 30;
+struct PoolBest {  // per candidate
+    unsigned long long key;  // order-preserving image of the best exact score (0 = none)
+    int32_t d;               // largest lag attaining it, stored as d + POOL_D_BIAS (0 = none)
+    float val;
+};
+
+FFS_DEV unsigned long long score_key(double x) {
+    const long long b = __double_as_longlong(x);
+    return b >= 0 ? ((unsigned long long)b | 0x8000000000000000ull) : ~(unsigned long long)b;
+}
+FFS_DEV double key_score(unsigned long long k) {
+    const unsigned long long b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
 FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 == v2 && d1 > d2); }
 
 // Branch-free sample fetch: the load is always issued (index clamped to element 0, so the sixteen
@@ -311,27 +341,81 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
     }
 }
 
+// Exhaustive variant for flagged candidates: append every in-window value within the margin of the
+// candidate's global fp32 maximum to the pool.
+template <int NV, class MOf>
+FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int nN, const int (&ci)[2],
+                               const bool (&want)[2], const float (&thr)[2], PoolHeader* __restrict__ pool,
+                               PoolEntry* __restrict__ entries) {
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int m = m_of(q);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!want[h]) continue;
+            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
+            const float val = h ? v[q].y : v[q].x;
+            if (ok && val >= thr[h]) {
+                const unsigned slot = atomicAdd(&pool->count, 1u);
+                if (slot < pool->capacity) {
+                    PoolEntry e;
+                    e.ci = ci[h];
+                    e.d = d;
+                    e.val = val;
+                    e.pad = 0;
+                    e.score = 0.0;
+                    entries[slot] = e;
+                }
+            }
+        }
+    }
+}
+
+// Which of a transform's two candidates need the exhaustive pass (nominee overflow, flag 2)?
+FFS_DEV bool exhaustive_wanted(const NomList* __restrict__ noms, const CandDesc* __restrict__ cands, int cand0, int kp,
+                               int n_cand, int (&ci)[2], bool (&want)[2], float (&thr)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool present = (2 * kp + h) < n_cand;
+        ci[h] = cand0 + (present ? 2 * kp + h : 0);
+        want[h] = present && (noms[ci[h]].flags & 2) != 0;
+        thr[h] = want[h] ? noms[ci[h]].gmax - cands[ci[h]].margin : INFINITY;
+    }
+    return want[0] || want[1];
+}
+
 // --------------------------------------------------------------------------------------------
 // pass C.  grid = (N2/C, n_candidate_transforms); same thread mapping as pass A.
 // grid.y enumerates the candidate transforms of the pairs in flight: ly = lp*n_packed + k uses work
 // slot lp*n_slots + 1 + k and candidates first_cand + lp*n_cand + {2k, 2k+1}.
-template <int L, int C, bool WRITE>
+// MODE 0: nominees; 1: write the full correlation (diagnostics); 2: exhaustive collect for flagged
+// candidates (blocks of unflagged transforms exit immediately).
+template <int L, int C, int MODE>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ work, int N2, long long N,
                                                          const cf* __restrict__ tw, const CandDesc* __restrict__ cands,
                                                          int first_cand, int n_cand, int n_packed, int n_slots,
                                                          BlockNom* __restrict__ bnom, float* __restrict__ out_a,
-                                                         float* __restrict__ out_b) {
+                                                         float* __restrict__ out_b, const NomList* __restrict__ noms,
+                                                         PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
     constexpr int NW = NT / 64;
+    constexpr bool WRITE = (MODE == 1);
     const int tid = threadIdx.x;
     const int c = tid % C;
     const int u = tid / C;
     const int tile = blockIdx.x;
     const int ly = blockIdx.y;
     const int lp = ly / n_packed, kp = ly % n_packed;
+    int xci[2];
+    bool xwant[2];
+    float xthr[2];
+    if (MODE == 2) {
+        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
+    }
     const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
     TwRegs<L> twr;
     twr.load(tw, u);
@@ -352,6 +436,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
         return;
     }
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    if (MODE == 2) {
+        block_collect_all<16>(
+            v, [&](int q) { return m1 + N2 * (u + LT * q); }, wp, (int)N, xci, xwant, xthr, pool, entries);
+        return;
+    }
     block_nominees<16, NW>(
         v, [&](int q) { return m1 + N2 * (u + LT * q); }, wp, (int)N, smem, tid,
         &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
@@ -370,12 +459,15 @@ struct BinList {
     int b[MAXBINS];  // signed bin offsets (m2 or m2 - N1)
 };
 
-template <int L, int C>
+template <int L, int C, bool EXH>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __restrict__ work, int N2, long long N,
                                                                 const cf* __restrict__ twn1,
                                                                 const CandDesc* __restrict__ cands, int first_cand,
                                                                 int n_cand, int n_packed, int n_slots,
-                                                                BlockNom* __restrict__ bnom, BinList bins) {
+                                                                BlockNom* __restrict__ bnom, BinList bins,
+                                                                const NomList* __restrict__ noms,
+                                                                PoolHeader* __restrict__ pool,
+                                                                PoolEntry* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -390,6 +482,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     const int tile = blockIdx.x;
     const int ly = blockIdx.y;
     const int lp = ly / n_packed, kp = ly % n_packed;
+    int xci[2];
+    bool xwant[2];
+    float xthr[2];
+    if (EXH) {
+        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
+    }
     const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
     cf v[16];
 #pragma unroll
@@ -439,6 +537,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
         }
     }
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    if (EXH) {
+        block_collect_all<NVF>(
+            val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries);
+        return;
+    }
     block_nominees<NVF, NW>(
         val, [&](int j) { return mm[j]; }, wp, (int)N, smem, tid, &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile],
         &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
@@ -614,9 +717,97 @@ FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int d
            (double)n00 * (cd.s0 * cd.r0);
 }
 
+// Pool re-evaluation: one block per entry (grid-stride), the whole overlap in one block.
+template <int DT>
+__global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict__ cands, const PoolHeader* __restrict__ pool,
+                                                      PoolEntry* __restrict__ entries, PoolBest* __restrict__ best) {
+    const unsigned n = pool->count < pool->capacity ? pool->count : pool->capacity;
+    __shared__ unsigned int s_cnt[3][4];
+    __shared__ double s_sum[4];
+    for (unsigned e = blockIdx.x; e < n; e += gridDim.x) {
+        const int ci = entries[e].ci, d = entries[e].d;
+        const CandDesc& cd = cands[ci];
+        const int i0 = d < 0 ? -d : 0;
+        const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+        double score = 0.0;
+        if (DT == 0) {
+            const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
+            const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
+            unsigned int n11 = 0, n1x = 0, nx1 = 0;
+            for (int i = i0 + 16 * (int)threadIdx.x; i < i1; i += 16 * 256) {
+                if (i + 16 <= i1) {
+                    uint4 sv, rv;
+                    __builtin_memcpy(&sv, s + i, 16);
+                    __builtin_memcpy(&rv, r + i, 16);
+                    const unsigned sw[4] = {sv.x, sv.y, sv.z, sv.w}, rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned fs = nz_flags(sw[k]), fr = nz_flags(rw[k]);
+                        n11 += __popc(fs & fr);
+                        n1x += __popc(fs);
+                        nx1 += __popc(fr);
+                    }
+                } else {
+                    for (int k = i; k < i1; ++k) {
+                        const unsigned sb = s[k] != 0, rb = r[k] != 0;
+                        n11 += sb & rb;
+                        n1x += sb;
+                        nx1 += rb;
+                    }
+                }
+            }
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                n11 += __shfl_xor(n11, sft, 64);
+                n1x += __shfl_xor(n1x, sft, 64);
+                nx1 += __shfl_xor(nx1, sft, 64);
+            }
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) {
+                s_cnt[0][threadIdx.x >> 6] = n11;
+                s_cnt[1][threadIdx.x >> 6] = n1x;
+                s_cnt[2][threadIdx.x >> 6] = nx1;
+            }
+            __syncthreads();
+            RescoreAcc a;
+            a.n11 = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+            a.n1x = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+            a.nx1 = s_cnt[2][0] + s_cnt[2][1] + s_cnt[2][2] + s_cnt[2][3];
+            score = exact_score(cd, a, d, 0);
+        } else {
+            const float* s = reinterpret_cast<const float*>(cd.s);
+            const float* r = reinterpret_cast<const float*>(cd.r) + d;
+            double sum = 0.0;
+            for (int i = i0 + (int)threadIdx.x; i < i1; i += 256)
+                sum += (2.0 * (double)s[i] - 1.0) * (2.0 * (double)r[i] - 1.0);
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            score = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+        }
+        if (threadIdx.x == 0) {
+            entries[e].score = score;
+            atomicMax(&best[ci].key, score_key(score));
+        }
+    }
+}
+
+// second phase: among the entries attaining a candidate's best exact score keep the largest lag
+__global__ void k_pool_pick(const PoolHeader* __restrict__ pool, const PoolEntry* __restrict__ entries,
+                            PoolBest* __restrict__ best) {
+    const unsigned n = pool->count < pool->capacity ? pool->count : pool->capacity;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const PoolEntry& en = entries[e];
+        if (score_key(en.score) == best[en.ci].key) atomicMax(&best[en.ci].d, en.d + POOL_D_BIAS);
+    }
+}
+
 // one thread per candidate: best nominee by exact score (ties -> largest d = first k)
 __global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
-                                 const RescoreAcc* __restrict__ acc, CandResult* __restrict__ out, int n, int dt) {
+                                 const RescoreAcc* __restrict__ acc, CandResult* __restrict__ out, int n, int dt,
+                                 const PoolHeader* __restrict__ pool, const PoolBest* __restrict__ pbest) {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= n) return;
     const CandDesc& cd = cands[ci];
@@ -644,6 +835,13 @@ __global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomLi
         r.offset = bd;
         r.score_f32 = bf;
         r.flags = nl.flags & 2;
+        // nominee lists overflowed: the exhaustive pool holds every lag within the margin, unless the
+        // pool itself overflowed (then the best-of-list answer above stands, flagged ambiguous)
+        if ((nl.flags & 2) && pool->count <= pool->capacity && pbest[ci].key != 0) {
+            r.score = key_score(pbest[ci].key);
+            r.offset = pbest[ci].d - POOL_D_BIAS;
+            r.flags = 0;
+        }
     }
     out[ci] = r;
 }

@@ -39,6 +39,7 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
+constexpr unsigned kPoolCapacity = 1u << 20;
 
 int ilog2(int64_t x) {
     int p = 0;
@@ -110,6 +111,7 @@ struct ffs_plan {
     cf* twn1 = nullptr;                       // W_N1^k, k < N1 (pruned pass C)
     cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
     BlockNom* bnom = nullptr;                 // [pairs_in_flight*n_packed*2][tiles]
+    PoolEntry* pool_entries = nullptr;        // [kPoolCapacity] exhaustive fallback for flagged candidates
     // per-call descriptor storage (grown on demand)
     void* dev_desc = nullptr;
     size_t dev_desc_bytes = 0;
@@ -241,27 +243,33 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
     return fail(FFS_E_INVALID, "unsupported row length %d", p->N2);
 }
 
-template <int L, int C, bool WRITE>
+struct PoolArgs {
+    const NomList* noms;
+    PoolHeader* header;
+    PoolEntry* entries;
+};
+
+template <int L, int C, int MODE>
 int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
-                       int n_pairs, float* out_a, float* out_b, hipStream_t st) {
+                       int n_pairs, float* out_a, float* out_b, const PoolArgs& pa, hipStream_t st) {
     static bool attr_done = false;
     const size_t lds = col_lds_bytes(L);
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c<L, C, WRITE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c<L, C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 grid(p->N2 / C, n_pairs * n_packed);
-    hipLaunchKernelGGL((k_pass_c<L, C, WRITE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
-                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b);
+    hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
+                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
-template <bool WRITE>
+template <int MODE>
 int launch_pass_c(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
-                  int n_pairs, float* out_a, float* out_b, hipStream_t st) {
+                  int n_pairs, float* out_a, float* out_b, const PoolArgs& pa, hipStream_t st) {
 #define FFS_PC(L, C) \
-    case L: return launch_pass_c_inst<L, C, WRITE>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, out_a, out_b, st)
+    case L: return launch_pass_c_inst<L, C, MODE>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, out_a, out_b, pa, st)
     switch (p->N1) {
         FFS_PC(16, 256);
         FFS_PC(32, 128);
@@ -283,26 +291,27 @@ size_t pruned_lds_bytes(int L) {
     return 1024 + (size_t)L * sizeof(cf) + (size_t)MAXBINS * (LT / upw) * C * sizeof(cf);
 }
 
-template <int L, int C>
+template <int L, int C, bool EXH>
 int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed,
-                              int n_slots, int n_pairs, const BinList& bins, hipStream_t st) {
+                              int n_slots, int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st) {
     static bool attr_done = false;
     const size_t lds = pruned_lds_bytes(L);
     if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c_pruned<L, C>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c_pruned<L, C, EXH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
     dim3 grid(p->N2 / C, n_pairs * n_packed);
-    hipLaunchKernelGGL((k_pass_c_pruned<L, C>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
-                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins);
+    hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
+                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
+template <bool EXH>
 int launch_pass_c_pruned(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
-                         int n_pairs, const BinList& bins, hipStream_t st) {
+                         int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st) {
 #define FFS_PCP(L, C) \
-    case L: return launch_pass_c_pruned_inst<L, C>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, st)
+    case L: return launch_pass_c_pruned_inst<L, C, EXH>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, pa, st)
     switch (p->N1) {
         FFS_PCP(16, 256);
         FFS_PCP(32, 128);
@@ -522,6 +531,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     const size_t bn_bytes = (size_t)pairs_in_flight * (p->max_slots - 1) * 2 * (N2 / p->C) * sizeof(BlockNom);
     HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
     p->workspace_bytes += (int64_t)bn_bytes;
+    HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
+    p->workspace_bytes += (int64_t)kPoolCapacity * sizeof(PoolEntry);
     *out = p;
     return FFS_OK;
 }
@@ -539,6 +550,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->twn1);
     (void)hipFree(p->work);
     (void)hipFree(p->bnom);
+    (void)hipFree(p->pool_entries);
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -570,16 +582,23 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const size_t n_cands = (size_t)n_pairs * n_cand;
     const size_t n_xf = (size_t)n_pairs * n_slots;
     // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
-    const size_t o_cand = 0;
+    const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
+    const size_t o_cand = 64;
     const size_t o_xf = o_cand + n_cands * sizeof(CandDesc);
     const size_t host_bytes = o_xf + n_xf * sizeof(XformDesc);
     const size_t o_nom = (host_bytes + 255) & ~(size_t)255;
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
-    const size_t total = o_acc + n_cands * KNOM * sizeof(RescoreAcc);
+    const size_t o_pbest = o_acc + n_cands * KNOM * sizeof(RescoreAcc);  // zeroed together with acc
+    const size_t total = o_pbest + n_cands * sizeof(PoolBest);
     int rc;
     if ((rc = ensure_desc(p, total))) return rc;
     HIP_TRY(hipEventSynchronize(p->upload_done));  // previous call's upload has left the pinned buffer
     char* hb = (char*)p->host_desc;
+    {
+        PoolHeader* ph = (PoolHeader*)(hb + o_pool);
+        memset(hb + o_pool, 0, 64);
+        ph->capacity = kPoolCapacity;
+    }
     CandDesc* hc = (CandDesc*)(hb + o_cand);
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     const int stride = 1 + n_cand;
@@ -614,6 +633,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const XformDesc* dx = (const XformDesc*)(db + o_xf);
     NomList* dn = (NomList*)(db + o_nom);
     RescoreAcc* da = (RescoreAcc*)(db + o_acc);
+    PoolBest* dpb = (PoolBest*)(db + o_pbest);
+    const PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries};
     CandResult* cres = (CandResult*)cand_out_dev;
     PairResult* pres = (PairResult*)pair_out_dev;
 
@@ -624,7 +645,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             hipLaunchKernelGGL((k_direct<1>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres);
         HIP_TRY(hipGetLastError());
     } else {
-        HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc), st));
+        HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
         const int tiles = p->N2 / p->C;
         for (int p0 = 0; p0 < n_pairs; p0 += p->pairs_in_flight) {
             const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
@@ -644,8 +665,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_PASS_C);
-                rc = pruned ? launch_pass_c_pruned(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, st)
-                            : launch_pass_c<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, st);
+                rc = pruned ? launch_pass_c_pruned<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, pa, st)
+                            : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, pa, st);
             }
             if (rc) return rc;
             {
@@ -654,6 +675,11 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                                    dn, first_cand);
             }
             HIP_TRY(hipGetLastError());
+            // candidates whose nominee lists overflowed: sweep their transforms again, exhaustively
+            // (blocks of unflagged transforms exit at once)
+            rc = pruned ? launch_pass_c_pruned<true>(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, pa, st)
+                        : launch_pass_c<2>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, pa, st);
+            if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
                 if (dtype == FFS_DTYPE_U8)
@@ -663,8 +689,13 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             }
             HIP_TRY(hipGetLastError());
         }
+        if (dtype == FFS_DTYPE_U8)
+            hipLaunchKernelGGL((k_pool_rescore<0>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb);
+        else
+            hipLaunchKernelGGL((k_pool_rescore<1>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb);
+        hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
         hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
-                           (int)n_cands, dtype);
+                           (int)n_cands, dtype, pa.header, dpb);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
@@ -698,7 +729,8 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
         rc = launch_pass_a<1>(p, dx, 2, st);
     if (rc) return rc;
     if ((rc = launch_mid(p, 1, 2, st))) return rc;
-    return launch_pass_c<true>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, st);
+    const PoolArgs none{nullptr, nullptr, nullptr};
+    return launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st);
 }
 
 int ffs_plan_profile(ffs_plan* p, int enable) {

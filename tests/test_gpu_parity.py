@@ -289,3 +289,31 @@ def test_window_shortened_transform_equals_full_length(torch):
     b = batch.BatchAligner(n_full, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
     assert np.array_equal(a[0]["offset"], b[0]["offset"]) and np.array_equal(a[0]["score"], b[0]["score"])
     assert np.array_equal(a[1], b[1])
+
+
+def test_flat_topped_peak_uses_exhaustive_fallback(torch):
+    """A silent reference makes the correlation exactly flat over thousands of lags: far more exact
+    ties than the per-block / per-candidate nominee lists hold.  The overflow pool must then
+    re-evaluate every tied lag and apply np.argmax's rule (first k = largest offset) -- no
+    FFS_FLAG_AMBIGUOUS left -- on both the full and the pruned last pass, for bytes and floats."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.aligners import _as_array, _Vec, solve_pairs
+
+    rng = np.random.RandomState(5)
+    ref = np.zeros(30000)
+    # every sample < 0.5, so every product with the silent reference is positive: the score grows
+    # with the overlap and is exactly flat where the overlap is complete, d in [0, R-S]
+    sub = 0.4 * (rng.rand(20000) < 0.3)
+    sub_f = rng.choice([0.0, 0.125, 0.25, 0.375], size=20000)  # four levels -> float path
+    for s in (sub, sub_f):
+        for mo in (None, 6000):
+            conv, S = orc.convolve_full(ref, s)
+            m = orc.mask_extreme_offsets(conv, S, mo)
+            top = m.max()
+            k = int(np.argmax(m >= top - 1e-6))  # first index of the (exactly tied) plateau
+            assert (m >= top - 1e-6).sum() > 5000
+            cres, pres = solve_pairs([(_Vec(_as_array(ref)), [_Vec(_as_array(s))])], mo, mo)
+            assert int(cres[0, 0]["offset"]) == len(m) - 1 - k - S
+            assert cres[0, 0]["score"] == pytest.approx(top, rel=1e-9)
+            assert not (int(cres[0, 0]["flags"]) & _native.FLAG_AMBIGUOUS)
+            assert int(pres[0]["best_cand"]) == 0
