@@ -106,10 +106,12 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("FFS_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from ffsubsync_amd import _native, batch, synth
@@ -123,12 +125,13 @@ def main():
     n_dev = n_ref if args.full_length else db.required_fft_length(6000)
     cand_out = torch.empty(P * n_cand * 24, dtype=torch.uint8, device="cuda")
     pair_out = torch.empty(P * 24, dtype=torch.uint8, device="cuda")
-    gathered = torch.empty(world * P * 24, dtype=torch.uint8, device="cuda") if world > 1 else None
+    use_dist = world > 1 or force_dist
+    gathered = torch.empty(world * P * 24, dtype=torch.uint8, device="cuda") if use_dist else None
     profile = not args.no_profile
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +141,7 @@ def main():
 
         def step():
             aligner.solve_async(db, 0, P, cand_out, pair_out)
-            if world > 1:
+            if use_dist:
                 dist.all_gather_into_tensor(gathered, pair_out)
 
         for _ in range(warmup):
@@ -152,7 +155,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ktimes = aligner.plan.profile_read() if profile else {}
         aligner.plan.profile(False)
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -296,7 +299,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
+        if rank == 0:
+            ok = bool(torch.equal(gathered[rank * P * 24:(rank + 1) * P * 24], pair_out))
+            assert ok, "all-gathered records differ from the local ones"
         dist.destroy_process_group()
 
 

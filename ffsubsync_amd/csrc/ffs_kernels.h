@@ -151,21 +151,73 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 #pragma unroll
     for (int q = 1; q < 16; ++q) wq[q] = ts[q * N2 + n2];
     cf v[16];
+    if constexpr (DT == 0 && C == 16) {
+        // Byte inputs, 16-column tiles: the 64 (row, 16-byte) pieces a wave needs per candidate are
+        // fetched by ONE dwordx4 load per lane (lane l: row (l % 4) of this wave, q = l / 4) and
+        // redistributed through LDS, instead of sixteen scalar byte loads per lane.
+        const int lane = threadIdx.x & 63;
+        const int wave = threadIdx.x >> 6;
+        unsigned char* stage = smem + wave * 2048;
+        const int lrow = (wave * 4 + (lane & 3)) + LT * (lane >> 2);
+        const int n0 = lrow * N2 + tile * 16;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int n = (u + LT * q) * N2 + n2;
-        v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
-        v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
+        for (int h = 0; h < 2; ++h) {
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(h ? d.b : d.a);
+            const int len = h ? d.len_b : d.len_a;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (n0 + 16 <= len) {
+                __builtin_memcpy(&w, src + n0, 16);
+            } else if (n0 < len) {  // the one piece that straddles the end of the vector
+                unsigned char tmp[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) tmp[k] = (n0 + k < len) ? src[n0 + k] : (unsigned char)0;
+                __builtin_memcpy(&w, tmp, 16);
+            }
+            *reinterpret_cast<uint4*>(stage + h * 1024 + lane * 16) = w;
+        }
+        __syncthreads();
+        const int uu = (threadIdx.x >> 4) & 3;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = (u + LT * q) * N2 + n2;
+            const unsigned char ba = stage[(q * 4 + uu) * 16 + c];
+            const unsigned char bb = stage[1024 + (q * 4 + uu) * 16 + c];
+            v[q].x = (n < d.len_a) ? (ba ? d.a1 : d.a0) : 0.0f;
+            v[q].y = (n < d.len_b) ? (bb ? d.b1 : d.b0) : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = (u + LT * q) * N2 + n2;
+            v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
+            v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
+        }
     }
     ColAddr<L, C> addr(u, c);
     fft_regs<L>(v, lds, u, addr, twr);
     // v[q] = Y[k1 = u + LT*q][n2]
     cf* out = work + (size_t)blockIdx.y * N;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const cf w = (q == 0) ? wq[0] : cmul(wq[0], wq[q]);
-        const int k1 = u + LT * q;
-        out[((size_t)tile * L + k1) * C + c] = cmul(v[q], w);
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (q == 0) ? wq[0] : cmul(wq[0], wq[q]));
+    if constexpr (C >= 2) {
+        // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
+        // the even-c lane writes rows q = 0,2,.. of columns (c, c+1), the odd-c lane rows q = 1,3,..
+        // (a wave store then covers 8 full 128-byte rows).
+        const bool odd = c & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const cf mine = odd ? v[2 * j + 1] : v[2 * j];   // stays in this lane's store
+            const cf give = odd ? v[2 * j] : v[2 * j + 1];   // goes to the partner lane
+            cf got;
+            got.x = __shfl_xor(give.x, 1, 64);
+            got.y = __shfl_xor(give.y, 1, 64);
+            const int k1 = u + LT * (2 * j + (odd ? 1 : 0));
+            float4 pk = odd ? make_float4(got.x, got.y, mine.x, mine.y) : make_float4(mine.x, mine.y, got.x, got.y);
+            *reinterpret_cast<float4*>(&out[((size_t)tile * L + k1) * C + (c & ~1)]) = pk;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) out[((size_t)tile * L + (u + LT * q)) * C + c] = v[q];
     }
 }
 
