@@ -42,6 +42,9 @@ EXPORTED_SYMBOLS = (
     "ffs_correlate_full",
     "ffs_vad_energy",
     "ffs_speech_bounds",
+    "ffs_raster_length",
+    "ffs_raster_intervals",
+    "ffs_rasterize_subtitles",
     "ffs_plan_profile",
     "ffs_plan_profile_read",
     "ffs_last_error",
@@ -107,6 +110,14 @@ def load():
         lib.ffs_vad_energy.argtypes = [c.c_void_p, c.c_int64, c.c_int, c.c_double, c.c_float, c.c_void_p, c.c_void_p]
         lib.ffs_speech_bounds.restype = c.c_int
         lib.ffs_speech_bounds.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        lib.ffs_raster_length.restype = c.c_int64
+        lib.ffs_raster_length.argtypes = [c.c_void_p, c.c_int64, c.c_double, c.c_double]
+        lib.ffs_raster_intervals.restype = c.c_int64
+        lib.ffs_raster_intervals.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_double,
+                                             c.c_double, c.c_int64, c.c_void_p]
+        lib.ffs_rasterize_subtitles.restype = c.c_int
+        lib.ffs_rasterize_subtitles.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_double,
+                                                c.c_double, c.c_void_p, c.c_int64, c.c_void_p]
         lib.ffs_plan_profile.restype = c.c_int
         lib.ffs_plan_profile.argtypes = [c.c_void_p, c.c_int]
         lib.ffs_plan_profile_read.restype = c.c_int
@@ -267,3 +278,40 @@ def speech_bounds(frames):
                                    current_stream_ptr(torch)))
     lo, hi = (int(v) for v in out.cpu())
     return (None, None) if hi < 0 else (lo, hi)
+
+
+def _us_arrays(start_us, end_us, is_metadata):
+    start_us = np.ascontiguousarray(start_us, dtype=np.int64)
+    end_us = np.ascontiguousarray(end_us, dtype=np.int64)
+    if start_us.shape != end_us.shape:
+        raise ValueError("start_us and end_us must have the same length")
+    meta = None if is_metadata is None else np.ascontiguousarray(is_metadata, dtype=np.uint8)
+    return start_us, end_us, meta
+
+
+def raster_length(end_us, ratio: float, sample_rate: float) -> int:
+    end_us = np.ascontiguousarray(end_us, dtype=np.int64)
+    return int(load().ffs_raster_length(end_us.ctypes.data, end_us.size, float(ratio), float(sample_rate)))
+
+
+def raster_intervals(start_us, end_us, is_metadata, ratio, sample_rate, start_seconds, out_len) -> np.ndarray:
+    """Host-only: [n, 2] int32 array of the clamped [start, end) sample intervals."""
+    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
+    iv = np.zeros((start_us.size + 1, 2), dtype=np.int32)
+    n = load().ffs_raster_intervals(start_us.ctypes.data, end_us.ctypes.data, None if meta is None else meta.ctypes.data,
+                                    start_us.size, float(ratio), float(sample_rate), float(start_seconds), int(out_len),
+                                    iv.ctypes.data)
+    return iv[:n]
+
+
+def rasterize_subtitles(start_us, end_us, is_metadata, ratio, sample_rate=100.0, start_seconds=0.0):
+    """0/1 uint8 CUDA tensor of the subtitle track rescaled by ``ratio`` (see ffs_rasterize_subtitles)."""
+    torch = require_gpu()
+    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
+    n = raster_length(end_us, ratio, sample_rate)
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    check(load().ffs_rasterize_subtitles(start_us.ctypes.data, end_us.ctypes.data,
+                                         None if meta is None else meta.ctypes.data, start_us.size, float(ratio),
+                                         float(sample_rate), float(start_seconds), out.data_ptr(), n,
+                                         current_stream_ptr(torch)))
+    return out

@@ -32,24 +32,39 @@ def _as_array(x: Any) -> np.ndarray:
 
 
 class _Vec:
-    """One activity vector as the native library wants it: two-level bytes + (lo, hi), or floats."""
+    """One activity vector as the native library wants it: two-level bytes + (lo, hi) -- on the host
+    or already in HBM (``DeviceRaster``) -- or arbitrary floats."""
 
-    __slots__ = ("values", "two_level", "lo", "hi", "bits")
+    __slots__ = ("n", "two_level", "lo", "hi", "bits", "_values", "dev")
 
-    def __init__(self, values: np.ndarray) -> None:
-        self.values = values
-        n = values.size
-        if n == 0:
+    def __init__(self, x: Any) -> None:
+        self.dev = None
+        self._values = None
+        if hasattr(x, "bits") and hasattr(x, "lo") and hasattr(x, "hi") and hasattr(x.bits, "data_ptr"):
+            # a DeviceRaster: nothing to convert or upload
+            self.dev, self.n = x.bits, int(x.bits.numel())
+            self.two_level, self.lo, self.hi, self.bits = True, float(x.lo), float(x.hi), None
+            return
+        values = _as_array(x)
+        self._values = values
+        self.n = values.size
+        if self.n == 0:
             self.two_level, self.lo, self.hi, self.bits = True, 0.0, 1.0, np.zeros(0, np.uint8)
             return
         lo, hi = float(values.min()), float(values.max())
         is_hi = values == hi
         self.two_level = bool(np.all(is_hi | (values == lo))) and np.isfinite(lo) and np.isfinite(hi)
         self.lo, self.hi = lo, hi
-        self.bits = is_hi.astype(np.uint8) if (self.two_level and hi != lo) else np.zeros(n, np.uint8)
+        self.bits = is_hi.astype(np.uint8) if (self.two_level and hi != lo) else np.zeros(self.n, np.uint8)
 
     def __len__(self) -> int:
-        return self.values.size
+        return self.n
+
+    def host_values(self) -> np.ndarray:
+        if self._values is None:
+            host = self.dev.cpu().numpy()
+            self._values = np.where(host != 0, self.hi, self.lo).astype(float)
+        return self._values
 
 
 def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Optional[int],
@@ -84,22 +99,26 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
     all_two_level = all(v.two_level for v in vecs)
     if all_two_level:
         dtype, elem = _native.FFS_DTYPE_U8, 1
-        chunks = [v.bits for v in vecs]
+        chunks = [None if v.dev is not None else v.bits for v in vecs]  # device-resident: no upload
     else:
         dtype, elem = _native.FFS_DTYPE_F32, 4
-        chunks = [v.values.astype(np.float32) for v in vecs]
-    # one H2D copy: vectors packed back to back at 64-byte aligned offsets
-    lens = np.array([c.size for c in chunks], dtype=np.int64)
+        chunks = [v.host_values().astype(np.float32) for v in vecs]
+    # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
+    lens = np.array([len(v) for v in vecs], dtype=np.int64)
     offs = np.zeros(len(chunks), dtype=np.int64)
     total = 0
     for i, c in enumerate(chunks):
+        if c is None:
+            continue
         offs[i] = total
         total += (c.size * elem + 63) // 64 * 64
     host = np.zeros(max(total, 64), dtype=np.uint8)
     for c, o in zip(chunks, offs):
-        host[o:o + c.size * elem] = c.view(np.uint8)
+        if c is not None:
+            host[o:o + c.size * elem] = c.view(np.uint8)
     dev = torch.from_numpy(host).cuda()
-    ptrs = (dev.data_ptr() + offs).astype(np.uint64)
+    ptrs = np.array([v.dev.data_ptr() if c is None else dev.data_ptr() + int(o)
+                     for v, c, o in zip(vecs, chunks, offs)], dtype=np.uint64)
     lo = np.array([v.lo for v in vecs], dtype=np.float64)
     hi = np.array([v.hi for v in vecs], dtype=np.float64)
     plan = _native.get_plan(n_fft, pairs_in_flight=1 if n_pairs == 1 else 2, max_cand=max(8, n_cand))
@@ -126,8 +145,8 @@ class FFTAligner(TransformerMixin):
     def _solve_many(self, refstring: Any, substrings: Sequence[Any]) -> List[Tuple[float, int]]:
         """All candidates against one reference in a single device batch; leaves the fitted
         attributes as the reference's sequential loop would (those of the last candidate)."""
-        ref = _Vec(_as_array(refstring))
-        subs = [_Vec(_as_array(s)) for s in substrings]
+        ref = _Vec(refstring)
+        subs = [_Vec(s) for s in substrings]
         cres, _ = solve_pairs([(ref, subs)], self.max_offset_samples)
         out = [(np.float64(r["score"]), int(r["offset"])) for r in cres[0]]
         self.best_score_, self.best_offset_ = out[-1]

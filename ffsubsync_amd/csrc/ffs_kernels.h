@@ -1036,6 +1036,17 @@ __global__ __launch_bounds__(256) void k_vad_energy(const int16_t* __restrict__ 
     }
 }
 
+// subtitle rasteriser: one wave per [start, end) interval, byte stores of 1 (overlaps are unions)
+__global__ __launch_bounds__(256) void k_fill_intervals(const int2* __restrict__ iv, int n, unsigned char* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x / 64) + (threadIdx.x / 64);
+    const int nw = gridDim.x * (blockDim.x / 64);
+    for (int i = wave; i < n; i += nw) {
+        const int2 se = iv[i];
+        for (int k = se.x + lane; k < se.y; k += 64) out[k] = 1;
+    }
+}
+
 __global__ void k_bounds_init(long long* b) {
     b[0] = 0x7fffffffffffffffLL;
     b[1] = -1;

@@ -733,6 +733,83 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     return launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st);
 }
 
+// datetime.timedelta(seconds=x).total_seconds() for a float x >= 0, i.e. x rounded to whole
+// microseconds the way CPython's delta_new/accum does it (integer part exact, fractional part
+// times 1e6 split again, leftover rounded half-to-even on the accumulated parity).
+static int64_t timedelta_us(double x) {
+    double ip;
+    const double fr = modf(x, &ip);
+    int64_t us = (int64_t)ip * 1000000;
+    if (fr != 0.0) {
+        double ip2;
+        const double fr2 = modf(1e6 * fr, &ip2);
+        us += (int64_t)ip2;
+        if (fr2 != 0.0) {
+            double whole = round(fr2);
+            if (fabs(whole - fr2) == 0.5) {
+                const int is_odd = (int)(us & 1);
+                whole = 2.0 * round((fr2 + is_odd) * 0.5) - is_odd;
+            }
+            us += (int64_t)whole;
+        }
+    }
+    return us;
+}
+static double scaled_seconds(int64_t us, double ratio) {
+    const double t = (double)us / 1e6;                  // timedelta.total_seconds()
+    return (double)timedelta_us(t * ratio) / 1e6;       // SubtitleScaler: timedelta(seconds=t*ratio)
+}
+
+int64_t ffs_raster_length(const int64_t* end_us, int64_t n_subs, double ratio, double sample_rate) {
+    double max_time = 0.0;  // speech_transformers.py:958-960
+    for (int64_t i = 0; i < n_subs; ++i) {
+        const double e = scaled_seconds(end_us[i], ratio);
+        if (e > max_time) max_time = e;
+    }
+    return (int64_t)(max_time * sample_rate) + 2;       // :962
+}
+
+int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
+                             double ratio, double sample_rate, double start_seconds, int64_t out_len, int32_t* iv_out) {
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_subs; ++i) {
+        if (is_metadata && is_metadata[i]) continue;    // speech_transformers.py:966-967
+        const double ts = scaled_seconds(start_us[i], ratio), te = scaled_seconds(end_us[i], ratio);
+        const int64_t start = (int64_t)rint((ts - start_seconds) * sample_rate);   // :968-972 (round half even)
+        const int64_t end = start + (int64_t)rint((te - ts) * sample_rate);        // :974-975
+        const int64_t a = py_clamp(start, out_len), b = py_clamp(end, out_len);    // samples[start:end] = ...
+        if (a < b) {
+            iv_out[2 * n] = (int32_t)a;
+            iv_out[2 * n + 1] = (int32_t)b;
+            ++n;
+        }
+    }
+    return n;
+}
+
+int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
+                            double ratio, double sample_rate, double start_seconds, uint8_t* out_dev, int64_t out_len,
+                            void* hip_stream) {
+    if (n_subs < 0 || out_len < 0 || (n_subs > 0 && (!start_us || !end_us))) return fail(FFS_E_INVALID, "bad argument");
+    if (out_len > 0 && !out_dev) return fail(FFS_E_INVALID, "null output");
+    if (out_len >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (out_len > 0) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_len, st));
+    std::vector<int32_t> iv((size_t)(2 * n_subs + 2));
+    const int64_t n_iv = ffs_raster_intervals(start_us, end_us, is_metadata, n_subs, ratio, sample_rate, start_seconds,
+                                              out_len, iv.data());
+    if (n_iv == 0) return FFS_OK;
+    int2* d_iv = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_iv, (size_t)n_iv * sizeof(int2), st));
+    HIP_TRY(hipMemcpyAsync(d_iv, iv.data(), (size_t)n_iv * sizeof(int2), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // iv is a host temporary; the copy must have consumed it
+    const int blocks = (int)((n_iv + 3) / 4);
+    hipLaunchKernelGGL(k_fill_intervals, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, d_iv, (int)n_iv, out_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(d_iv, st));
+    return FFS_OK;
+}
+
 int ffs_plan_profile(ffs_plan* p, int enable) {
     if (!p) return fail(FFS_E_INVALID, "plan is null");
     p->profiling = enable != 0;

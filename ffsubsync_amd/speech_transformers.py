@@ -75,7 +75,9 @@ class ComputeSpeechFrameBoundariesMixin:
 
     def fit_boundaries(self, speech_frames) -> "ComputeSpeechFrameBoundariesMixin":
         torch = _native.require_gpu()
-        if isinstance(speech_frames, np.ndarray) or not hasattr(speech_frames, "is_cuda"):
+        if hasattr(speech_frames, "frames_float"):  # a DeviceRaster
+            frames = speech_frames.frames_float()
+        elif isinstance(speech_frames, np.ndarray) or not hasattr(speech_frames, "is_cuda"):
             frames = torch.from_numpy(np.asarray(speech_frames, dtype=np.float32)).cuda()
         else:
             frames = speech_frames.to(torch.float32)

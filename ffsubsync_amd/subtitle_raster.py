@@ -1,0 +1,109 @@
+"""On-device subtitle rasteriser: the step immediately before the aligner.
+
+Mirrors ``SubtitleScaler`` (ffsubsync/subtitle_transformers.py:29-50) + ``SubtitleSpeechTransformer``
+(ffsubsync/speech_transformers.py:946-984): subtitle intervals are sent to the GPU once (a few KB)
+and rasterised there into the 100 Hz activity vector, for any number of framerate ratios, instead of
+building a 720 KB float array per ratio on the host and copying seven of them over PCIe.  The
+vectors stay in HBM as :class:`DeviceRaster` objects, which ``FFTAligner`` / ``MaxScoreAligner``
+accept directly.
+"""
+from datetime import timedelta
+from typing import Any, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+from .sklearn_shim import TransformerMixin
+from .speech_transformers import ComputeSpeechFrameBoundariesMixin
+
+
+class DeviceRaster:
+    """A two-level activity vector in HBM: byte 0 -> ``lo``, byte != 0 -> ``hi``."""
+
+    def __init__(self, bits, lo: float = 0.0, hi: float = 1.0) -> None:
+        self.bits = bits  # torch.uint8 CUDA tensor
+        self.lo = float(lo)
+        self.hi = float(hi)
+
+    def __len__(self) -> int:
+        return int(self.bits.numel())
+
+    @property
+    def size(self) -> int:
+        return len(self)
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.bits.cpu().numpy()
+        out = np.where(host != 0, self.hi, self.lo).astype(float)
+        return out if dtype is None else out.astype(dtype)
+
+    def frames_float(self):
+        """float32 CUDA tensor of the sample values (for the boundary scan)."""
+        import torch
+
+        return torch.where(self.bits != 0, torch.tensor(self.hi, device=self.bits.device),
+                           torch.tensor(self.lo, device=self.bits.device)).to(torch.float32)
+
+
+def _microseconds(td: timedelta) -> int:
+    return (td.days * 86400 + td.seconds) * 10 ** 6 + td.microseconds
+
+
+def subtitle_records(subs: Iterable[Any], is_metadata=None):
+    """(start_us, end_us, meta) int64/uint8 arrays from objects with ``.start`` / ``.end`` timedeltas.
+    ``is_metadata(content, is_first_or_last)`` is the reference's text heuristic
+    (speech_transformers.py:926-943); it is host-side text logic and is taken from an importable
+    ffsubsync when not supplied (no subtitle is skipped if neither is available)."""
+    subs = list(subs)
+    if is_metadata is None:
+        try:
+            from ffsubsync.speech_transformers import _is_metadata as is_metadata  # type: ignore
+        except Exception:
+            is_metadata = None
+    start_us = np.array([_microseconds(s.start) for s in subs], dtype=np.int64)
+    end_us = np.array([_microseconds(s.end) for s in subs], dtype=np.int64)
+    meta = np.zeros(len(subs), dtype=np.uint8)
+    if is_metadata is not None:
+        for i, s in enumerate(subs):
+            content = getattr(s, "content", None)
+            if content is not None:
+                meta[i] = 1 if is_metadata(content, i == 0 or i + 1 == len(subs)) else 0
+    return start_us, end_us, meta
+
+
+def rasterize_candidates(start_us, end_us, meta, ratios: Sequence[float], sample_rate: int = 100,
+                         start_seconds: float = 0) -> List[DeviceRaster]:
+    """One DeviceRaster per framerate ratio: times scaled by the ratio (SubtitleScaler), amplitude
+    min(1/ratio, 1) (speech_transformers.py:977)."""
+    return [DeviceRaster(_native.rasterize_subtitles(start_us, end_us, meta, r, sample_rate, start_seconds),
+                         0.0, min(1.0 / r, 1.0)) for r in ratios]
+
+
+class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBoundariesMixin):
+    """Drop-in for ``SubtitleSpeechTransformer`` as the ``speech_extract`` step of the subtitle
+    pipeline (it receives the already scaled subtitles from the ``scale`` step): same constructor,
+    same fitted attributes (``subtitle_speech_results_`` is a :class:`DeviceRaster`, ``max_time_``,
+    ``start_frame_`` / ``end_frame_`` / ``num_frames``)."""
+
+    def __init__(self, sample_rate: int, start_seconds: int = 0, framerate_ratio: float = 1.0,
+                 is_metadata=None) -> None:
+        super(DeviceSubtitleSpeechTransformer, self).__init__()
+        self.sample_rate = sample_rate
+        self.start_seconds = start_seconds
+        self.framerate_ratio = framerate_ratio
+        self._is_metadata = is_metadata
+        self.subtitle_speech_results_: Optional[DeviceRaster] = None
+        self.max_time_: Optional[float] = None
+
+    def fit(self, subs, *_) -> "DeviceSubtitleSpeechTransformer":
+        start_us, end_us, meta = subtitle_records(subs, self._is_metadata)
+        max_time = max([0] + [e / 10 ** 6 for e in end_us.tolist()])
+        self.max_time_ = max_time - self.start_seconds
+        bits = _native.rasterize_subtitles(start_us, end_us, meta, 1.0, self.sample_rate, self.start_seconds)
+        self.subtitle_speech_results_ = DeviceRaster(bits, 0.0, min(1.0 / self.framerate_ratio, 1.0))
+        self.fit_boundaries(self.subtitle_speech_results_.frames_float())
+        return self
+
+    def transform(self, *_) -> DeviceRaster:
+        assert self.subtitle_speech_results_ is not None
+        return self.subtitle_speech_results_

@@ -131,6 +131,27 @@ int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len,
 int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev,
                       void* hip_stream);
 
+/* ---- subtitle rasteriser (the step immediately before the aligner) ----------
+ * SubtitleScaler.fit (subtitle_transformers.py:35-47) followed by SubtitleSpeechTransformer.fit
+ * (speech_transformers.py:957-980) for one framerate ratio, from subtitle start/end times given as
+ * integer microseconds (datetime.timedelta's resolution) in HOST arrays:
+ *   scaled = timedelta(seconds = total_seconds * ratio)         (microsecond rounding, half-even)
+ *   start  = int(round((scaled_start - start_seconds) * sample_rate))
+ *   end    = start + int(round((scaled_end - scaled_start) * sample_rate))
+ *   out[start:end] = 1   (Python slice semantics, union over subtitles; metadata lines skipped)
+ * ffs_raster_length = int(max scaled end * sample_rate) + 2 over ALL subtitles (metadata too).
+ * The sample value min(1/ratio, 1) (speech_transformers.py:977) is passed to ffs_align_batch as the
+ * vector's `hi` level; out_dev holds 0/1 bytes. */
+int64_t ffs_raster_length(const int64_t* end_us, int64_t n_subs, double ratio, double sample_rate);
+/* Host-only: the clamped [start, end) sample intervals ffs_rasterize_subtitles fills, written as
+ * pairs into iv_out[2*n_subs]; returns how many intervals were produced. */
+int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
+                             int64_t n_subs, double ratio, double sample_rate, double start_seconds,
+                             int64_t out_len, int32_t* iv_out);
+int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
+                            int64_t n_subs, double ratio, double sample_rate, double start_seconds,
+                            uint8_t* out_dev, int64_t out_len, void* hip_stream);
+
 /* Per-kernel timing with HIP events recorded on the caller's stream around every launch of the
  * hot kernels (used by bench.py for the roofline figures).  Kernel ids: */
 #define FFS_K_PASS_A 0   /* load/map/pad + column FFT + twiddle                    */

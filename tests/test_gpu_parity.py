@@ -271,12 +271,12 @@ def test_window_shortened_transform_equals_full_length(torch):
     """With a lag window the plan may use a transform shorter than the reference's N (no aliasing
     reaches the windowed lags, ffs_plan_length): every result record must equal the full-length one."""
     from ffsubsync_amd import _native, batch, synth
-    from ffsubsync_amd.aligners import _as_array, _Vec, solve_pairs
+    from ffsubsync_amd.aligners import _Vec, solve_pairs
 
     assert _native.plan_length(720000, 750751, 6000) == 1 << 20 and _native.fft_length(720000, 750751) == 1 << 21
     for name in ("config1_6000", "pipeline_10min", "mask100", "mask_negative_index", "sparse2"):
         c = SMALL[name]
-        pair = [(_Vec(_as_array(c["ref"])), [_Vec(_as_array(s)) for s in c["cands"]])]
+        pair = [(_Vec(c["ref"]), [_Vec(s) for s in c["cands"]])]
         short = solve_pairs(pair, c["max_offset"], c["max_offset"])
         full = solve_pairs(pair, c["max_offset"], c["max_offset"], full_length=True)
         assert np.array_equal(short[0]["offset"], full[0]["offset"]) and np.array_equal(short[0]["score"], full[0]["score"])
@@ -297,7 +297,7 @@ def test_flat_topped_peak_uses_exhaustive_fallback(torch):
     re-evaluate every tied lag and apply np.argmax's rule (first k = largest offset) -- no
     FFS_FLAG_AMBIGUOUS left -- on both the full and the pruned last pass, for bytes and floats."""
     from ffsubsync_amd import _native
-    from ffsubsync_amd.aligners import _as_array, _Vec, solve_pairs
+    from ffsubsync_amd.aligners import _Vec, solve_pairs
 
     rng = np.random.RandomState(5)
     ref = np.zeros(30000)
@@ -312,7 +312,7 @@ def test_flat_topped_peak_uses_exhaustive_fallback(torch):
             top = m.max()
             k = int(np.argmax(m >= top - 1e-6))  # first index of the (exactly tied) plateau
             assert (m >= top - 1e-6).sum() > 5000
-            cres, pres = solve_pairs([(_Vec(_as_array(ref)), [_Vec(_as_array(s))])], mo, mo)
+            cres, pres = solve_pairs([(_Vec(ref), [_Vec(s)])], mo, mo)
             assert int(cres[0, 0]["offset"]) == len(m) - 1 - k - S
             assert cres[0, 0]["score"] == pytest.approx(top, rel=1e-9)
             assert not (int(cres[0, 0]["flags"]) & _native.FLAG_AMBIGUOUS)

@@ -1,0 +1,70 @@
+"""On-device subtitle rasteriser against the committed outputs of the unmodified reference classes
+(SubtitleScaler + SubtitleSpeechTransformer), and the HBM-resident pipeline into the aligner."""
+import os
+from datetime import timedelta
+
+import numpy as np
+import pytest
+
+from oracle import aligners_oracle as orc
+from oracle import raster_oracle as ro
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "raster_golden.npz"))
+RATIOS = [float(r) for r in GOLD["ratios"]]
+
+
+@pytest.mark.parametrize("name", ["a", "b", "late_start"])
+def test_device_rasters_match_reference(name):
+    from ffsubsync_amd import _native
+
+    s, e, m = GOLD[name + "_start_us"], GOLD[name + "_end_us"], GOLD[name + "_meta"]
+    ss = int(GOLD[name + "_start_seconds"])
+    for j, r in enumerate(RATIOS):
+        got = _native.rasterize_subtitles(s, e, m, r, 100, ss).cpu().numpy()
+        assert np.array_equal(got, GOLD["%s_r%d" % (name, j)])
+
+
+class _Sub:
+    def __init__(self, s, e, content):
+        self.start, self.end, self.content = timedelta(microseconds=int(s)), timedelta(microseconds=int(e)), content
+
+
+def test_speech_extract_dropin_and_boundaries():
+    from ffsubsync_amd.subtitle_raster import DeviceSubtitleSpeechTransformer
+
+    s, e, m = GOLD["a_start_us"], GOLD["a_end_us"], GOLD["a_meta"]
+    subs = [_Sub(a, b, "[music]" if k else "hello") for a, b, k in zip(s, e, m)]
+    t = DeviceSubtitleSpeechTransformer(100, 0, 1.0417, is_metadata=lambda c, edge: c == "[music]").fit(subs)
+    want = ro.rasterize(s, e, m, 1.0, 100, 0) * min(1 / 1.0417, 1.0)  # times already scaled upstream
+    assert np.array_equal(np.asarray(t.transform()), want)
+    assert (t.start_frame_, t.end_frame_) == orc.speech_boundaries(want)
+    assert t.num_frames == t.end_frame_ - t.start_frame_
+    assert t.max_time_ == max(e) / 1e6
+
+
+def test_hbm_resident_candidates_through_the_aligner():
+    """Intervals -> seven device rasters -> MaxScoreAligner, no host activity vectors: same answer as
+    the reference-shaped host path (oracle on the reference's float arrays)."""
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+    from ffsubsync_amd.constants import candidate_ratios
+    from ffsubsync_amd.subtitle_raster import rasterize_candidates
+
+    s, e, m = ro.synth_subtitles(31, n=170, minutes=10.0)
+    ratios = candidate_ratios()
+    # reference vector: the same track at ratio 25/24, shifted by +412 frames, as a 0/1 host array
+    truth = ro.rasterize(s, e, m, ratios[3], 100, 0)
+    ref = np.concatenate([np.zeros(412), (truth > 0).astype(float), np.zeros(900)])
+    cands = rasterize_candidates(s, e, m, ratios)
+    (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(ref, cands)
+    host = [ro.rasterize(s, e, m, r, 100, 0) for r in ratios]
+    (o_score, o_offset), idx = orc.max_score_align(ref, host, 6000)
+    assert winner is cands[idx] and idx == 3 and offset == o_offset == 412
+    assert score == pytest.approx(o_score, rel=1e-9)
+    # a DeviceRaster reference works too
+    from ffsubsync_amd.subtitle_raster import DeviceRaster
+    import torch
+
+    dref = DeviceRaster(torch.from_numpy((ref > 0).astype(np.uint8)).cuda())
+    assert FFTAligner(6000).fit_transform(dref, cands[3]) == 412
