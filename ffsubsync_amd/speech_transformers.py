@@ -147,3 +147,38 @@ class PCMSpeechTransformer(TransformerMixin):
 
     def transform(self, *_) -> np.ndarray:
         return self.video_speech_results_
+
+
+def serialize_speech(fname: str, speech) -> None:
+    """``--serialize-speech``: np.savez_compressed(<ref>.npz, speech=...) (ffsubsync/ffsubsync.py:639-644)."""
+    np.savez_compressed(fname, speech=np.asarray(speech))
+
+
+class DeserializeSpeechTransformer(TransformerMixin):
+    """speech_transformers.py:987-1009: a ``.npy`` / ``.npz`` (key ``speech``) reference activity
+    vector; every sample below 1.0 becomes ``non_speech_label``.  The bulk on-disk format for batch
+    jobs that feed precomputed reference vectors straight to the device."""
+
+    def __init__(self, non_speech_label: float) -> None:
+        super(DeserializeSpeechTransformer, self).__init__()
+        self._non_speech_label: float = non_speech_label
+        self.deserialized_speech_results_: Optional[np.ndarray] = None
+
+    def fit(self, fname, *_) -> "DeserializeSpeechTransformer":
+        speech = np.load(fname)
+        if hasattr(speech, "files"):
+            if "speech" in speech.files:
+                speech = speech["speech"]
+            else:
+                raise ValueError(
+                    'could not find "speech" array in '
+                    "serialized file; only contains: %s" % speech.files
+                )
+        speech = np.array(speech, dtype=float)
+        speech[speech < 1.0] = self._non_speech_label
+        self.deserialized_speech_results_ = speech
+        return self
+
+    def transform(self, *_) -> np.ndarray:
+        assert self.deserialized_speech_results_ is not None
+        return self.deserialized_speech_results_

@@ -145,3 +145,18 @@ def test_product_path_fails_loudly_without_gpu():
 
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FFTAligner().fit("1001", "1001")
+
+
+def test_npz_speech_round_trip(tmp_path):
+    """--serialize-speech / DeserializeSpeechTransformer (ffsubsync.py:639-644, speech_transformers.py:987-1009)."""
+    from ffsubsync_amd.speech_transformers import DeserializeSpeechTransformer, serialize_speech
+
+    speech = np.array([0.0, 1.0, 0.6, 1.0, 0.0, 0.4])
+    serialize_speech(str(tmp_path / "ref.npz"), speech)
+    got = DeserializeSpeechTransformer(non_speech_label=-0.5).fit(str(tmp_path / "ref.npz")).transform()
+    assert got.tolist() == [-0.5, 1.0, -0.5, 1.0, -0.5, -0.5]
+    np.save(str(tmp_path / "ref.npy"), speech)
+    assert DeserializeSpeechTransformer(0.0).fit(str(tmp_path / "ref.npy")).transform().tolist() == [0, 1, 0, 1, 0, 0]
+    np.savez(str(tmp_path / "bad.npz"), other=speech)
+    with pytest.raises(ValueError, match='could not find "speech" array'):
+        DeserializeSpeechTransformer(0.0).fit(str(tmp_path / "bad.npz"))
