@@ -53,6 +53,58 @@ def _make_energy_detector(sample_rate: int, frame_rate: int, non_speech_label: f
     return _detect
 
 
+def _make_webrtcvad_detector(sample_rate: int, frame_rate: int, non_speech_label: float):
+    """Seam only (speech_transformers.py:155-183): WebRTC's GMM lives in the third-party webrtcvad
+    wheel; when the reference package is importable its factory is used unchanged."""
+    try:
+        from ffsubsync.speech_transformers import _make_webrtcvad_detector as ref_factory  # type: ignore
+    except Exception as e:  # pragma: no cover - depends on the environment
+        raise ImportError("webrtcvad detector needs ffsubsync + webrtcvad installed: %s" % e)
+    return ref_factory(sample_rate, frame_rate, non_speech_label)
+
+
+def _make_silero_detector(sample_rate: int, frame_rate: int, non_speech_label: float):
+    """Seam only (speech_transformers.py:186-236): needs torch.hub + the silero weights (network)."""
+    try:
+        from ffsubsync.speech_transformers import _make_silero_detector as ref_factory  # type: ignore
+    except Exception as e:  # pragma: no cover - depends on the environment
+        raise ImportError("silero detector needs ffsubsync + torch.hub access: %s" % e)
+    return ref_factory(sample_rate, frame_rate, non_speech_label)
+
+
+_FUSION_STRATEGIES = ("weighted", "intersection", "union")  # speech_transformers.py:253
+
+
+def _make_fused_detector(sample_rate: int, frame_rate: int, non_speech_label: float,
+                         fusion_strategy: str = "weighted") -> Callable[[bytes], np.ndarray]:
+    """speech_transformers.py:256-296: combine two detectors frame by frame -- ``intersection``
+    (minimum), ``union`` (maximum) or ``weighted`` (0.6 * silero + 0.4 * webrtc) -- after clipping
+    both label vectors to their common length.  The two factories are looked up as module attributes
+    at call time, the seam the reference's tests/test_vad_fused.py:11-18 patches."""
+    if fusion_strategy not in _FUSION_STRATEGIES:
+        raise ValueError(
+            "unknown fused VAD strategy %r; choose one of %s" % (fusion_strategy, ", ".join(_FUSION_STRATEGIES))
+        )
+    import sys
+
+    mod = sys.modules[__name__]
+    webrtc_detector = mod._make_webrtcvad_detector(sample_rate, frame_rate, non_speech_label)
+    silero_detector = mod._make_silero_detector(sample_rate, frame_rate, non_speech_label)
+
+    def _detect(asegment) -> np.ndarray:
+        webrtc_result = webrtc_detector(asegment)
+        silero_result = silero_detector(asegment)
+        n = min(len(webrtc_result), len(silero_result))
+        webrtc_result, silero_result = webrtc_result[:n], silero_result[:n]
+        if fusion_strategy == "intersection":
+            return np.minimum(webrtc_result, silero_result)
+        if fusion_strategy == "union":
+            return np.maximum(webrtc_result, silero_result)
+        return 0.6 * silero_result + 0.4 * webrtc_result
+
+    return _detect
+
+
 def detect_device(pcm_dev, sample_rate: int, frame_rate: int, non_speech_label: float,
                   energy_threshold_db: float = DEFAULT_ENERGY_THRESHOLD_DB):
     """Same sweep for PCM already resident in HBM (int16 CUDA tensor) -> float32 CUDA labels."""
@@ -105,38 +157,80 @@ class PCMSpeechTransformer(TransformerMixin):
         self.video_speech_results_: Optional[np.ndarray] = None
 
     def _make_detector(self):
+        if "fused" in self.vad:  # e.g. "fused" or "fused:intersection" (speech_transformers.py:655-665)
+            strategy = self.vad.split(":", 1)[1] if ":" in self.vad else "weighted"
+            return _make_fused_detector(self.sample_rate, self.frame_rate, self._non_speech_label, strategy)
+        if "webrtc" in self.vad:
+            return _make_webrtcvad_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
         if "energy" in self.vad or "auditok" in self.vad:
             return _make_energy_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
+        if "silero" in self.vad:
+            return _make_silero_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
         raise ValueError("unknown vad: %s" % self.vad)  # speech_transformers.py:679
 
-    def fit(self, source, *_) -> "PCMSpeechTransformer":
-        detector = self._make_detector()
-        bytes_per_window = BYTES_PER_SAMPLE * self.frame_rate // self.sample_rate  # :683-684
-        chunk_bytes = bytes_per_window * WINDOWS_PER_BUFFER
+    def _chunks(self, source, chunk_bytes):
         if isinstance(source, (bytes, bytearray, memoryview, np.ndarray)):
             raw = _as_int16_bytes(source).view(np.uint8)
-
-            def reader():
-                for o in range(0, raw.size, chunk_bytes):
-                    yield raw[o:o + chunk_bytes]
+            for o in range(0, raw.size, chunk_bytes):
+                yield raw[o:o + chunk_bytes]
         else:
-            def reader():
-                while True:
-                    blob = source.read(chunk_bytes)
-                    if not blob:
-                        return
-                    yield np.frombuffer(blob, np.uint8)
+            while True:
+                blob = source.read(chunk_bytes)
+                if not blob:
+                    return
+                yield np.frombuffer(blob, np.uint8)
 
-        media_bstring: List[np.ndarray] = []
+    def _progress(self, processed):
+        if self.progress_handler is not None:
+            try:
+                self.progress_handler(processed)
+            except Exception:  # a host callback must never break syncing (:731-734)
+                pass
+
+    def _fit_energy_pipelined(self, source, chunk_bytes) -> List[np.ndarray]:
+        """Energy VAD with ingest overlap: chunks go through two pinned staging buffers with
+        asynchronous H2D copies, the sweep of chunk i runs while chunk i+1 is being read from the
+        pipe, and the labels come back in one transfer at the end."""
+        torch = _native.require_gpu()
+        frame_len = frames_per_window(self.sample_rate, self.frame_rate)
+        pinned = [torch.empty(chunk_bytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        device = [torch.empty(chunk_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        copied = [None, None]
+        labels = []
         processed = 0.0
-        for in_bytes in reader():
+        for i, in_bytes in enumerate(self._chunks(source, chunk_bytes)):
+            k = i % 2
+            n = in_bytes.size // BYTES_PER_SAMPLE * BYTES_PER_SAMPLE
             processed += len(in_bytes) / float(BYTES_PER_SAMPLE) / self.frame_rate
-            if self.progress_handler is not None:
-                try:
-                    self.progress_handler(processed)
-                except Exception:  # a host callback must never break syncing (:731-734)
-                    pass
-            media_bstring.append(detector(in_bytes))
+            self._progress(processed)
+            if n == 0:
+                labels.append(torch.empty(0, dtype=torch.float32, device="cuda"))
+                continue
+            if copied[k] is not None:
+                copied[k].synchronize()  # the copy that last used this staging buffer is done
+            pinned[k][:n].numpy()[:] = in_bytes[:n]
+            device[k][:n].copy_(pinned[k][:n], non_blocking=True)
+            copied[k] = torch.cuda.Event()
+            copied[k].record()
+            pcm = device[k][:n].view(torch.int16)
+            labels.append(_native.vad_energy(pcm, frame_len, DEFAULT_ENERGY_THRESHOLD_DB, self._non_speech_label))
+        if not labels:
+            return []
+        return [torch.cat(labels).cpu().numpy().astype(float)]
+
+    def fit(self, source, *_) -> "PCMSpeechTransformer":
+        bytes_per_window = BYTES_PER_SAMPLE * self.frame_rate // self.sample_rate  # :683-684
+        chunk_bytes = bytes_per_window * WINDOWS_PER_BUFFER
+        if ("energy" in self.vad or "auditok" in self.vad) and "fused" not in self.vad:
+            media_bstring = self._fit_energy_pipelined(source, chunk_bytes)
+        else:
+            detector = self._make_detector()
+            media_bstring = []
+            processed = 0.0
+            for in_bytes in self._chunks(source, chunk_bytes):
+                processed += len(in_bytes) / float(BYTES_PER_SAMPLE) / self.frame_rate
+                self._progress(processed)
+                media_bstring.append(detector(in_bytes))
         if len(media_bstring) == 0:
             raise ValueError(
                 "Unable to detect speech. "

@@ -110,3 +110,30 @@ def test_batched_gss_equals_per_file_gss_and_oracle():
     orc.gss_trace(objective, 0.9, 1.1)
     assert repr(rec["v"][0]) == repr(got[0][1]) and rec["v"][2] == got[0][0][1]
     assert rec["v"][1] == pytest.approx(got[0][0][0], rel=1e-9)
+
+
+def test_end_to_end_pcm_to_offset():
+    """BASELINE config 5 at small scale: 48 kHz PCM from a pipe -> chunked on-GPU frame-energy VAD
+    (pinned double-buffered ingest) -> seven HBM-resident subtitle rasters -> MaxScoreAligner."""
+    import io
+
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+    from ffsubsync_amd.constants import candidate_ratios
+    from ffsubsync_amd.speech_transformers import PCMSpeechTransformer
+    from ffsubsync_amd.subtitle_raster import rasterize_candidates
+
+    ratios = candidate_ratios()
+    s, e, m = ro.synth_subtitles(51, n=140, minutes=8.0)
+    true_idx, shift = 5, 733
+    speech = np.concatenate([np.zeros(shift, bool), ro.rasterize(s, e, m, ratios[true_idx], 100, 0) > 0, np.zeros(300, bool)])
+    rng = np.random.RandomState(0)
+    pcm = np.rint(rng.randn(speech.size * 480) * np.repeat(np.where(speech, 3000.0, 30.0), 480))
+    pcm = np.clip(pcm, -32768, 32767).astype("<i2")
+    seen = []
+    t = PCMSpeechTransformer("energy", 100, 48000, 0.0, progress_handler=seen.append).fit(io.BytesIO(pcm.tobytes()))
+    labels = t.transform()
+    assert labels.dtype == np.float64 and np.array_equal(labels > 0.5, speech)
+    assert len(seen) == -(-pcm.size * 2 // (960 * 10000)) and seen == sorted(seen)
+    cands = rasterize_candidates(s, e, m, ratios)
+    (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(labels, cands)
+    assert winner is cands[true_idx] and offset == shift
