@@ -140,7 +140,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     constexpr int LT = L / 16;
     const int c = threadIdx.x % C;
     const int u = threadIdx.x / C;
-    const int tile = blockIdx.x;
+    // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), and the input
+    // bytes of 128/C neighbouring tiles share one 128-byte line, so give every XCD a contiguous run of
+    // tiles instead of every eighth one -- otherwise each input line is fetched by up to 8 L2s.
+    const int nt = gridDim.x;
+    const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int n2 = tile * C + c;
     const XformDesc d = descs[blockIdx.y];
     // every table value this thread needs is requested up front, together with the inputs
