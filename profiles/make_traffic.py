@@ -19,7 +19,14 @@ pmc_dir, n_dev, ppl = sys.argv[1], sys.argv[2], float(sys.argv[3])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
-        if "ffsa::k_" in row["Kernel_Name"] and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+        kn = row["Kernel_Name"]
+        # the exhaustive-collect instantiations (k_pass_c_pruned<.., true>, k_pass_c<.., 2>) exit at once
+        # for unflagged transforms; they are separate launches and must not dilute the pass-C average
+        if "k_pass_c_pruned<" in kn and ", true>" in kn:
+            continue
+        if "k_pass_c<" in kn and ", 2>" in kn:
+            continue
+        if "ffsa::k_" in kn and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = row["Kernel_Name"].split("ffsa::k_")[1].split("<")[0].split("(")[0]
             acc[k.replace("pass_c_pruned", "pass_c")][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
