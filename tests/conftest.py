@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # libffsalign.so is a build product (git-ignored): build it once if this checkout has none yet
+    lib = os.path.join(ROOT, "ffsubsync_amd", "libffsalign.so")
+    if not os.path.exists(lib):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "ffsubsync_amd", "csrc")], check=False)
 
 
 def _have_gpu():
