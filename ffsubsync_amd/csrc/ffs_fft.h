@@ -18,13 +18,45 @@
 
 namespace ffsa {
 
-typedef float2 cf;
+// A complex fp32 value is one 64-bit VGPR pair; arithmetic uses the packed-FP32 VALU ops of gfx950
+// (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32), whose op_sel / neg modifiers express the complex
+// swizzles for free: a complex multiply is 2 instructions, a radix-4 butterfly 8 (16 and 4+.. scalar).
+typedef float cf __attribute__((ext_vector_type(2)));
 #define FFS_DEV __device__ __forceinline__
+#define FFS_HD __host__ __device__ __forceinline__
 
-FFS_DEV cf mk(float x, float y) { return make_float2(x, y); }
-FFS_DEV cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
-FFS_DEV cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
-FFS_DEV cf cmul(cf a, cf b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+FFS_HD cf mk(float x, float y) {
+    cf r = {x, y};
+    return r;
+}
+FFS_DEV cf cadd(cf a, cf b) { return a + b; }
+FFS_DEV cf csub(cf a, cf b) { return a - b; }
+// (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x)
+FFS_DEV cf cmul(cf a, cf b) {
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
+// same with a wave-uniform second factor (compile-time twiddle constants live in an SGPR pair)
+FFS_DEV cf cmul_k(cf a, float kx, float ky) {
+    const cf b = {kx, ky};
+    cf t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+    return r;
+}
+// a + (-i)*t = (a.x + t.y, a.y - t.x)   and   a - (-i)*t = (a.x - t.y, a.y + t.x)
+FFS_DEV cf add_negi(cf a, cf t) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
+FFS_DEV cf sub_negi(cf a, cf t) {
+    cf r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+    return r;
+}
 FFS_DEV cf cmul_negi(cf a) { return mk(a.y, -a.x); }  // a * (-i)
 
 // ---- forward DFT butterflies on registers --------------------------------------------------
@@ -49,12 +81,12 @@ struct Bfly<2> {
 };
 
 FFS_DEV void dft4(cf& x0, cf& x1, cf& x2, cf& x3) {
-    cf a0 = cadd(x0, x2), a1 = csub(x0, x2);
-    cf a2 = cadd(x1, x3), a3 = cmul_negi(csub(x1, x3));
+    const cf a0 = cadd(x0, x2), a1 = csub(x0, x2);
+    const cf a2 = cadd(x1, x3), t = csub(x1, x3);
     x0 = cadd(a0, a2);
     x2 = csub(a0, a2);
-    x1 = cadd(a1, a3);
-    x3 = csub(a1, a3);
+    x1 = add_negi(a1, t);
+    x3 = sub_negi(a1, t);
 }
 
 template <>
@@ -77,9 +109,9 @@ struct Bfly<8> {
             t[n2] = cadd(a, b);
             t[n2 + 4] = csub(a, b);
         }
-        t[5] = cmul(t[5], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));
+        t[5] = cmul_k(t[5], FFS_SQRT_HALF, -FFS_SQRT_HALF);
         t[6] = cmul_negi(t[6]);
-        t[7] = cmul(t[7], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));
+        t[7] = cmul_k(t[7], -FFS_SQRT_HALF, -FFS_SQRT_HALF);
         dft4(t[0], t[1], t[2], t[3]);
         dft4(t[4], t[5], t[6], t[7]);
     }
@@ -94,15 +126,15 @@ struct Bfly<16> {
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) dft4(t[n2], t[n2 + 4], t[n2 + 8], t[n2 + 12]);
         // slot n2 + 4*k1 now holds A[k1][n2]
-        t[5] = cmul(t[5], mk(FFS_COS_PI_8, -FFS_SIN_PI_8));       // W16^1
-        t[6] = cmul(t[6], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));     // W16^2
-        t[7] = cmul(t[7], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));       // W16^3
-        t[9] = cmul(t[9], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));     // W16^2
+        t[5] = cmul_k(t[5], FFS_COS_PI_8, -FFS_SIN_PI_8);       // W16^1
+        t[6] = cmul_k(t[6], FFS_SQRT_HALF, -FFS_SQRT_HALF);     // W16^2
+        t[7] = cmul_k(t[7], FFS_SIN_PI_8, -FFS_COS_PI_8);       // W16^3
+        t[9] = cmul_k(t[9], FFS_SQRT_HALF, -FFS_SQRT_HALF);     // W16^2
         t[10] = cmul_negi(t[10]);                                  // W16^4
-        t[11] = cmul(t[11], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));  // W16^6
-        t[13] = cmul(t[13], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));     // W16^3
-        t[14] = cmul(t[14], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));  // W16^6
-        t[15] = cmul(t[15], mk(-FFS_COS_PI_8, FFS_SIN_PI_8));     // W16^9
+        t[11] = cmul_k(t[11], -FFS_SQRT_HALF, -FFS_SQRT_HALF);  // W16^6
+        t[13] = cmul_k(t[13], FFS_SIN_PI_8, -FFS_COS_PI_8);     // W16^3
+        t[14] = cmul_k(t[14], -FFS_SQRT_HALF, -FFS_SQRT_HALF);  // W16^6
+        t[15] = cmul_k(t[15], -FFS_COS_PI_8, FFS_SIN_PI_8);     // W16^9
 #pragma unroll
         for (int k1 = 0; k1 < 4; ++k1) dft4(t[4 * k1], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3]);
     }
@@ -176,15 +208,15 @@ FFS_DEV void bfly16_twiddled(cf* t, const cf* w /* w1 w2 w3 w4 w8 w12 */) {
         t[4 * k1 + 2] = cmul(t[4 * k1 + 2], w[1]);
         t[4 * k1 + 3] = cmul(t[4 * k1 + 3], w[2]);
     }
-    t[5] = cmul(t[5], mk(FFS_COS_PI_8, -FFS_SIN_PI_8));
-    t[6] = cmul(t[6], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));
-    t[7] = cmul(t[7], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));
-    t[9] = cmul(t[9], mk(FFS_SQRT_HALF, -FFS_SQRT_HALF));
+    t[5] = cmul_k(t[5], FFS_COS_PI_8, -FFS_SIN_PI_8);
+    t[6] = cmul_k(t[6], FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[7] = cmul_k(t[7], FFS_SIN_PI_8, -FFS_COS_PI_8);
+    t[9] = cmul_k(t[9], FFS_SQRT_HALF, -FFS_SQRT_HALF);
     t[10] = cmul_negi(t[10]);
-    t[11] = cmul(t[11], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));
-    t[13] = cmul(t[13], mk(FFS_SIN_PI_8, -FFS_COS_PI_8));
-    t[14] = cmul(t[14], mk(-FFS_SQRT_HALF, -FFS_SQRT_HALF));
-    t[15] = cmul(t[15], mk(-FFS_COS_PI_8, FFS_SIN_PI_8));
+    t[11] = cmul_k(t[11], -FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[13] = cmul_k(t[13], FFS_SIN_PI_8, -FFS_COS_PI_8);
+    t[14] = cmul_k(t[14], -FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[15] = cmul_k(t[15], -FFS_COS_PI_8, FFS_SIN_PI_8);
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) dft4(t[4 * k1], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3]);
 }

@@ -129,12 +129,23 @@ FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
     return in ? val : 0.0f;
 }
 
+// Tile layout of the intermediate arrays: element (x, k1) of a transform (x = n2 or m1, k1 the
+// column-transform index) lives at ((x / CL)*N1 + k1)*CL + x % CL with CL = 2^log2CL >= C columns, so
+// a row k1 is a sequence of CL*8-byte chunks (256 B for CL = 32) and a block's C-column tile is a
+// C*8-byte slice of each chunk.  Returns the offset of (tile*C + c, k1 = 0); rows advance by CL.
+template <int L, int C>
+FFS_DEV size_t tile_base(int tile, int c, int log2CL) {
+    const int x = tile * C + c;
+    return (((size_t)(x >> log2CL) * L) << log2CL) + (size_t)(x & ((1 << log2CL) - 1));
+}
+
 // --------------------------------------------------------------------------------------------
 // pass A.  grid = (N2/C, n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
 template <int L, int C, int DT>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
-                                                         const cf* __restrict__ tb, const cf* __restrict__ ts) {
+                                                         const cf* __restrict__ tb, const cf* __restrict__ ts,
+                                                         int log2CL) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -155,15 +166,18 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 #pragma unroll
     for (int q = 1; q < 16; ++q) wq[q] = ts[q * N2 + n2];
     cf v[16];
-    if constexpr (DT == 0 && C == 16) {
-        // Byte inputs, 16-column tiles: the 64 (row, 16-byte) pieces a wave needs per candidate are
-        // fetched by ONE dwordx4 load per lane (lane l: row (l % 4) of this wave, q = l / 4) and
-        // redistributed through LDS, instead of sixteen scalar byte loads per lane.
+    if constexpr (DT == 0 && (C == 16 || C == 32 || C == 64)) {
+        // Byte inputs: the 64 sixteen-byte pieces a wave needs per candidate (64/C rows x C/16 pieces
+        // for each of the 16 q) are fetched by ONE dwordx4 load per lane and redistributed through
+        // LDS, instead of sixteen scalar byte loads per lane.
+        constexpr int PPR = C / 16;   // pieces per row chunk
+        constexpr int UPW = 64 / C;   // rows (u values) per wave
         const int lane = threadIdx.x & 63;
         const int wave = threadIdx.x >> 6;
         unsigned char* stage = smem + wave * 2048;
-        const int lrow = (wave * 4 + (lane & 3)) + LT * (lane >> 2);
-        const int n0 = lrow * N2 + tile * 16;
+        const int pr = lane & 3;  // piece within this q: row pr / PPR, sixteen-byte part pr % PPR
+        const int lrow = (wave * UPW + pr / PPR) + LT * (lane >> 2);
+        const int n0 = lrow * N2 + tile * C + (pr % PPR) * 16;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(h ? d.b : d.a);
@@ -180,12 +194,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             *reinterpret_cast<uint4*>(stage + h * 1024 + lane * 16) = w;
         }
         __syncthreads();
-        const int uu = (threadIdx.x >> 4) & 3;
+        const int piece = (u % UPW) * PPR + c / 16;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = (u + LT * q) * N2 + n2;
-            const unsigned char ba = stage[(q * 4 + uu) * 16 + c];
-            const unsigned char bb = stage[1024 + (q * 4 + uu) * 16 + c];
+            const unsigned char ba = stage[(q * 4 + piece) * 16 + (c & 15)];
+            const unsigned char bb = stage[1024 + (q * 4 + piece) * 16 + (c & 15)];
             v[q].x = (n < d.len_a) ? (ba ? d.a1 : d.a0) : 0.0f;
             v[q].y = (n < d.len_b) ? (bb ? d.b1 : d.b0) : 0.0f;
         }
@@ -217,11 +231,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             got.y = __shfl_xor(give.y, 1, 64);
             const int k1 = u + LT * (2 * j + (odd ? 1 : 0));
             float4 pk = odd ? make_float4(got.x, got.y, mine.x, mine.y) : make_float4(mine.x, mine.y, got.x, got.y);
-            *reinterpret_cast<float4*>(&out[((size_t)tile * L + k1) * C + (c & ~1)]) = pk;
+            *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, c & ~1, log2CL) + ((size_t)k1 << log2CL)]) = pk;
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[((size_t)tile * L + (u + LT * q)) * C + c] = v[q];
+        for (int q = 0; q < 16; ++q) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)] = v[q];
     }
 }
 
@@ -453,7 +467,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
                                                          int first_cand, int n_cand, int n_packed, int n_slots,
                                                          BlockNom* __restrict__ bnom, float* __restrict__ out_a,
                                                          float* __restrict__ out_b, const NomList* __restrict__ noms,
-                                                         PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries) {
+                                                         PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries,
+                                                         int log2CL) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -477,7 +492,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     twr.load(tw, u);
     cf v[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
+    for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
     ColAddr<L, C> addr(u, c);
     fft_regs<L>(v, lds, u, addr, twr);
     // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LT*q
@@ -523,7 +538,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                                                                 BlockNom* __restrict__ bnom, BinList bins,
                                                                 const NomList* __restrict__ noms,
                                                                 PoolHeader* __restrict__ pool,
-                                                                PoolEntry* __restrict__ entries) {
+                                                                PoolEntry* __restrict__ entries, int log2CL) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -547,7 +562,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
     cf v[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = in[((size_t)tile * L + (u + LT * q)) * C + c];
+    for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
     for (int i = tid; i < L; i += NT) s_tw[i] = twn1[i];
     __syncthreads();
     const int lane = tid % 64;

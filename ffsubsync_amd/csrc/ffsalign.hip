@@ -80,19 +80,19 @@ std::vector<cf> make_stage_tables(int L) {
             for (int jm = 0; jm < Ns; ++jm) {
                 const int e = (R == 16) ? pw16[i] : i;
                 const double a = -2.0 * M_PI * (double)e * (double)jm / ((double)Ns * (double)R);
-                t.push_back(make_float2((float)cos(a), (float)sin(a)));
+                t.push_back(mk((float)cos(a), (float)sin(a)));
             }
     };
     if (R1 > 1) add(R1, 16);
     if (R2 > 1) add(R2, 256);
-    if (t.empty()) t.push_back(make_float2(1.f, 0.f));
+    if (t.empty()) t.push_back(mk(1.f, 0.f));
     return t;
 }
 
 cf wn(int64_t N, int64_t p) {
     p %= N;
     const double a = -2.0 * M_PI * (double)p / (double)N;
-    return make_float2((float)cos(a), (float)sin(a));
+    return mk((float)cos(a), (float)sin(a));
 }
 
 }  // namespace
@@ -101,6 +101,7 @@ struct ffs_plan {
     int device = 0;
     int64_t N = 0;
     int N1 = 0, N2 = 0, C = 0, log2C = 0;
+    int log2CL = 0;  // tile layout T[x/CL][k1][x%CL]: CL = max(C, 64) columns (512-byte row chunks)
     int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
     bool direct_only = false;
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
@@ -191,7 +192,7 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, hipS
     }
     dim3 grid(p->N2 / C, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       p->tw1, p->tbA, p->tsA);
+                       p->tw1, p->tbA, p->tsA, p->log2CL);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -222,14 +223,14 @@ int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st)
     }
     constexpr int ROWS = 256 / (L / 16);
     dim3 grid(p->N1 / ROWS, n_pairs);
-    hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2C, (long long)p->N, n_slots,
+    hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2CL, (long long)p->N, n_slots,
                        (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
-    const bool sep = (p->N2 / 16) >= p->C;
+    const bool sep = (p->N2 / 16) >= (1 << p->log2CL);
 #define FFS_MID(L) \
     case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, st)
     switch (p->N2) {
@@ -260,7 +261,7 @@ int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand,
     }
     dim3 grid(p->N2 / C, n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
-                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries);
+                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -302,7 +303,7 @@ int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int firs
     }
     dim3 grid(p->N2 / C, n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
-                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries);
+                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -497,6 +498,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->N1 = (int)(n_fft >> lg2);
     p->C = tile_cols(p->N1);
     p->log2C = ilog2(p->C);
+    p->log2CL = p->log2C < 6 ? 6 : p->log2C;
+    if ((1 << p->log2CL) > p->N2) p->log2CL = ilog2(p->N2);
     const int64_t N = n_fft;
     const int N1 = p->N1, N2 = p->N2, LT1 = N1 / 16, LT2 = N2 / 16;
     int rc;

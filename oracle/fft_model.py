@@ -76,8 +76,9 @@ def split_n(N):
     return 1 << (p - p2), 1 << p2
 
 
-def tile_offset(x, k1, N1, C=16):
-    """Element offset of (x, k1) in the tiled layout [x/C][k1][x%C] (x = n2 or m1)."""
+def tile_offset(x, k1, N1, C=64):
+    """Element offset of (x, k1) in the tiled layout [x/CL][k1][x%CL] (x = n2 or m1; CL = 64 columns,
+    i.e. 512-byte row chunks, as in the kernels' tile_base)."""
     return ((x // C) * N1 + k1) * C + (x % C)
 
 
