@@ -299,6 +299,13 @@ struct RowAddr {
         s0base = row_base + 17 * u;
     }
     FFS_DEV void refresh() {}
+    FFS_DEV int at(int p) const { return row_base + p + (p >> 4); }
+    // position L-1-(u + LT*Q) = (LT-1-u) + LT*(15-Q): the mirrored element of this thread's slot Q
+    template <int Q>
+    FFS_DEV int gather_mirror() const {
+        const int um = LT - 1 - (16 * u_hi + u_lo);
+        return row_base + um + (um >> 4) + LT * (15 - Q) + (LT / 16) * (15 - Q);
+    }
     template <int Q>
     FFS_DEV int gather() const {
         return gbase + LT * Q + (LT / 16) * Q;

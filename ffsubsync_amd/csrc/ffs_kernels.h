@@ -145,7 +145,7 @@ template <int L, int C, int DT>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
-                                                         int log2CL) {
+                                                         int log2CL, int xf_per_pair, int slots_per_pair) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -214,7 +214,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     ColAddr<L, C> addr(u, c);
     fft_regs<L>(v, lds, u, addr, twr);
     // v[q] = Y[k1 = u + LT*q][n2]
-    cf* out = work + (size_t)blockIdx.y * N;
+    // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
+    // owns slots_per_pair consecutive length-N buffers
+    cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (q == 0) ? wq[0] : cmul(wq[0], wq[q]));
     if constexpr (C >= 2) {
@@ -297,6 +299,118 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
             at(buf, q) = cmul(v[q], w);
         }
     }
+}
+
+template <int L, int... Q>
+FFS_DEV void mirror_store(const cf (&v)[16], cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
+    ((lds[addr.template gather<Q>()] = v[Q]), ...);
+}
+template <int L, int... Q>
+FFS_DEV void mirror_load(cf (&v)[16], const cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
+    ((v[Q] = lds[addr.template gather_mirror<Q>()]), ...);
+}
+
+// --------------------------------------------------------------------------------------------
+// mid pass, packed-reference layout (odd candidate counts, N2 = 4096).  The last candidate transform
+// is z = c_last + i*r, so after the row transform  Z[k] = C[k] + i*R[k]  with C, R Hermitian:
+//     R[k] = (Z[k] - conj(Z[N-k])) / 2i,   C[k] = (Z[k] + conj(Z[N-k])) / 2.
+// In the four-step layout k = k1 + N1*k2 mirrors to row N1-k1 (rows 0 and N1/2 mirror onto
+// themselves), element k2 -> N2-1-k2 (row 0: (N2-k2) mod N2).  One block therefore owns the row pair
+// (b, N1-b): for each of the two rows it transforms both rows of the last slot, mirrors the partner
+// through LDS, forms conj(R)/N (kept in registers, as in k_mid) and the product C*conj(R)/N of the
+// last slot itself, then runs the remaining slots exactly like k_mid.  The last slot's pass-A data is
+// left untouched (its result goes to the spare slot), so the second row can recompute from it.
+// Saves one of five pass-A transforms and one of five row reads per pair; same number of FFTs.
+// ROW0 = true: the block of row 0 (mirror index (N2-k2) mod N2, not separable into base + constant),
+// launched on its own so that its extra address registers do not size the main kernel.
+template <int L, bool ROW0>
+__global__ __launch_bounds__(256, 3) void k_mid_packed(cf* __restrict__ work, int N1, int log2CL, long long N,
+                                                       int n_packed, float inv_n, const cf* __restrict__ tw,
+                                                       const cf* __restrict__ tb, const cf* __restrict__ ts) {
+    static_assert(L == 4096, "one row per 256-thread block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    const int u = threadIdx.x;
+    RowAddr<L> addr(0, u);
+    const int CL = 1 << log2CL;
+    cf* base = work + (size_t)blockIdx.y * (n_packed + 1) * N;
+    const cf* zin = base + (size_t)(n_packed - 1) * N;  // last candidate transform (+ i * reference)
+    cf* zout = base + (size_t)n_packed * N;             // its result
+    const size_t qstride = (size_t)LT * N1;
+    auto off0 = [&](int k1) { return (unsigned)(((u >> log2CL) * N1 + k1) * CL + (u & (CL - 1))); };
+
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    const int ka = ROW0 ? 0 : (int)blockIdx.x + 1, kb = (N1 - ka) % N1;
+    const int halves = (ka == kb) ? 1 : 2;
+    const float h = 0.5f * inv_n;
+    for (int half = 0; half < halves; ++half) {
+        const int k1 = half ? kb : ka, kp = half ? ka : kb;
+        const unsigned o1 = off0(k1), op = off0(kp);
+        cf A[16], B[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) A[q] = (zin + q * qstride)[o1];
+        fft_regs<L>(A, lds, u, addr, twr);
+        if (kp != k1) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) B[q] = (zin + q * qstride)[op];
+            fft_regs<L>(B, lds, u, addr, twr);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) B[q] = A[q];
+        }
+        // mirror the partner row through LDS: B[q] <- Z_partner[mirror of (u + LT*q)]
+        __syncthreads();
+        mirror_store(B, lds, addr, std::make_integer_sequence<int, 16>{});
+        __syncthreads();
+        if constexpr (ROW0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) B[q] = lds[addr.at((L - (u + LT * q)) & (L - 1))];
+        } else {
+            mirror_load(B, lds, addr, std::make_integer_sequence<int, 16>{});
+        }
+        // A = Z, B = Z mirrored.  conj(R)/N = ((A.y + B.y), (A.x - B.x)) / 2N;  C = ((A.x + B.x), (A.y - B.y)) / 2
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf rr = mk((A[q].y + B[q].y) * h, (A[q].x - B[q].x) * h);
+            const cf cc = mk((A[q].x + B[q].x) * 0.5f, (A[q].y - B[q].y) * 0.5f);
+            A[q] = cmul(cc, rr);
+            B[q] = rr;
+        }
+        const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+        fft_regs<L>(A, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
+            (zout + q * qstride)[o1] = cmul(A[q], w);
+        }
+        for (int s = 0; s < n_packed - 1; ++s) {
+            cf* buf = base + (size_t)s * N;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) A[q] = (buf + q * qstride)[o1];
+            fft_regs<L>(A, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) A[q] = cmul(A[q], B[q]);
+            fft_regs<L>(A, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
+                (buf + q * qstride)[o1] = cmul(A[q], w);
+            }
+        }
+    }
+}
+
+// Slot maps.  A pair owns n_packed + 1 consecutive length-N buffers.  The last-pass kernels receive
+// the map as one integer:  n_slots > 0: "separate reference" layout -- slot 0 = reference transform,
+// slot 1+k = candidate transform k (updated in place);  n_slots < 0: "packed reference" layout
+// (-n_slots = n_packed + 1) -- slot k = candidate transform k, except that the last one (which carries
+// the reference in its imaginary half) has its mid-pass result in slot n_packed.
+FFS_DEV int slot_stride(int n_slots) { return n_slots > 0 ? n_slots : -n_slots; }
+FFS_DEV int cand_slot(int n_slots, int kp, int n_packed) {
+    if (n_slots > 0) return 1 + kp;
+    return kp == n_packed - 1 ? n_packed : kp;
 }
 
 // --------------------------------------------------------------------------------------------
@@ -487,7 +601,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     if (MODE == 2) {
         if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
     }
-    const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
+    const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     TwRegs<L> twr;
     twr.load(tw, u);
     cf v[16];
@@ -559,7 +673,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     if (EXH) {
         if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
     }
-    const cf* in = work + (size_t)(lp * n_slots + 1 + kp) * N;
+    const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];

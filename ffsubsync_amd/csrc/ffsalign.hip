@@ -105,6 +105,7 @@ struct ffs_plan {
     int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
     bool direct_only = false;
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
+    bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
@@ -183,7 +184,8 @@ struct ProfSpan {
 
 // ---- kernel dispatch -------------------------------------------------------------------------
 template <int L, int C, int DT>
-int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, hipStream_t st) {
+int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
+                       hipStream_t st) {
     static bool attr_done = false;
     const size_t lds = col_lds_bytes(L);
     if (!attr_done) {
@@ -192,23 +194,23 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, hipS
     }
     dim3 grid(p->N2 / C, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       p->tw1, p->tbA, p->tsA, p->log2CL);
+                       p->tw1, p->tbA, p->tsA, p->log2CL, xf_per_pair, slots_per_pair);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 template <int DT>
-int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, hipStream_t st) {
+int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, hipStream_t st) {
     switch (p->N1) {
-        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, st);
-        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, st);
-        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, st);
-        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, st);
-        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, st);
-        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, st);
-        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, st);
-        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, st);
-        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, st);
+        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
     }
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
@@ -249,6 +251,24 @@ struct PoolArgs {
     PoolHeader* header;
     PoolEntry* entries;
 };
+
+int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t st) {
+    static bool attr_done = false;
+    const size_t lds = row_lds_bytes(4096);
+    if (!attr_done) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mid_packed<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_mid_packed<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const float inv_n = (float)(1.0 / (double)p->N);
+    // row pairs (b, N1-b), b = 1 .. N1/2 (row N1/2 pairs with itself); row 0 (self-paired, different mirror)
+    hipLaunchKernelGGL((k_mid_packed<4096, false>), dim3(p->N1 / 2, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
+                       (long long)p->N, n_packed, inv_n, p->tw2, p->tbM, p->tsM);
+    hipLaunchKernelGGL((k_mid_packed<4096, true>), dim3(1, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
+                       (long long)p->N, n_packed, inv_n, p->tw2, p->tbM, p->tsM);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
 
 template <int L, int C, int MODE>
 int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
@@ -486,6 +506,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     {
         const char* e = getenv("FFS_DISABLE_PRUNED_PASS_C");
         p->allow_pruned = !(e && e[0] == '1');
+        // measured neutral (pass A -2.0 us/pair, mid +2.0 us/pair: the second row of every pair re-reads
+        // and re-transforms the last slot's rows), so the simpler separate-reference layout is the default
+        const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
+        p->allow_packed_ref = (e2 && e2[0] == '1');
     }
     if (n_fft < kMinFftN) {
         p->direct_only = true;
@@ -581,9 +605,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     HIP_TRY(hipSetDevice(p->device));
 
     const int n_packed = (n_cand + 1) / 2;
-    const int n_slots = 1 + n_packed;
+    const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
+    // Odd candidate counts leave the imaginary half of the last packed transform free: put the reference
+    // there (k_mid_packed) instead of spending a fifth transform on it.
+    const bool packed_ref = !p->direct_only && p->allow_packed_ref && (n_cand % 2 == 1) && p->N2 == 4096 &&
+                            (p->N2 / 16) >= (1 << p->log2CL) && p->N1 >= 2;
+    const int xf_per_pair = packed_ref ? n_packed : n_slots;
+    const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
     const size_t n_cands = (size_t)n_pairs * n_cand;
-    const size_t n_xf = (size_t)n_pairs * n_slots;
+    const size_t n_xf = (size_t)n_pairs * xf_per_pair;
     // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
     const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
     const size_t o_cand = 64;
@@ -616,9 +646,14 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             }
             if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
         }
-        fill_xform(&hx[(size_t)pi * n_slots], &ref, nullptr);
-        for (int k = 0; k < n_packed; ++k)
-            fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
+        if (packed_ref) {
+            for (int k = 0; k < n_packed; ++k)
+                fill_xform(&hx[(size_t)pi * xf_per_pair + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : &ref);
+        } else {
+            fill_xform(&hx[(size_t)pi * n_slots], &ref, nullptr);
+            for (int k = 0; k < n_packed; ++k)
+                fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
+        }
     }
     // last-pass bins reachable by any lag window of this call (pruned pass C when there are few)
     std::vector<int> bin_set;
@@ -656,20 +691,20 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
                 if (dtype == FFS_DTYPE_U8)
-                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * n_slots, np * n_slots, st);
+                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, st);
                 else
-                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * n_slots, np * n_slots, st);
+                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, st);
             }
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_MID);
-                rc = launch_mid(p, np, n_slots, st);
+                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, st);
             }
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_PASS_C);
-                rc = pruned ? launch_pass_c_pruned<false>(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, pa, st)
-                            : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, pa, st);
+                rc = pruned ? launch_pass_c_pruned<false>(p, dc, first_cand, n_cand, n_packed, slot_map, np, bins, pa, st)
+                            : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
             }
             if (rc) return rc;
             {
@@ -680,8 +715,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             HIP_TRY(hipGetLastError());
             // candidates whose nominee lists overflowed: sweep their transforms again, exhaustively
             // (blocks of unflagged transforms exit at once)
-            rc = pruned ? launch_pass_c_pruned<true>(p, dc, first_cand, n_cand, n_packed, n_slots, np, bins, pa, st)
-                        : launch_pass_c<2>(p, dc, first_cand, n_cand, n_packed, n_slots, np, nullptr, nullptr, pa, st);
+            rc = pruned ? launch_pass_c_pruned<true>(p, dc, first_cand, n_cand, n_packed, slot_map, np, bins, pa, st)
+                        : launch_pass_c<2>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
@@ -727,9 +762,9 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     HIP_TRY(hipEventRecord(p->upload_done, st));
     const XformDesc* dx = (const XformDesc*)p->dev_desc;
     if (dtype == FFS_DTYPE_U8)
-        rc = launch_pass_a<0>(p, dx, 2, st);
+        rc = launch_pass_a<0>(p, dx, 2, 2, 2, st);
     else
-        rc = launch_pass_a<1>(p, dx, 2, st);
+        rc = launch_pass_a<1>(p, dx, 2, 2, 2, st);
     if (rc) return rc;
     if ((rc = launch_mid(p, 1, 2, st))) return rc;
     const PoolArgs none{nullptr, nullptr, nullptr};

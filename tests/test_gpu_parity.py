@@ -317,3 +317,34 @@ def test_flat_topped_peak_uses_exhaustive_fallback(torch):
             assert cres[0, 0]["score"] == pytest.approx(top, rel=1e-9)
             assert not (int(cres[0, 0]["flags"]) & _native.FLAG_AMBIGUOUS)
             assert int(pres[0]["best_cand"]) == 0
+
+
+def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
+    """Optional layout (FFS_ENABLE_PACKED_REF=1): odd candidate counts put the reference into the
+    imaginary half of the last candidate transform (k_mid_packed, Hermitian split across row pairs);
+    results must match the default separate-reference path on a 7-ratio batch, a 1-candidate problem
+    and a window-less problem."""
+    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd.aligners import _Vec, solve_pairs
+
+    specs = [synth.make_pair_spec(400 + i, duration_s=3000.0) for i in range(3)]
+    db = batch.build_device_batch(specs)
+    n = db.required_fft_length(6000)
+    c = SMALL["config1_none"]
+    one = [(_Vec(c["ref"]), [_Vec(c["cands"][0])])]
+
+    def run():
+        _native._plans.clear()  # the layout switch is read when a plan is created
+        out = (batch.BatchAligner(n, 7, 6000, pairs_in_flight=2).solve(db), solve_pairs(one, None), solve_pairs(one, 6000))
+        _native._plans.clear()
+        return out
+
+    separate = run()
+    monkeypatch.setenv("FFS_ENABLE_PACKED_REF", "1")
+    packed = run()
+    for a, b in zip(packed, separate):
+        assert np.array_equal(a[0]["offset"], b[0]["offset"]) and np.array_equal(a[0]["score"], b[0]["score"])
+        assert np.array_equal(a[1], b[1])
+        assert np.abs(a[0]["score_f32"] - b[0]["score_f32"]).max() < 0.25
+    for p, sp in enumerate(specs):
+        assert packed[0][1][p]["best_cand"] == sp.true_ratio_index
