@@ -121,6 +121,8 @@ struct ffs_plan {
     size_t host_desc_bytes = 0;
     hipEvent_t upload_done = nullptr;
     int64_t workspace_bytes = 0;
+    // kernels whose dynamic-LDS limit has been raised on this plan's device (the attribute is per device)
+    mutable std::vector<const void*> lds_configured;
     // optional per-kernel event timing
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool;            // reusable events
@@ -150,6 +152,15 @@ int ensure_desc(ffs_plan* p, size_t bytes) {
     HIP_TRY(hipMalloc(&p->dev_desc, cap));
     HIP_TRY(hipHostMalloc(&p->host_desc, cap, hipHostMallocDefault));
     p->dev_desc_bytes = p->host_desc_bytes = cap;
+    return FFS_OK;
+}
+
+// Raise a kernel's dynamic-LDS limit once per plan (tiles above 64 KB need it).
+int ensure_lds(const ffs_plan* p, const void* fn, size_t bytes) {
+    for (const void* f : p->lds_configured)
+        if (f == fn) return FFS_OK;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    p->lds_configured.push_back(fn);
     return FFS_OK;
 }
 
@@ -186,12 +197,9 @@ struct ProfSpan {
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
                        hipStream_t st) {
-    static bool attr_done = false;
     const size_t lds = col_lds_bytes(L);
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_a<L, C, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
                        p->tw1, p->tbA, p->tsA, p->log2CL, xf_per_pair, slots_per_pair);
@@ -217,12 +225,9 @@ int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_pe
 
 template <int L, bool SEP>
 int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
-    static bool attr_done = false;
     const size_t lds = row_lds_bytes(L);
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_mid<L, SEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_mid<L, SEP>, lds))) return rc_lds;
     constexpr int ROWS = 256 / (L / 16);
     dim3 grid(p->N1 / ROWS, n_pairs);
     hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2CL, (long long)p->N, n_slots,
@@ -253,13 +258,10 @@ struct PoolArgs {
 };
 
 int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t st) {
-    static bool attr_done = false;
     const size_t lds = row_lds_bytes(4096);
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_mid_packed<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_mid_packed<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_mid_packed<4096, false>, lds))) return rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_mid_packed<4096, true>, lds))) return rc_lds;
     const float inv_n = (float)(1.0 / (double)p->N);
     // row pairs (b, N1-b), b = 1 .. N1/2 (row N1/2 pairs with itself); row 0 (self-paired, different mirror)
     hipLaunchKernelGGL((k_mid_packed<4096, false>), dim3(p->N1 / 2, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
@@ -273,12 +275,9 @@ int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t 
 template <int L, int C, int MODE>
 int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
                        int n_pairs, float* out_a, float* out_b, const PoolArgs& pa, hipStream_t st) {
-    static bool attr_done = false;
     const size_t lds = col_lds_bytes(L);
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c<L, C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c<L, C, MODE>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
                        cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL);
@@ -315,12 +314,9 @@ size_t pruned_lds_bytes(int L) {
 template <int L, int C, bool EXH>
 int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed,
                               int n_slots, int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st) {
-    static bool attr_done = false;
     const size_t lds = pruned_lds_bytes(L);
-    if (!attr_done) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_pass_c_pruned<L, C, EXH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c_pruned<L, C, EXH>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
                        p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL);
@@ -497,6 +493,12 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     if (pairs_in_flight < 1 || max_cand < 1) return fail(FFS_E_INVALID, "pairs_in_flight and max_cand must be >= 1");
     HIP_TRY(hipSetDevice(device));
     ffs_plan* p = new ffs_plan();
+    struct Guard {  // destroy the half-built plan on any early return
+        ffs_plan* p;
+        ~Guard() {
+            if (p) ffs_plan_destroy(p);
+        }
+    } guard{p};
     p->device = device;
     p->N = n_fft;
     p->pairs_in_flight = pairs_in_flight;
@@ -513,6 +515,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     }
     if (n_fft < kMinFftN) {
         p->direct_only = true;
+        guard.p = nullptr;
         *out = p;
         return FFS_OK;
     }
@@ -560,6 +563,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->workspace_bytes += (int64_t)bn_bytes;
     HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
     p->workspace_bytes += (int64_t)kPoolCapacity * sizeof(PoolEntry);
+    guard.p = nullptr;
     *out = p;
     return FFS_OK;
 }

@@ -34,7 +34,7 @@ def _direct_corr(ref_pm, s_pm, N):
     return np.real(np.fft.ifft(np.conj(np.fft.fft(a)) * np.fft.fft(b)))
 
 
-@pytest.mark.parametrize("log2n", [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.parametrize("log2n", [12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24])
 def test_raw_correlation_u8_matches_fp64(torch, log2n):
     """Every (N1, N2) kernel instantiation: full fp32 correlation vs numpy complex128."""
     from ffsubsync_amd import _native
@@ -348,3 +348,19 @@ def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
         assert np.abs(a[0]["score_f32"] - b[0]["score_f32"]).max() < 0.25
     for p, sp in enumerate(specs):
         assert packed[0][1][p]["best_cand"] == sp.true_ratio_index
+
+
+def test_maximum_length_solve(torch):
+    """Largest supported transform (N = 2^24, 46 h of 100 Hz frames): a windowed and a window-less
+    solve through the batch entry point, checked against an exact evaluation of the winning lag."""
+    from ffsubsync_amd import synth
+    from ffsubsync_amd.aligners import FFTAligner
+
+    ref, sub = synth.simple_pair(9_000_000, 7_500_000, -4321, seed=9)
+    for mo in (6000, None):
+        score, offset = FFTAligner(mo).fit_transform(ref, sub, get_score=True)
+        assert offset == -4321
+        i = np.arange(sub.size)
+        ok = (i + offset >= 0) & (i + offset < ref.size)
+        exact = float(np.sum((2.0 * sub[ok] - 1) * (2.0 * ref[i[ok] + offset] - 1)))
+        assert float(score) == exact
