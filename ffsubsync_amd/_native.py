@@ -4,6 +4,7 @@ There is deliberately no fallback: if the HIP library is missing or no MI355X is
 product path raises -- it never degrades to a CPU implementation.
 """
 import ctypes
+import math
 import os
 import threading
 from typing import Dict, Optional, Tuple
@@ -42,6 +43,7 @@ EXPORTED_SYMBOLS = (
     "ffs_correlate_full",
     "ffs_vad_energy",
     "ffs_speech_bounds",
+    "ffs_vad_tokenize",
     "ffs_raster_length",
     "ffs_raster_intervals",
     "ffs_rasterize_subtitles",
@@ -108,6 +110,9 @@ def load():
         ]
         lib.ffs_vad_energy.restype = c.c_int
         lib.ffs_vad_energy.argtypes = [c.c_void_p, c.c_int64, c.c_int, c.c_double, c.c_float, c.c_void_p, c.c_void_p]
+        lib.ffs_vad_tokenize.restype = c.c_int
+        lib.ffs_vad_tokenize.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_int, c.c_int, c.c_int, c.c_float,
+                                         c.c_void_p, c.c_void_p]
         lib.ffs_speech_bounds.restype = c.c_int
         lib.ffs_speech_bounds.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
         lib.ffs_raster_length.restype = c.c_int64
@@ -268,6 +273,18 @@ def vad_energy(pcm, frame_len: int, threshold_db: float, non_speech_label: float
         check(load().ffs_vad_energy(pcm.data_ptr(), n, int(frame_len), float(threshold_db), float(non_speech_label),
                                     labels.data_ptr(), current_stream_ptr(torch)))
     return labels
+
+
+def vad_tokenize(valid, chunk_frames: int, min_length: int, max_length: int, max_continuous_silence: int,
+                 non_speech_label: float):
+    """auditok-style token smoothing of a float32 CUDA validity vector (see ffs_vad_tokenize)."""
+    torch = require_gpu()
+    out = torch.empty_like(valid)
+    if valid.numel():
+        check(load().ffs_vad_tokenize(valid.data_ptr(), valid.numel(), int(chunk_frames), int(math.ceil(min_length)),
+                                      int(max_length), int(math.ceil(max_continuous_silence)), float(non_speech_label), out.data_ptr(),
+                                      current_stream_ptr(torch)))
+    return out
 
 
 def speech_bounds(frames):

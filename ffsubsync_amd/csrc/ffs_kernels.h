@@ -1169,6 +1169,92 @@ __global__ __launch_bounds__(256) void k_vad_energy(const int16_t* __restrict__ 
     }
 }
 
+// auditok-style token smoothing: the tokenizer is a sequential state machine per chunk, so one thread
+// walks each chunk (chunks are independent; a 2 h file has 72 of them -- negligible work).
+__global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_frames, long long chunk, int min_len,
+                               int max_len, int max_sil, float non_speech, float* __restrict__ out) {
+    const long long ci = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long f0 = ci * chunk;
+    if (f0 >= n_frames) return;
+    const long long n = (f0 + chunk) < n_frames ? chunk : (n_frames - f0);
+    const float* v = valid + f0;
+    float* o = out + f0;
+    // markers live in the output buffer itself (slot n, the one past the end, is tracked separately)
+    for (long long i = 0; i < n; ++i) o[i] = 0.0f;
+    enum { SILENCE = 0, POSSIBLE_SILENCE = 1, NOISE = 3 };
+    int state = SILENCE, silence_len = 0;
+    long long start = 0, len = 0;  // current token: frames [start, start + len)
+    bool contiguous = false;
+    auto deliver = [&](bool truncated, long long cur) {
+        // _process_end_of_detection (default mode: trailing silence kept, min length not strict)
+        if (len >= min_len || (len > 0 && contiguous)) {
+            const long long end = start + len - 1;
+            o[start] = 1.0f;
+            if (end + 1 < n) o[end + 1] = non_speech - 1.0f;
+            if (truncated) {
+                start = cur + 1;
+                contiguous = true;
+            } else {
+                contiguous = false;
+            }
+        } else {
+            contiguous = false;
+        }
+        len = 0;
+    };
+    for (long long i = 0; i < n; ++i) {
+        const bool ok = v[i] != 0.0f;
+        if (state == SILENCE) {
+            if (ok) {
+                silence_len = 0;
+                start = i;
+                len = 1;
+                state = NOISE;  // init_min = 0
+                if (len >= max_len) deliver(true, i);
+            }
+        } else if (state == NOISE) {
+            if (ok) {
+                ++len;
+                if (len >= max_len) deliver(true, i);
+            } else if (max_sil <= 0) {
+                deliver(false, i);
+                state = SILENCE;
+            } else {
+                silence_len = 1;
+                ++len;
+                state = POSSIBLE_SILENCE;
+                if (len == max_len) deliver(true, i);
+            }
+        } else {  // POSSIBLE_SILENCE
+            if (ok) {
+                ++len;
+                silence_len = 0;
+                state = NOISE;
+                if (len >= max_len) deliver(true, i);
+            } else if (silence_len >= max_sil) {
+                if (silence_len < len)
+                    deliver(false, i);
+                else
+                    len = 0;
+                state = SILENCE;
+                silence_len = 0;
+            } else {
+                ++len;
+                ++silence_len;
+                if (len >= max_len) deliver(true, i);
+            }
+        }
+    }
+    // _post_process: flush a token still open at the end of the chunk
+    if ((state == NOISE || state == POSSIBLE_SILENCE) && len > 0 && len > silence_len) deliver(false, n - 1);
+    // clip(cumsum(markers)[:-1], 0, 1)
+    float acc = 0.0f;
+    for (long long i = 0; i < n; ++i) {
+        acc += o[i];
+        o[i] = fminf(fmaxf(acc, 0.0f), 1.0f);
+    }
+}
+
 // subtitle rasteriser: one wave per [start, end) interval, byte stores of 1 (overlaps are unions)
 __global__ __launch_bounds__(256) void k_fill_intervals(const int2* __restrict__ iv, int n, unsigned char* __restrict__ out) {
     const int lane = threadIdx.x & 63;

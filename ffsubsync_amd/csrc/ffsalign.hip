@@ -887,6 +887,19 @@ int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len, dou
     return FFS_OK;
 }
 
+int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_frames, int min_length, int max_length,
+                     int max_continuous_silence, float non_speech_label, float* labels_dev, void* hip_stream) {
+    if (n_frames < 0 || chunk_frames < 1 || max_length < 1) return fail(FFS_E_INVALID, "bad argument");
+    if (n_frames == 0) return FFS_OK;
+    if (!valid_dev || !labels_dev || valid_dev == labels_dev) return fail(FFS_E_INVALID, "null or aliased buffers");
+    const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
+    hipLaunchKernelGGL(k_vad_tokenize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, valid_dev,
+                       (long long)n_frames, (long long)chunk_frames, min_length, max_length, max_continuous_silence,
+                       non_speech_label, labels_dev);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
 int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev, void* hip_stream) {
     if (!bounds_dev || (n_frames > 0 && !frames_dev) || n_frames < 0) return fail(FFS_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)hip_stream;

@@ -53,6 +53,30 @@ def _make_energy_detector(sample_rate: int, frame_rate: int, non_speech_label: f
     return _detect
 
 
+def _make_auditok_detector(sample_rate: int, frame_rate: int, non_speech_label: float,
+                           energy_threshold_db: float = DEFAULT_ENERGY_THRESHOLD_DB
+                           ) -> Callable[[Union[bytes, np.ndarray]], np.ndarray]:
+    """GPU counterpart of the reference's auditok detector (speech_transformers.py:101-152): the
+    frame-energy test (threshold 50 dB, :124) followed by the StreamTokenizer smoothing with the
+    reference's parameters (min 0.2 s, max 5 s, 0.25 s of tolerated silence, :125-131) and its marker /
+    cumsum rasterisation (:143-150), one tokenizer pass per call as in the reference.  Restated from
+    auditok 0.1.5's published source -- parity unpinned (see oracle/vad_oracle.py)."""
+    frame_len = frames_per_window(sample_rate, frame_rate)
+
+    def _detect(asegment) -> np.ndarray:
+        torch = _native.require_gpu()
+        pcm = _as_int16_bytes(asegment)
+        if pcm.size == 0:
+            return np.zeros(0, dtype=float)
+        dev = torch.from_numpy(pcm.copy()).cuda()
+        valid = _native.vad_energy(dev, frame_len, energy_threshold_db, 0.0)
+        labels = _native.vad_tokenize(valid, max(int(valid.numel()), 1), 0.2 * sample_rate, int(5 * sample_rate),
+                                      0.25 * sample_rate, non_speech_label)
+        return labels.cpu().numpy().astype(float)
+
+    return _detect
+
+
 def _make_webrtcvad_detector(sample_rate: int, frame_rate: int, non_speech_label: float):
     """Seam only (speech_transformers.py:155-183): WebRTC's GMM lives in the third-party webrtcvad
     wheel; when the reference package is importable its factory is used unchanged."""
@@ -162,7 +186,9 @@ class PCMSpeechTransformer(TransformerMixin):
             return _make_fused_detector(self.sample_rate, self.frame_rate, self._non_speech_label, strategy)
         if "webrtc" in self.vad:
             return _make_webrtcvad_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
-        if "energy" in self.vad or "auditok" in self.vad:
+        if "auditok" in self.vad:
+            return _make_auditok_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
+        if "energy" in self.vad:
             return _make_energy_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
         if "silero" in self.vad:
             return _make_silero_detector(self.sample_rate, self.frame_rate, self._non_speech_label)
@@ -221,7 +247,7 @@ class PCMSpeechTransformer(TransformerMixin):
     def fit(self, source, *_) -> "PCMSpeechTransformer":
         bytes_per_window = BYTES_PER_SAMPLE * self.frame_rate // self.sample_rate  # :683-684
         chunk_bytes = bytes_per_window * WINDOWS_PER_BUFFER
-        if ("energy" in self.vad or "auditok" in self.vad) and "fused" not in self.vad:
+        if "energy" in self.vad and "fused" not in self.vad and "auditok" not in self.vad:
             media_bstring = self._fit_energy_pipelined(source, chunk_bytes)
         else:
             detector = self._make_detector()

@@ -125,6 +125,18 @@ int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len,
                    double energy_threshold_db, float non_speech_label,
                    float* labels_dev, void* hip_stream);
 
+/* Token smoothing of a frame-validity sweep, as the reference's auditok detector applies it
+ * (speech_transformers.py:125-131, 140-150): auditok 0.1.5's StreamTokenizer state machine
+ * (min_length, max_length, max_continuous_silence in frames; default mode) run independently on
+ * every chunk of `chunk_frames` frames (the reference re-opens the tokenizer per 100 s buffer), then
+ * the reference's rasterisation: marker[start] = 1, marker[end+1] = non_speech_label - 1 (assigned in
+ * token order), out = clip(cumsum(marker)[:-1], 0, 1).
+ * valid_dev[f] != 0  <=>  frame f passed the energy test.  PARITY UNPINNED: auditok is not available
+ * to check against; restated from its published source (oracle/vad_oracle.py, tokenize()). */
+int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_frames, int min_length,
+                     int max_length, int max_continuous_silence, float non_speech_label,
+                     float* labels_dev, void* hip_stream);
+
 /* ComputeSpeechFrameBoundariesMixin.fit_boundaries (speech_transformers.py:310-317):
  * bounds_dev[0] = first index with frames[i] > 0.5, bounds_dev[1] = last such index;
  * both -1 when there is none. */

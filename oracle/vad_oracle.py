@@ -81,3 +81,101 @@ def synth_pcm(n_samples, seed=0, frame=480, speech_sigma=3000.0, noise_sigma=30.
     sigma = np.repeat(np.where(state, speech_sigma, noise_sigma), frame)[:n_samples]
     x = rng.randn(n_samples) * sigma
     return np.clip(np.rint(x), -32768, 32767).astype(np.int16), state
+
+
+class _Tokenizer:
+    """auditok 0.1.5 ``StreamTokenizer`` in its default mode (init_min=0, init_max_silence=0, no
+    STRICT_MIN_LENGTH, no DROP_TRAILING_SILENCE), restated from the published source with its own
+    data-list bookkeeping (PARITY UNPINNED: auditok is not installed here).  Frames are booleans."""
+
+    SILENCE, POSSIBLE_SILENCE, POSSIBLE_NOISE, NOISE = 0, 1, 2, 3
+
+    def __init__(self, min_length, max_length, max_continuous_silence):
+        self.min_length, self.max_length, self.max_continuous_silence = min_length, max_length, max_continuous_silence
+
+    def tokenize(self, frames):
+        self.state, self.data, self.tokens = self.SILENCE, [], []
+        self.silence_length, self.start_frame, self.contiguous = 0, 0, False
+        self.current = -1
+        for frame in frames:
+            self.current += 1
+            self._process(bool(frame))
+        # _post_process
+        if self.state in (self.NOISE, self.POSSIBLE_SILENCE):
+            if len(self.data) > 0 and len(self.data) > self.silence_length:
+                self._end_of_detection()
+        return self.tokens
+
+    def _process(self, valid):
+        if self.state == self.SILENCE:
+            if valid:
+                self.silence_length = 0
+                self.start_frame = self.current
+                self.data.append(valid)
+                self.state = self.NOISE  # init_min == 0
+                if len(self.data) >= self.max_length:
+                    self._end_of_detection(True)
+        elif self.state == self.NOISE:
+            if valid:
+                self.data.append(valid)
+                if len(self.data) >= self.max_length:
+                    self._end_of_detection(True)
+            elif self.max_continuous_silence <= 0:
+                self._end_of_detection()
+                self.state = self.SILENCE
+            else:
+                self.silence_length = 1
+                self.data.append(valid)
+                self.state = self.POSSIBLE_SILENCE
+                if len(self.data) == self.max_length:
+                    self._end_of_detection(True)
+        elif self.state == self.POSSIBLE_SILENCE:
+            if valid:
+                self.data.append(valid)
+                self.silence_length = 0
+                self.state = self.NOISE
+                if len(self.data) >= self.max_length:
+                    self._end_of_detection(True)
+            elif self.silence_length >= self.max_continuous_silence:
+                if self.silence_length < len(self.data):
+                    self._end_of_detection()
+                else:
+                    self.data = []
+                self.state = self.SILENCE
+                self.silence_length = 0
+            else:
+                self.data.append(valid)
+                self.silence_length += 1
+                if len(self.data) >= self.max_length:
+                    self._end_of_detection(True)
+
+    def _end_of_detection(self, truncated=False):
+        if len(self.data) >= self.min_length or (len(self.data) > 0 and self.contiguous):
+            self.tokens.append((self.start_frame, self.start_frame + len(self.data) - 1))
+            if truncated:
+                self.start_frame = self.current + 1
+                self.contiguous = True
+            else:
+                self.contiguous = False
+        else:
+            self.contiguous = False
+        self.data = []
+
+
+def tokenize_chunk(valid, non_speech_label=0.0, sample_rate=100):
+    """One detector call of the reference's auditok wiring (speech_transformers.py:125-131, 143-150):
+    tokens -> markers (assigned in order) -> clip(cumsum[:-1], 0, 1)."""
+    tok = _Tokenizer(0.2 * sample_rate, int(5 * sample_rate), 0.25 * sample_rate)
+    media_bstring = np.zeros(len(valid) + 1)
+    for start, end in tok.tokenize(valid):
+        media_bstring[start] = 1.0
+        media_bstring[end + 1] = non_speech_label - 1.0
+    return np.clip(np.cumsum(media_bstring)[:-1], 0.0, 1.0)
+
+
+def tokenize(valid, non_speech_label=0.0, chunk_frames=10000, sample_rate=100):
+    """Chunk loop: the reference builds the tokenizer once but every detector call starts a fresh
+    tokenize() pass over its own 100 s buffer."""
+    valid = np.asarray(valid)
+    return np.concatenate([tokenize_chunk(valid[o:o + chunk_frames], non_speech_label, sample_rate)
+                           for o in range(0, len(valid), chunk_frames)]) if len(valid) else np.zeros(0)

@@ -364,3 +364,30 @@ def test_maximum_length_solve(torch):
         ok = (i + offset >= 0) & (i + offset < ref.size)
         exact = float(np.sum((2.0 * sub[ok] - 1) * (2.0 * ref[i[ok] + offset] - 1)))
         assert float(score) == exact
+
+
+def test_vad_token_smoothing_matches_restatement(torch):
+    """ffs_vad_tokenize (auditok-style smoothing, parity unpinned) against the Python restatement:
+    random validity patterns exercising min/max length, tolerated silence, truncation, several labels,
+    chunk boundaries; then the whole auditok-like detector on PCM."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.speech_transformers import PCMSpeechTransformer, _make_auditok_detector
+
+    rng = np.random.RandomState(3)
+    for trial in range(12):
+        n = int(rng.choice([1, 7, 500, 10000, 23456]))
+        p_on = rng.choice([0.02, 0.2, 0.6, 0.95])
+        runs = rng.geometric(1.0 / rng.choice([3, 15, 80, 700]), size=n // 2 + 4)
+        valid = np.repeat(rng.rand(runs.size) < p_on, runs)[:n]
+        if valid.size < n:
+            valid = np.concatenate([valid, np.zeros(n - valid.size, bool)])
+        for label in (0.0, 0.25, -1.0):
+            for chunk in (10000, 997):
+                got = _native.vad_tokenize(torch.from_numpy(valid.astype(np.float32)).cuda(), chunk, 20.0, 500, 25.0, label)
+                want = vo.tokenize(valid, label, chunk)
+                assert np.array_equal(got.cpu().numpy().astype(float), want), (trial, n, label, chunk)
+    pcm, _ = vo.synth_pcm(480 * 25000 + 77, seed=8)
+    want = np.concatenate([vo.tokenize_chunk(vo.detect_fast(pcm[o:o + 4800000]) > 0.5, 0.0)
+                           for o in range(0, pcm.size, 4800000)])
+    assert np.array_equal(_make_auditok_detector(100, 48000, 0.0)(pcm[:4800000].tobytes()), want[:10000])
+    assert np.array_equal(PCMSpeechTransformer("auditok", 100, 48000, 0.0).fit(pcm).transform(), want)

@@ -28,3 +28,25 @@ def test_chunk_loop_concatenates():
     pcm, _ = vo.synth_pcm(480 * 25000 + 7, seed=2)
     a = vo.chunked_detect(pcm)
     assert a.size == 25001 and np.array_equal(a, vo.detect_fast(pcm))
+
+
+def test_tokenizer_restatement_basics():
+    """Hand-checkable behaviour of the (unpinned) auditok tokenizer restatement."""
+    v = np.zeros(300, bool)
+    v[10:40] = True          # 30 valid frames -> token [10, 39 + 25 trailing tolerated silence]
+    v[100:110] = True        # 10 < min_length 20 -> dropped ... but trailing silence counts: 10 + 25 = 35 >= 20
+    out = vo.tokenize_chunk(v)
+    assert out[:10].sum() == 0 and out[10:65].all() and out[65:100].sum() == 0
+    assert out[100:135].all() and out[135:].sum() == 0
+    # a run longer than max_length is cut into contiguous tokens; the reference's marker assignment then
+    # leaves the cumulative sum at 1 until the chunk ends (only one end marker survives)
+    w = np.zeros(1500, bool)
+    w[50:900] = True
+    out = vo.tokenize_chunk(w)
+    assert out[:50].sum() == 0 and out[50:].all()
+    # non-default label: silence after a token reads as the label, before the first token as 0
+    out = vo.tokenize_chunk(v, non_speech_label=0.25)
+    assert out[5] == 0.0 and out[70] == 0.25 and out[20] == 1.0
+    # chunks are tokenised independently
+    z = np.concatenate([v, v])
+    assert np.array_equal(vo.tokenize(z, chunk_frames=300), np.concatenate([vo.tokenize_chunk(v)] * 2))
