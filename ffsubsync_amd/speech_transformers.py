@@ -12,7 +12,10 @@ What is mirrored from the reference (ffsubsync/speech_transformers.py):
 ffmpeg spawning, ffprobe, progress bars, webrtcvad/silero and the auditok token smoothing stay on
 the host in the reference and are out of scope.
 """
-from typing import Callable, List, Optional, Union
+import os
+import subprocess
+from datetime import timedelta
+from typing import Callable, List, NamedTuple, Optional, Union
 
 import numpy as np
 
@@ -267,6 +270,68 @@ class PCMSpeechTransformer(TransformerMixin):
 
     def transform(self, *_) -> np.ndarray:
         return self.video_speech_results_
+
+
+class ProgressInfo(NamedTuple):
+    """ffsubsync/speech_transformers.py:40-53: what ``progress_handler`` receives per PCM chunk."""
+
+    processed_seconds: float
+    total_seconds: Optional[float]
+
+    @property
+    def fraction(self) -> Optional[float]:
+        if not self.total_seconds:
+            return None
+        return min(1.0, self.processed_seconds / self.total_seconds)
+
+
+class VideoSpeechTransformer(PCMSpeechTransformer):
+    """Same constructor and fitted attribute as the reference's ``VideoSpeechTransformer``
+    (speech_transformers.py:320-351): ``fit(fname)`` decodes the reference's audio with an ffmpeg
+    subprocess to s16le mono PCM on a pipe (:681-682) and runs the chunked VAD loop on the GPU.
+    Only the decode command needed for that is built here; the reference's embedded-subtitle
+    shortcut, ffprobe duration probing, remote-URL temp extraction and GUI/VLC progress plumbing are
+    control plane and stay with the reference (a ``subs_then_*`` vad falls straight through to audio)."""
+
+    def __init__(self, vad: str, sample_rate: int, frame_rate: int, non_speech_label: float,
+                 start_seconds: int = 0, ffmpeg_path: Optional[str] = None, ref_stream: Optional[str] = None,
+                 vlc_mode: bool = False, gui_mode: bool = False, max_duration_seconds: Optional[float] = None,
+                 extract_audio_first: bool = False, progress_handler=None) -> None:
+        super(VideoSpeechTransformer, self).__init__(vad, sample_rate, frame_rate, non_speech_label, None)
+        self.start_seconds = start_seconds
+        self.ffmpeg_path = ffmpeg_path
+        self.ref_stream = ref_stream
+        self.vlc_mode = vlc_mode
+        self.gui_mode = gui_mode
+        self.max_duration_seconds = max_duration_seconds
+        self.extract_audio_first = extract_audio_first
+        self._video_progress_handler = progress_handler
+
+    def _decode_command(self, fname: str) -> List[str]:
+        exe = "ffmpeg" if self.ffmpeg_path is None else os.path.join(self.ffmpeg_path, "ffmpeg")
+        cmd = [exe]
+        if self.start_seconds > 0:
+            cmd += ["-ss", str(timedelta(seconds=self.start_seconds))]
+        if self.max_duration_seconds is not None:
+            cmd += ["-t", str(timedelta(seconds=self.max_duration_seconds))]
+        cmd += ["-loglevel", "fatal", "-nostdin", "-i", fname]
+        if self.ref_stream is not None and self.ref_stream.startswith("0:a:"):
+            cmd += ["-map", self.ref_stream]
+        cmd += ["-f", "s16le", "-ac", "1", "-acodec", "pcm_s16le", "-af", "aresample=async=1",
+                "-ar", str(self.frame_rate), "-"]
+        return cmd
+
+    def fit(self, fname: str, *_) -> "VideoSpeechTransformer":
+        total = self.max_duration_seconds
+        if self._video_progress_handler is not None:
+            handler = self._video_progress_handler
+            self.progress_handler = lambda processed: handler(ProgressInfo(processed, total))
+        process = subprocess.Popen(self._decode_command(fname), stdin=subprocess.DEVNULL, stdout=subprocess.PIPE)
+        try:
+            super(VideoSpeechTransformer, self).fit(process.stdout)
+        finally:
+            process.wait()
+        return self
 
 
 def serialize_speech(fname: str, speech) -> None:

@@ -8,6 +8,7 @@ import pytest
 
 from oracle import aligners_oracle as orc
 from oracle import raster_oracle as ro
+from oracle import vad_oracle as vo
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -137,3 +138,46 @@ def test_end_to_end_pcm_to_offset():
     cands = rasterize_candidates(s, e, m, ratios)
     (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(labels, cands)
     assert winner is cands[true_idx] and offset == shift
+
+
+def test_video_speech_transformer_over_a_fake_ffmpeg_pipe(monkeypatch):
+    """The reference's own technique (tests/test_progress.py:47-80): Popen is replaced by a process
+    whose stdout yields PCM; the drop-in VideoSpeechTransformer must read it in 100 s buffers, fire the
+    progress callback monotonically and produce the oracle's labels."""
+    import ffsubsync_amd.speech_transformers as st
+
+    pcm, _ = vo.synth_pcm(480 * 23000 + 11, seed=12)
+    raw = pcm.tobytes()
+
+    class FakeStdout:
+        def __init__(self):
+            self.pos = 0
+
+        def read(self, n):
+            blob = raw[self.pos:self.pos + n]
+            self.pos += len(blob)
+            return blob
+
+    class FakeProcess:
+        def __init__(self, cmd, **kw):
+            FakeProcess.cmd = cmd
+            self.stdout = FakeStdout()
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(st.subprocess, "Popen", FakeProcess)
+    seen = []
+    t = st.VideoSpeechTransformer("subs_then_auditok", 100, 48000, 0.0, start_seconds=3, ref_stream="0:a:1",
+                                  max_duration_seconds=600.0, progress_handler=seen.append)
+    assert t.fit("movie.mkv") is t
+    cmd = FakeProcess.cmd
+    assert cmd[0] == "ffmpeg" and cmd[cmd.index("-ss") + 1] == "0:00:03" and cmd[cmd.index("-map") + 1] == "0:a:1"
+    assert cmd[cmd.index("-i") + 1] == "movie.mkv" and cmd[-1] == "-" and cmd[cmd.index("-ar") + 1] == "48000"
+    want = np.concatenate([vo.tokenize_chunk(vo.detect_fast(pcm[o:o + 4800000]) > 0.5, 0.0)
+                           for o in range(0, pcm.size, 4800000)])
+    assert np.array_equal(t.transform(), want) and t.video_speech_results_.dtype == np.float64
+    secs = [p.processed_seconds for p in seen]
+    assert len(secs) == 3 and secs == sorted(secs) and seen[-1].total_seconds == 600.0 and 0 < seen[0].fraction <= 1
+    with pytest.raises(ValueError, match="unknown vad"):
+        st.VideoSpeechTransformer("nonsense", 100, 48000, 0.0).fit("x.mkv")
