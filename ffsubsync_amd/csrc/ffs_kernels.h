@@ -161,10 +161,15 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // every table value this thread needs is requested up front, together with the inputs
     TwRegs<L> twr;
     twr.load(tw, u);
-    cf wq[16];  // W_N^(n2*k1), k1 = u + LT*q:  tb[u][n2] * ts[q][n2]
+    // W_N^(n2*k1), k1 = u + LT*q:  tb[u][n2] * g^q with g = W_N^(n2*LT).  Only g, g^2, g^4, g^8 are
+    // fetched (ts rows 1, 2, 4, 8); the other powers are built with at most three multiplications
+    // each, which trades eleven table loads per thread for eleven packed complex multiplies.
+    cf wq[16];
     wq[0] = tb[u * N2 + n2];
-#pragma unroll
-    for (int q = 1; q < 16; ++q) wq[q] = ts[q * N2 + n2];
+    wq[1] = ts[1 * N2 + n2];
+    wq[2] = ts[2 * N2 + n2];
+    wq[4] = ts[4 * N2 + n2];
+    wq[8] = ts[8 * N2 + n2];
     cf v[16];
     if constexpr (DT == 0 && (C == 16 || C == 32 || C == 64)) {
         // Byte inputs: the 64 sixteen-byte pieces a wave needs per candidate (64/C rows x C/16 pieces
@@ -217,6 +222,17 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+    wq[3] = cmul(wq[1], wq[2]);
+    wq[5] = cmul(wq[4], wq[1]);
+    wq[6] = cmul(wq[4], wq[2]);
+    wq[7] = cmul(wq[4], wq[3]);
+    wq[9] = cmul(wq[8], wq[1]);
+    wq[10] = cmul(wq[8], wq[2]);
+    wq[11] = cmul(wq[8], wq[3]);
+    wq[12] = cmul(wq[8], wq[4]);
+    wq[13] = cmul(wq[8], wq[5]);
+    wq[14] = cmul(wq[8], wq[6]);
+    wq[15] = cmul(wq[8], wq[7]);
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (q == 0) ? wq[0] : cmul(wq[0], wq[q]));
     if constexpr (C >= 2) {
