@@ -246,15 +246,17 @@ class Plan:
         return out_a, out_b
 
 
-_plans: Dict[Tuple[int, int, int, int], Plan] = {}
+_plans: Dict[Tuple[int, int, int, int, int], Plan] = {}
 _plans_lock = threading.Lock()
 
 
 def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Optional[int] = None) -> Plan:
-    """Process-wide plan cache keyed by (device, n_fft, pairs_in_flight, max_cand)."""
+    """Plan cache keyed by (thread, device, n_fft, pairs_in_flight, max_cand).  A plan owns one
+    workspace and may be driven by one host thread at a time, so every Python thread gets its own
+    (the reference runs detectors/aligners from a small thread pool, speech_transformers.py:872-873)."""
     torch = require_gpu()
     dev = torch.cuda.current_device() if device is None else int(device)
-    key = (dev, int(n_fft), int(pairs_in_flight), int(max_cand))
+    key = (threading.get_ident(), dev, int(n_fft), int(pairs_in_flight), int(max_cand))
     with _plans_lock:
         plan = _plans.get(key)
         if plan is None:

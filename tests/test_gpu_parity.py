@@ -391,3 +391,27 @@ def test_vad_token_smoothing_matches_restatement(torch):
                            for o in range(0, pcm.size, 4800000)])
     assert np.array_equal(_make_auditok_detector(100, 48000, 0.0)(pcm[:4800000].tobytes()), want[:10000])
     assert np.array_equal(PCMSpeechTransformer("auditok", 100, 48000, 0.0).fit(pcm).transform(), want)
+
+
+def test_aligner_is_usable_from_a_thread_pool(torch):
+    """The reference drives its transformers from a 4-thread pool (speech_transformers.py:872-873);
+    every thread gets its own plan, so concurrent solves must not disturb each other."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ffsubsync_amd import synth
+    from ffsubsync_amd.aligners import FFTAligner
+
+    jobs = []
+    for i in range(8):
+        off = 100 * i - 350
+        ref, sub = synth.simple_pair(40000, 36000, off, seed=30 + i)
+        jobs.append((ref, sub, off))
+
+    def solve(job):
+        ref, sub, off = job
+        out = [FFTAligner(6000).fit_transform(ref, sub) for _ in range(5)]
+        return out, off
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for out, off in ex.map(solve, jobs):
+            assert out == [off] * 5
