@@ -1300,9 +1300,22 @@ __global__ __launch_bounds__(256) void k_speech_bounds(const float* __restrict__
         lo = lo < ol ? lo : ol;
         hi = hi > oh ? hi : oh;
     }
-    if ((threadIdx.x & 63) == 0 && hi >= 0) {
-        atomicMin(reinterpret_cast<long long*>(&b[0]), lo);
-        atomicMax(reinterpret_cast<long long*>(&b[1]), hi);
+    // one pair of atomics per block (every wave hitting the same two words serialises)
+    __shared__ long long s_lo[4], s_hi[4];
+    if ((threadIdx.x & 63) == 0) {
+        s_lo[threadIdx.x >> 6] = lo;
+        s_hi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            lo = lo < s_lo[w] ? lo : s_lo[w];
+            hi = hi > s_hi[w] ? hi : s_hi[w];
+        }
+        if (hi >= 0) {
+            atomicMin(reinterpret_cast<long long*>(&b[0]), lo);
+            atomicMax(reinterpret_cast<long long*>(&b[1]), hi);
+        }
     }
 }
 __global__ void k_bounds_fix(long long* b) {

@@ -906,7 +906,7 @@ int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(1), 0, st, (long long*)bounds_dev);
     if (n_frames > 0) {
         long long blocks = (n_frames + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > 512) blocks = 512;
         hipLaunchKernelGGL(k_speech_bounds, dim3((unsigned)blocks), dim3(256), 0, st, frames_dev, (long long)n_frames,
                            (long long*)bounds_dev);
     }
