@@ -26,7 +26,9 @@ def radices(L):
 
 
 def stage_twiddles(L):
-    """Per-stage DIT twiddle tables, layout [r][j % Ns] (fp64 -> complex64)."""
+    """Per-stage DIT twiddle tables, layout [r][j % Ns] (fp64 -> complex64).  (The kernels store only
+    w^{1,2,3,4,8,12} for a radix-16 stage and form w^r = w^(4a) * w^b inside the butterfly; the model
+    keeps the full table, which is the same mathematics.)"""
     tabs = []
     Ns = 1
     for R in radices(L):
