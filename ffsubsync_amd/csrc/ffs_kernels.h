@@ -112,6 +112,14 @@ FFS_DEV double key_score(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 
+// Tie margin actually applied around a maximum vmax: the candidate's data-independent margin, or
+// 24 ulp of the maximum itself if that is larger.  The fp32 pipeline's error grows with the DC
+// content of the signals (measured up to ~6.4 eps * |c| at activity densities of 2 % / 98 %, where
+// |c| reaches 7e5), so a margin proportional to sqrt(S*R) alone would be too tight there.
+FFS_DEV float eff_margin(float cand_margin, float vmax) {
+    return fmaxf(cand_margin, 24.0f * 5.9604645e-08f * fabsf(vmax));
+}
+
 FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 == v2 && d1 > d2); }
 
 // Branch-free sample fetch: the load is always issued (index clamped to element 0, so the sixteen
@@ -513,7 +521,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const float thr = s_bmax[h] - wp.marg[h];
+        const float thr = s_bmax[h] - eff_margin(wp.marg[h], s_bmax[h]);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int m = m_of(q);
@@ -580,7 +588,7 @@ FFS_DEV bool exhaustive_wanted(const NomList* __restrict__ noms, const CandDesc*
         const bool present = (2 * kp + h) < n_cand;
         ci[h] = cand0 + (present ? 2 * kp + h : 0);
         want[h] = present && (noms[ci[h]].flags & 2) != 0;
-        thr[h] = want[h] ? noms[ci[h]].gmax - cands[ci[h]].margin : INFINITY;
+        thr[h] = want[h] ? noms[ci[h]].gmax - eff_margin(cands[ci[h]].margin, noms[ci[h]].gmax) : INFINITY;
     }
     return want[0] || want[1];
 }
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bn
         s_flags = 0;
     }
     __syncthreads();
-    const float thr = g - cd.margin;
+    const float thr = g - eff_margin(cd.margin, g);
     for (int t = lane; t < tiles; t += 64) {
         const BlockNom& b = rows[t];
         if (b.bmax >= thr) {

@@ -435,8 +435,10 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
     cd->r1 = mapped(ref.hi);
     const double as = fmax(fabs(cd->s0), fabs(cd->s1)), ar = fmax(fabs(cd->r0), fabs(cd->r1));
     const double lg = (double)ilog2(p->N > 2 ? p->N : 2);
-    // measured max fp32 error is ~0.02 of eps*log2(N)*sqrt(S*R)*|s||r| (N = 2^12..2^22); nominate within 0.5x
-    cd->margin = (float)(0.5 * 5.9604645e-08 * lg * sqrt((double)S * (double)R) * as * ar);
+    // measured max fp32 error of the pipeline: ~0.02 (activity density 0.5) to ~0.2 (density 0.2) of
+    // eps*log2(N)*sqrt(S*R)*|s||r| for N = 2^12..2^24; lags within 1.0x of it are nominated, and the
+    // kernels widen this to 24 ulp of the maximum for DC-heavy signals (eff_margin)
+    cd->margin = (float)(1.0 * 5.9604645e-08 * lg * sqrt((double)S * (double)R) * as * ar);
     return FFS_OK;
 }
 

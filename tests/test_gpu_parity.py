@@ -51,11 +51,11 @@ def test_raw_correlation_u8_matches_fp64(torch, log2n):
     torch.cuda.synchronize()
     ea = _direct_corr(2.0 * ref - 1, 2.0 * a - 1, N)
     eb = _direct_corr(2.0 * ref - 1, 2.0 * (0.96 * b) - 1, N)
-    tol = 0.5 * 6e-8 * log2n * np.sqrt(R * Sa)  # the nominee margin the library uses
+    tol = 1.0 * 6e-8 * log2n * np.sqrt(R * Sa)  # the data-independent part of the nominee margin
     err_a = np.abs(out_a.cpu().numpy() - ea).max()
     err_b = np.abs(out_b.cpu().numpy() - eb).max()
     print("N=2^%d max abs err a=%.4g b=%.4g (margin %.4g)" % (log2n, err_a, err_b, tol))
-    assert err_a < tol / 4 and err_b < tol / 4  # fp32 error must stay well inside the margin
+    assert err_a < tol / 8 and err_b < tol / 8  # fp32 error must stay well inside the margin
     plan.close()
 
 
@@ -415,3 +415,26 @@ def test_aligner_is_usable_from_a_thread_pool(torch):
     with ThreadPoolExecutor(max_workers=4) as ex:
         for out, off in ex.map(solve, jobs):
             assert out == [off] * 5
+
+
+def test_extreme_densities_stay_exact(torch):
+    """Activity densities of 2 % / 98 % give the correlation a huge DC term and the fp32 pipeline its
+    largest error (~0.3 at N = 2^21); the margin widens with the maximum so the exact winner is still
+    nominated.  Offsets and scores must equal an exact evaluation."""
+    from ffsubsync_amd.aligners import FFTAligner
+
+    for dens, seed in [(0.02, 1), (0.98, 2), (0.03, 3)]:
+        rng = np.random.RandomState(seed)
+        ref = (rng.rand(720000) < dens).astype(np.uint8)
+        sub = np.zeros(700000, np.uint8)
+        off = 1234 if dens < 0.5 else -777
+        idx = np.arange(sub.size) + off
+        ok = (idx >= 0) & (idx < ref.size)
+        sub[ok] = ref[idx[ok]]
+        flip = rng.rand(sub.size) < 0.002
+        sub = np.where(flip, 1 - sub, sub).astype(np.uint8)
+        for mo in (6000, None):
+            score, offset = FFTAligner(mo).fit_transform(ref, sub, get_score=True)
+            s_o, o_o = orc.fft_align(ref, sub, mo)
+            assert offset == o_o == off
+            assert float(score) == float(np.rint(s_o))
