@@ -438,3 +438,63 @@ def test_extreme_densities_stay_exact(torch):
             s_o, o_o = orc.fft_align(ref, sub, mo)
             assert offset == o_o == off
             assert float(score) == float(np.rint(s_o))
+
+
+def test_randomised_problems_against_oracle(torch):
+    """Fuzz over lengths (direct kernel, every FFT split up to 2^17), densities, sample levels, lag
+    windows (including ones wider than the data and Python-negative-slice ones) and candidate counts:
+    offsets must equal the oracle's whenever its top-2 gap exceeds 0.5, scores always match."""
+    from ffsubsync_amd.aligners import _Vec, solve_pairs
+
+    rng = np.random.RandomState(2024)
+    checked = unique = 0
+    for trial in range(140):
+        R = int(rng.choice([rng.randint(40, 400), rng.randint(400, 6000), rng.randint(6000, 70000)]))
+        S = int(max(20, R * rng.uniform(0.3, 1.6)))
+        dens = rng.choice([0.05, 0.3, 0.5, 0.9])
+        seg = np.maximum(1, rng.geometric(1.0 / rng.choice([2, 20, 200]), size=R))
+        ref01 = np.repeat(rng.rand(seg.size) < dens, seg)[:R]
+        n_cand = int(rng.choice([1, 1, 2, 3, 7]))
+        lo_hi_ref = [(0.0, 1.0), (-1.0, 1.0), (0.25, 1.0)][rng.randint(3)]
+        ref = np.where(ref01, lo_hi_ref[1], lo_hi_ref[0])
+        cands = []
+        for j in range(n_cand):
+            off = int(rng.randint(-S // 2, R // 2 + 1))
+            idx = np.arange(S) + off
+            ok = (idx >= 0) & (idx < R)
+            c01 = np.zeros(S, bool)
+            c01[ok] = ref01[idx[ok]]
+            c01 ^= rng.rand(S) < rng.choice([0.0, 0.02, 0.3])
+            amp = [1.0, 0.96, 0.999][rng.randint(3)]
+            cands.append(c01 * amp)
+        mo = [None, None, 6000, int(rng.randint(0, 3 * R)), int(rng.randint(1, 200))][rng.randint(5)]
+        cres, pres = solve_pairs([(_Vec(ref), [_Vec(c) for c in cands])], mo, mo)
+        best = None
+        for j, c in enumerate(cands):
+            conv, S_ = orc.convolve_full(ref, c)
+            m = orc.mask_extreme_offsets(conv, S_, mo)
+            k = int(np.argmax(m))
+            s_o, o_o = m[k], len(m) - 1 - k - S_
+            got_s, got_o = float(cres[0, j]["score"]), int(cres[0, j]["offset"])
+            checked += 1
+            if not np.isfinite(s_o):
+                assert got_s == -np.inf and got_o == o_o, (trial, j)
+                continue
+            assert got_s == pytest.approx(s_o, rel=1e-9, abs=1e-6), (trial, j, R, S, mo)
+            fin = np.sort(m[np.isfinite(m)])
+            if fin.size < 2 or fin[-1] - fin[-2] > 0.5:
+                unique += 1
+                assert got_o == o_o, (trial, j, R, S, mo, got_o, o_o)
+            else:
+                assert m[len(m) - 1 - got_o - S_] >= s_o - 1e-6 * max(1.0, abs(s_o)), (trial, j)
+        assert not (cres["flags"] & 2).any()
+        # MaxScoreAligner.transform: drop |offset| > max, first maximum wins (aligners.py:154-167)
+        kept = [(float(cres[0, j]["score"]), j) for j in range(n_cand)
+                if mo is None or abs(int(cres[0, j]["offset"])) <= mo]
+        if not kept:
+            assert int(pres[0]["best_cand"]) == -1
+        else:
+            top = max(s for s, _ in kept)
+            assert int(pres[0]["best_cand"]) == next(j for s, j in kept if s == top)
+            assert float(pres[0]["score"]) == top
+    assert unique > checked // 2
