@@ -43,6 +43,30 @@ class DeviceBatch:
         return n
 
 
+def pack_pairs(pairs) -> DeviceBatch:
+    """DeviceBatch from HBM-resident two-level vectors: ``pairs`` is a list of
+    (reference, [candidates]) whose items expose ``.bits`` (uint8 CUDA tensor), ``.lo`` and ``.hi``
+    (e.g. ``subtitle_raster.DeviceRaster``).  The vectors are copied device-to-device into one
+    buffer at 64-byte aligned offsets."""
+    torch = _native.require_gpu()
+    n_pairs, n_vec = len(pairs), 1 + len(pairs[0][1])
+    flat = []
+    for ref, cands in pairs:
+        if len(cands) != n_vec - 1:
+            raise ValueError("all pairs need the same number of candidates")
+        flat.append(ref)
+        flat.extend(cands)
+    lens = np.array([int(v.bits.numel()) for v in flat], dtype=np.int64).reshape(n_pairs, n_vec)
+    padded = (lens + 63) // 64 * 64
+    offs = np.concatenate([[0], np.cumsum(padded.ravel())[:-1]]).reshape(n_pairs, n_vec).astype(np.int64)
+    data = torch.zeros(int(padded.sum()), dtype=torch.uint8, device=flat[0].bits.device)
+    for v, o in zip(flat, offs.ravel()):
+        data[int(o): int(o) + int(v.bits.numel())] = v.bits
+    lo = np.array([v.lo for v in flat], dtype=np.float64).reshape(n_pairs, n_vec)
+    hi = np.array([v.hi for v in flat], dtype=np.float64).reshape(n_pairs, n_vec)
+    return DeviceBatch(data, offs, lens, lo, hi)
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of ceil(n/world) items per rank: [lo, hi)."""
     per = (n_items + world - 1) // world

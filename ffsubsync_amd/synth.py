@@ -115,3 +115,18 @@ def simple_pair(n_ref: int, n_sub: int, offset: int, seed: int = 0, density: flo
     noise = rng.rand(n_sub) < flip
     sub = np.where(noise, 1 - sub, sub).astype(np.uint8)
     return ref, sub
+
+
+def make_subtitle_records(seed: int, duration_s: float = 5400.0, mean_gap_s: float = 3.0, mean_dur_s: float = 2.7):
+    """Seeded subtitle file as (start_us, end_us, is_metadata) with millisecond stamps (srt
+    resolution): alternating gaps U[0.2, 2*mean_gap] and lines U[0.4, 2*mean_dur] up to the duration."""
+    rng = np.random.RandomState(seed)
+    n_max = int(duration_s / 0.6) + 8
+    gaps = rng.uniform(0.2, 2.0 * mean_gap_s, n_max)
+    durs = rng.uniform(0.4, 2.0 * mean_dur_s, n_max)
+    ends = np.cumsum(gaps + durs)
+    keep = ends < duration_s
+    ends, durs = ends[keep], durs[keep]
+    start_us = np.rint((ends - durs) * 1e3).astype(np.int64) * 1000
+    end_us = np.rint(ends * 1e3).astype(np.int64) * 1000
+    return start_us, end_us, np.zeros(start_us.size, dtype=np.uint8)

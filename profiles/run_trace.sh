@@ -7,5 +7,5 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- \
-    python $GRAFT_REPO_ROOT/bench.py --cpu-pairs 0 --skip-full-length-record --no-vad $EXTRA > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.log"
+    python $GRAFT_REPO_ROOT/bench.py --cpu-pairs 0 --e2e-files 0 --skip-full-length-record --no-vad $EXTRA > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.log"
 ls "$OUT"
