@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
-    ap.add_argument("--pairs-in-flight", type=int, default=64)
+    ap.add_argument("--pairs-in-flight", type=int, default=128)
     ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-vad", action="store_true", help="skip the VAD frame-energy sweep figures")
@@ -133,7 +133,7 @@ def e2e_figures(torch, _native, n_files, minutes=90.0):
             ref = DeviceRaster((labels > 0.5).to(torch.uint8), 0.0, 1.0)
             pairs.append((ref, rasterize_candidates(s_us, e_us, meta, ratios)))
         db = batch.pack_pairs(pairs)
-        al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=min(64, n_files))
+        al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=min(128, n_files))
         _, pres = al.solve(db)
         al.plan.close()
         return pres
