@@ -334,6 +334,100 @@ class VideoSpeechTransformer(PCMSpeechTransformer):
         return self
 
 
+def _probe_duration(fname: str, ffmpeg_path: Optional[str] = None) -> float:
+    """Container duration in seconds via an ffprobe subprocess (the reference uses ffmpeg-python's
+    probe for the same number, speech_transformers.py:849-858)."""
+    exe = "ffprobe" if ffmpeg_path is None else os.path.join(ffmpeg_path, "ffprobe")
+    out = subprocess.check_output([exe, "-v", "error", "-show_entries", "format=duration", "-of",
+                                   "default=noprint_wrappers=1:nokey=1", fname], stdin=subprocess.DEVNULL)
+    return float(out.decode().strip())
+
+
+class MultiSegmentVideoSpeechTransformer(TransformerMixin):
+    """Sparse reference signal from a few sampled windows (speech_transformers.py:760-903): VAD runs on
+    ``segment_count`` windows of ``segment_duration`` seconds spread evenly over the reference (each
+    through its own :class:`VideoSpeechTransformer`, up to ``parallel_workers`` at a time -- every worker
+    thread drives the GPU through its own handles) and the labels are scattered into an otherwise
+    zero full-length vector, which the aligner consumes unchanged."""
+
+    START_MARGIN_SECONDS: int = 30
+    END_MARGIN_SECONDS: int = 60
+
+    def __init__(self, vad: str, sample_rate: int, frame_rate: int, non_speech_label: float,
+                 segment_count: int = 8, segment_duration: int = 60, skip_intro_outro: bool = False,
+                 parallel_workers: int = 4, ffmpeg_path: Optional[str] = None, ref_stream: Optional[str] = None,
+                 vlc_mode: bool = False, gui_mode: bool = False) -> None:
+        self.vad = vad.split("subs_then_")[-1]  # sampling is audio-only (:795-797)
+        self.sample_rate = sample_rate
+        self.frame_rate = frame_rate
+        self._non_speech_label = non_speech_label
+        self.segment_count = segment_count
+        self.segment_duration = segment_duration
+        self.skip_intro_outro = skip_intro_outro
+        self.parallel_workers = parallel_workers
+        self.ffmpeg_path = ffmpeg_path
+        self.ref_stream = ref_stream
+        self.vlc_mode = vlc_mode
+        self.gui_mode = gui_mode
+        self.video_speech_results_: Optional[np.ndarray] = None
+
+    def _segment_starts(self, total_duration: float) -> List[int]:
+        """Start seconds of the sampled windows (:813-834): evenly spaced over the usable span, margins
+        honoured when they leave room, clamped into range and de-duplicated."""
+        window = self.segment_duration
+        if total_duration <= window:
+            return [0]
+        first = float(self.START_MARGIN_SECONDS if self.skip_intro_outro else 0)
+        last = total_duration - (self.END_MARGIN_SECONDS if self.skip_intro_outro else 0)
+        if last - first < window:
+            first, last = 0.0, total_duration
+        span = last - first - window
+        count = max(1, self.segment_count)
+        if span <= 0 or count == 1:
+            return [int(max(0.0, min(first, total_duration - window)))]
+        picks = [int(round(first + i * span / (count - 1))) for i in range(count)]
+        top = int(total_duration) - window
+        return sorted({max(0, min(p, top)) for p in picks})
+
+    def _extract_segment_speech(self, fname: str, start: int):
+        seg = VideoSpeechTransformer(self.vad, self.sample_rate, self.frame_rate, self._non_speech_label,
+                                     start_seconds=start, ffmpeg_path=self.ffmpeg_path, ref_stream=self.ref_stream,
+                                     vlc_mode=self.vlc_mode, gui_mode=self.gui_mode,
+                                     max_duration_seconds=self.segment_duration)
+        seg.fit(fname)
+        return start, seg.transform()
+
+    def fit(self, fname: str, *_) -> "MultiSegmentVideoSpeechTransformer":
+        from concurrent.futures import ThreadPoolExecutor, as_completed
+
+        try:
+            total_duration = float(_probe_duration(fname, self.ffmpeg_path))
+        except Exception as e:
+            raise ValueError("multi-segment sync needs the reference duration, but probing "
+                             "'%s' failed: %s" % (fname, e))
+        starts = self._segment_starts(total_duration)
+        sparse = np.zeros(int(total_duration * self.sample_rate) + 2, dtype=float)
+        with ThreadPoolExecutor(max_workers=max(1, min(self.parallel_workers, len(starts)))) as pool:
+            pending = {pool.submit(self._extract_segment_speech, fname, s): s for s in starts}
+            for fut in as_completed(pending):
+                try:
+                    start, labels = fut.result()
+                except Exception:  # one bad window must not sink the sync (:878-886)
+                    continue
+                lo = int(start * self.sample_rate)
+                hi = min(lo + len(labels), len(sparse))
+                if hi > lo:
+                    sparse[lo:hi] = labels[: hi - lo]
+        if not np.any(sparse > 0):
+            raise ValueError("Unable to detect speech in any sampled segment. "
+                             "Perhaps try specifying a different stream / track, or a different vad.")
+        self.video_speech_results_ = sparse
+        return self
+
+    def transform(self, *_) -> np.ndarray:
+        return self.video_speech_results_
+
+
 def serialize_speech(fname: str, speech) -> None:
     """``--serialize-speech``: np.savez_compressed(<ref>.npz, speech=...) (ffsubsync/ffsubsync.py:639-644)."""
     np.savez_compressed(fname, speech=np.asarray(speech))

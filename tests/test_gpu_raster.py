@@ -181,3 +181,45 @@ def test_video_speech_transformer_over_a_fake_ffmpeg_pipe(monkeypatch):
     assert len(secs) == 3 and secs == sorted(secs) and seen[-1].total_seconds == 600.0 and 0 < seen[0].fraction <= 1
     with pytest.raises(ValueError, match="unknown vad"):
         st.VideoSpeechTransformer("nonsense", 100, 48000, 0.0).fit("x.mkv")
+
+
+def test_multi_segment_reference_on_four_threads(monkeypatch):
+    """MultiSegmentVideoSpeechTransformer with the real GPU detector behind a fake ffmpeg that honours
+    -ss / -t: four worker threads run the VAD concurrently; the sparse vector must equal the oracle's
+    labels inside the sampled windows and be zero elsewhere."""
+    import ffsubsync_amd.speech_transformers as st
+
+    total_s = 600
+    pcm, _ = vo.synth_pcm(480 * 100 * total_s, seed=21)
+    full = vo.detect_fast(pcm)
+
+    def seconds(txt):
+        h, m, s = txt.split(":")
+        return int(h) * 3600 + int(m) * 60 + int(float(s))
+
+    class FakeProcess:
+        def __init__(self, cmd, **kw):
+            start = seconds(cmd[cmd.index("-ss") + 1]) if "-ss" in cmd else 0
+            dur = seconds(cmd[cmd.index("-t") + 1])
+            self.raw = pcm[start * 48000: (start + dur) * 48000].tobytes()
+            self.pos = 0
+            self.stdout = self
+
+        def read(self, n):
+            blob = self.raw[self.pos:self.pos + n]
+            self.pos += len(blob)
+            return blob
+
+        def wait(self):
+            return 0
+
+    monkeypatch.setattr(st.subprocess, "Popen", FakeProcess)
+    monkeypatch.setattr(st, "_probe_duration", lambda *a, **k: float(total_s))
+    t = st.MultiSegmentVideoSpeechTransformer("energy", 100, 48000, 0.0, segment_count=6, segment_duration=30,
+                                              parallel_workers=4).fit("ref.mkv")
+    sparse = t.transform()
+    assert sparse.size == total_s * 100 + 2
+    want = np.zeros_like(sparse)
+    for s in t._segment_starts(float(total_s)):
+        want[s * 100: (s + 30) * 100] = full[s * 100: (s + 30) * 100]
+    assert np.array_equal(sparse, want) and sparse.sum() > 0
