@@ -839,14 +839,27 @@ int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, cons
     if (out_len >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
     hipStream_t st = (hipStream_t)hip_stream;
     if (out_len > 0) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_len, st));
-    std::vector<int32_t> iv((size_t)(2 * n_subs + 2));
+    // The interval list is a host temporary that an asynchronous copy reads later: park it in a
+    // per-thread keep-alive list that is only emptied after a stream synchronisation, so that a run
+    // of calls (seven ratios per file) costs one sync per 64 calls instead of one each.
+    thread_local std::vector<std::vector<int32_t>> keep_alive;
+    thread_local hipStream_t keep_stream = nullptr;
+    if (keep_alive.size() >= 64 || (!keep_alive.empty() && keep_stream != st)) {
+        HIP_TRY(hipStreamSynchronize(keep_stream));
+        keep_alive.clear();
+    }
+    keep_stream = st;
+    keep_alive.emplace_back((size_t)(2 * n_subs + 2));
+    std::vector<int32_t>& iv = keep_alive.back();
     const int64_t n_iv = ffs_raster_intervals(start_us, end_us, is_metadata, n_subs, ratio, sample_rate, start_seconds,
                                               out_len, iv.data());
-    if (n_iv == 0) return FFS_OK;
+    if (n_iv == 0) {
+        keep_alive.pop_back();
+        return FFS_OK;
+    }
     int2* d_iv = nullptr;
     HIP_TRY(hipMallocAsync((void**)&d_iv, (size_t)n_iv * sizeof(int2), st));
     HIP_TRY(hipMemcpyAsync(d_iv, iv.data(), (size_t)n_iv * sizeof(int2), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // iv is a host temporary; the copy must have consumed it
     const int blocks = (int)((n_iv + 3) / 4);
     hipLaunchKernelGGL(k_fill_intervals, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, d_iv, (int)n_iv, out_dev);
     HIP_TRY(hipGetLastError());
