@@ -160,3 +160,37 @@ def test_npz_speech_round_trip(tmp_path):
     np.savez(str(tmp_path / "bad.npz"), other=speech)
     with pytest.raises(ValueError, match='could not find "speech" array'):
         DeserializeSpeechTransformer(0.0).fit(str(tmp_path / "bad.npz"))
+
+
+def test_install_swaps_the_classes_the_caller_binds(monkeypatch):
+    """ffsubsync/ffsubsync.py:14 binds FFTAligner / MaxScoreAligner by name from ffsubsync.aligners;
+    install() must replace them in both modules (the seam tests/test_quality_gate.py:98-102 patches)
+    and adopt the reference's exception class so the caller's `except` clauses keep working."""
+    import sys
+    import types
+
+    import ffsubsync_amd
+    from ffsubsync_amd import aligners as amd_aligners
+
+    class RefFailed(Exception):
+        pass
+
+    pkg = types.ModuleType("ffsubsync")
+    pkg.__path__ = []
+    ref_al = types.ModuleType("ffsubsync.aligners")
+    ref_al.FFTAligner, ref_al.MaxScoreAligner, ref_al.FailedToFindAlignmentException = object, object, RefFailed
+    ref_main = types.ModuleType("ffsubsync.ffsubsync")
+    ref_main.FFTAligner, ref_main.MaxScoreAligner = object, object
+    pkg.aligners, pkg.ffsubsync = ref_al, ref_main
+    for name, mod in (("ffsubsync", pkg), ("ffsubsync.aligners", ref_al), ("ffsubsync.ffsubsync", ref_main)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    monkeypatch.setattr(amd_aligners, "FailedToFindAlignmentException", amd_aligners.FailedToFindAlignmentException)
+    monkeypatch.setattr(ffsubsync_amd, "FailedToFindAlignmentException", ffsubsync_amd.FailedToFindAlignmentException)
+    ffsubsync_amd.install()
+    for mod in (ref_al, ref_main):
+        assert mod.FFTAligner is amd_aligners.FFTAligner and mod.MaxScoreAligner is amd_aligners.MaxScoreAligner
+    assert amd_aligners.FailedToFindAlignmentException is RefFailed
+    # the drop-in now raises the reference's exception type
+    c0 = golden_cases.build_cases(include_large=False)["mask_all"]
+    with pytest.raises(RefFailed, match="Synchronization failed"):
+        MaxScoreAligner(OracleBackedAligner, None, 100, 0).fit_transform(c0["ref"], list(c0["cands"]))
