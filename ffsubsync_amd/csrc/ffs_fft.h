@@ -377,4 +377,63 @@ FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& 
     }
 }
 
+// ---- column transforms of length 3 * 2^k ----------------------------------------------------
+// A column transform of length L = 3*LI (LI a power of two) is three interleaved length-LI transforms
+// (decimation in time) and one radix-3 combine:
+//     F_g[k'] = sum_j x[3j + g] W_LI^(j k')                       g = 0..2, k' < LI
+//     X[k' + LI*r] = sum_g W_L^(g k') W_3^(g r) F_g[k']           r = 0..2
+// Thread u12 (= 3u + g) of a column holds x[u12 + (L/16)*q] = x[3(u + LTI*q) + g], i.e. exactly the
+// inputs of sub-transform g in fft_regs' register layout -- the loads are the same as for a
+// power-of-two column.  After the sub-transforms the three groups swap their (twiddled) F_g through
+// LDS and thread (u, g) produces the outputs of r = g:  X[(u + LI*g) + LTI*q].
+template <int L>
+struct ColShape {
+    static constexpr bool R3 = (L % 3 == 0);
+    static constexpr int LI = R3 ? L / 3 : L;  // power-of-two transform length
+    static constexpr int LT = L / 16;          // threads per column
+    static constexpr int LTI = LI / 16;        // threads per power-of-two transform
+    static constexpr int OSTEP = LTI;          // output index = out_base(u12) + OSTEP*q
+    static FFS_DEV int out_base(int u12) { return R3 ? (u12 / 3) + LI * (u12 % 3) : u12; }
+};
+
+#define FFS_SQRT3_HALF 0.86602540378443864676f
+
+// Forward DFT of one column of a C-column tile.  In: v[q] = x[u12 + LT*q].  Out: v[q] =
+// X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L), used only for L = 3*LI.
+template <int L, int C>
+FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
+                     const cf* __restrict__ tw3) {
+    typedef ColShape<L> CS;
+    if constexpr (!CS::R3) {
+        ColAddr<L, C> addr(u12, c);
+        fft_regs<L>(v, lds, u12, addr, twr);
+    } else {
+        constexpr int LI = CS::LI, LTI = CS::LTI;
+        const int u = u12 / 3, g = u12 % 3;
+        cf wg[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wg[q] = tw3[g * (u + LTI * q)];  // W_L^(g k'), requested early
+        ColAddr<LI, C> addr(u, c);
+        fft_regs<LI>(v, lds + g * (LI * C), u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], wg[q]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lds[(g * LI + u + LTI * q) * C + c] = v[q];
+        __syncthreads();
+        // W_3 = -1/2 - i*sqrt(3)/2:  X_r = a + alpha*(b + cc) + beta*(-i)*(b - cc),
+        // (alpha, beta) = (1, 0), (-1/2, sqrt3/2), (-1/2, -sqrt3/2) for r = 0, 1, 2
+        const float alpha = (g == 0) ? 1.0f : -0.5f;
+        const float beta = (g == 0) ? 0.0f : (g == 1 ? FFS_SQRT3_HALF : -FFS_SQRT3_HALF);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = (u + LTI * q) * C + c;
+            const cf a = lds[k], b = lds[LI * C + k], cc = lds[2 * LI * C + k];
+            const cf t = cadd(b, cc), d = csub(b, cc);
+            v[q].x = a.x + alpha * t.x + beta * d.y;
+            v[q].y = a.y + alpha * t.y - beta * d.x;
+        }
+    }
+}
+
 }  // namespace ffsa

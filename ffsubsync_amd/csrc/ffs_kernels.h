@@ -153,9 +153,11 @@ template <int L, int C, int DT>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
-                                                         int log2CL, int xf_per_pair, int slots_per_pair) {
+                                                         const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
+                                                         int slots_per_pair) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
+    typedef ColShape<L> CS;
     constexpr int LT = L / 16;
     const int c = threadIdx.x % C;
     const int u = threadIdx.x / C;
@@ -167,9 +169,10 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     const int n2 = tile * C + c;
     const XformDesc d = descs[blockIdx.y];
     // every table value this thread needs is requested up front, together with the inputs
-    TwRegs<L> twr;
-    twr.load(tw, u);
-    // W_N^(n2*k1), k1 = u + LT*q:  tb[u][n2] * g^q with g = W_N^(n2*LT).  Only g, g^2, g^4, g^8 are
+    TwRegs<CS::LI> twr;
+    twr.load(tw, CS::R3 ? u / 3 : u);
+    // W_N^(n2*k1), k1 = ob + OSTEP*q (ob = out_base(u)):  tb[u][n2] * g^q with g = W_N^(n2*OSTEP) (the
+    // host lays the tables out per column shape).  Only g, g^2, g^4, g^8 are
     // fetched (ts rows 1, 2, 4, 8); the other powers are built with at most three multiplications
     // each, which trades eleven table loads per thread for eleven packed complex multiplies.
     cf wq[16];
@@ -224,9 +227,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
         }
     }
-    ColAddr<L, C> addr(u, c);
-    fft_regs<L>(v, lds, u, addr, twr);
-    // v[q] = Y[k1 = u + LT*q][n2]
+    col_fft<L, C>(v, lds, u, c, twr, tw3);
+    // v[q] = Y[k1 = ob + OSTEP*q][n2]
+    const int ob = CS::out_base(u);
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
@@ -255,13 +258,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             cf got;
             got.x = __shfl_xor(give.x, 1, 64);
             got.y = __shfl_xor(give.y, 1, 64);
-            const int k1 = u + LT * (2 * j + (odd ? 1 : 0));
+            const int k1 = ob + CS::OSTEP * (2 * j + (odd ? 1 : 0));
             float4 pk = odd ? make_float4(got.x, got.y, mine.x, mine.y) : make_float4(mine.x, mine.y, got.x, got.y);
             *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, c & ~1, log2CL) + ((size_t)k1 << log2CL)]) = pk;
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)] = v[q];
+        for (int q = 0; q < 16; ++q) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];
     }
 }
 
@@ -440,7 +443,7 @@ FFS_DEV int cand_slot(int n_slots, int kp, int n_packed) {
 // --------------------------------------------------------------------------------------------
 // Lag-window bookkeeping shared by both pass-C variants.
 struct WinParams {
-    int S[2], lo[2], hi[2];
+    int lo[2], hi[2];
     float marg[2];
 };
 
@@ -450,7 +453,6 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
     for (int h = 0; h < 2; ++h) {
         const bool present = (2 * kp + h) < n_cand;
         const CandDesc& cd = cands[cand0 + (present ? 2 * kp + h : 0)];
-        w.S[h] = cd.S;
         w.lo[h] = cd.d_lo;
         w.hi[h] = (present && !(cd.flags & 1)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
         w.marg[h] = cd.margin;
@@ -471,7 +473,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
         const int m = m_of(q);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && better(val, d, bv[h], bd[h])) {
@@ -525,7 +527,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int m = m_of(q);
-            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && val >= thr) {
@@ -561,7 +563,7 @@ FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int n
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!want[h]) continue;
-            const int d = (m <= nN - 1 - wp.S[h]) ? m : m - nN;
+            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && val >= thr[h]) {
@@ -606,7 +608,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
                                                          BlockNom* __restrict__ bnom, float* __restrict__ out_a,
                                                          float* __restrict__ out_b, const NomList* __restrict__ noms,
                                                          PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries,
-                                                         int log2CL) {
+                                                         int log2CL, const cf* __restrict__ tw3) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -626,19 +628,20 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
         if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
     }
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
-    TwRegs<L> twr;
-    twr.load(tw, u);
+    typedef ColShape<L> CS;
+    TwRegs<CS::LI> twr;
+    twr.load(tw, CS::R3 ? u / 3 : u);
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
-    ColAddr<L, C> addr(u, c);
-    fft_regs<L>(v, lds, u, addr, twr);
-    // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LT*q
+    col_fft<L, C>(v, lds, u, c, twr, tw3);
+    // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = ob + OSTEP*q
     const int m1 = tile * C + c;
+    const int ob = CS::out_base(u);
     if (WRITE) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const size_t m = (size_t)m1 + (size_t)N2 * (u + LT * q);
+            const size_t m = (size_t)m1 + (size_t)N2 * (ob + CS::OSTEP * q);
             if (out_a) out_a[m] = v[q].x;
             if (out_b) out_b[m] = v[q].y;
         }
@@ -647,11 +650,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
     if (MODE == 2) {
         block_collect_all<16>(
-            v, [&](int q) { return m1 + N2 * (u + LT * q); }, wp, (int)N, xci, xwant, xthr, pool, entries);
+            v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, xci, xwant, xthr, pool, entries);
         return;
     }
     block_nominees<16, NW>(
-        v, [&](int q) { return m1 + N2 * (u + LT * q); }, wp, (int)N, smem, tid,
+        v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, smem, tid,
         &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
 }
 
@@ -705,11 +708,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     __syncthreads();
     const int lane = tid % 64;
     for (int i = 0; i < bins.n; ++i) {
-        const int b = bins.b[i];
+        const unsigned b = (unsigned)(bins.b[i] + L) % L;
         cf a = mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const cf w = s_tw[((u + LT * q) * b) & (L - 1)];
+            const cf w = s_tw[((unsigned)(u + LT * q) * b) % L];
             a.x = fmaf(v[q].x, w.x, fmaf(-v[q].y, w.y, a.x));
             a.y = fmaf(v[q].x, w.y, fmaf(v[q].y, w.x, a.y));
         }
@@ -726,7 +729,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     }
     __syncthreads();
     // thread t finishes (bin, column) pairs t, t + NT, ...  (more than one only when LT < MAXBINS)
-    constexpr int NVF = (LT >= MAXBINS) ? 1 : (MAXBINS / LT);
+    constexpr int NVF = (MAXBINS + LT - 1) / LT;
     cf val[NVF];
     int mm[NVF];
 #pragma unroll
@@ -741,7 +744,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                 val[j].x += p.x;
                 val[j].y += p.y;
             }
-            const int m2 = (bins.b[i] + L) & (L - 1);
+            const int m2 = (bins.b[i] + L) % L;
             mm[j] = tile * C + cc + N2 * m2;
         }
     }

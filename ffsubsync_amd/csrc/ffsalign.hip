@@ -49,6 +49,10 @@ int ilog2(int64_t x) {
 
 // column-tile width for a column transform of length L
 int tile_cols(int L) {
+    if (L % 3 == 0) {  // 3 * 2^k columns: 48, 96, 192, 384, 768
+        const int c = 3072 / L;
+        return c < 16 ? 16 : c;
+    }
     if (L <= 16) return 256;
     if (L <= 128) return 4096 / L;
     if (L <= 1024) return 16;
@@ -87,6 +91,13 @@ std::vector<cf> make_stage_tables(int L) {
     if (R2 > 1) add(R2, 256);
     if (t.empty()) t.push_back(mk(1.f, 0.f));
     return t;
+}
+
+// Transform lengths 3 * 2^k the kernels can run: N = N1 * N2 with N1 = 3 * 2^j in [48, 768] columns.
+bool radix3_length(int64_t n) {
+    if (n % 3) return false;
+    const int64_t m = n / 3;
+    return (m & (m - 1)) == 0 && n >= 48 * 256 && n <= 768 * 4096;
 }
 
 cf wn(int64_t N, int64_t p) {
@@ -202,7 +213,7 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       p->tw1, p->tbA, p->tsA, p->log2CL, xf_per_pair, slots_per_pair);
+                       p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -210,6 +221,11 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
 template <int DT>
 int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, hipStream_t st) {
     switch (p->N1) {
+        case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 192: return launch_pass_a_inst<192, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 384: return launch_pass_a_inst<384, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 768: return launch_pass_a_inst<768, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
         case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
         case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
         case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
@@ -280,7 +296,8 @@ int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand,
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_c<L, C, MODE>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
-                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL);
+                       cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL,
+                       p->twn1);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -291,6 +308,11 @@ int launch_pass_c(const ffs_plan* p, const CandDesc* cands, int first_cand, int 
 #define FFS_PC(L, C) \
     case L: return launch_pass_c_inst<L, C, MODE>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, out_a, out_b, pa, st)
     switch (p->N1) {
+        FFS_PC(48, 64);
+        FFS_PC(96, 32);
+        FFS_PC(192, 16);
+        FFS_PC(384, 16);
+        FFS_PC(768, 16);
         FFS_PC(16, 256);
         FFS_PC(32, 128);
         FFS_PC(64, 64);
@@ -330,6 +352,11 @@ int launch_pass_c_pruned(const ffs_plan* p, const CandDesc* cands, int first_can
 #define FFS_PCP(L, C) \
     case L: return launch_pass_c_pruned_inst<L, C, EXH>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, pa, st)
     switch (p->N1) {
+        FFS_PCP(48, 64);
+        FFS_PCP(96, 32);
+        FFS_PCP(192, 16);
+        FFS_PCP(384, 16);
+        FFS_PCP(768, 16);
         FFS_PCP(16, 256);
         FFS_PCP(32, 128);
         FFS_PCP(64, 64);
@@ -395,6 +422,16 @@ bool lag_window(int64_t R, int64_t S, int64_t n_ref, int64_t max_off, int64_t* d
     *d_hi = n_ref - 1 - S - kA;
     *d_lo = n_ref - S - kB;
     return true;
+}
+
+// Samples that can meet the other vector at some lag of the window: s[i] is multiplied by r[i+d], which
+// is zero padding unless i + d < R, so only i < R - d_lo of the candidate and j < S + d_hi of the
+// reference ever contribute.  The transforms read just these prefixes.
+void effective_lengths(int64_t R, int64_t S, int64_t d_lo, int64_t d_hi, int64_t* s_eff, int64_t* r_eff) {
+    int64_t se = R - d_lo < S ? R - d_lo : S;
+    int64_t re = S + d_hi < R ? S + d_hi : R;
+    *s_eff = se < 1 ? 1 : se;
+    *r_eff = re < 1 ? 1 : re;
 }
 
 int64_t next_pow2(int64_t x) {
@@ -477,21 +514,29 @@ int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_sam
     if (n_ref == 0 || max_offset_samples < 0) return n_ref;
     int64_t d_lo, d_hi;
     if (!lag_window(ref_len, sub_len, n_ref, max_offset_samples, &d_lo, &d_hi)) return 2;  // nothing to evaluate
-    // lags d in [d_lo, d_hi] of a length-n circular correlation equal the linear ones iff
-    // d - n <= -S and d + n >= R for all of them; the kernels also need S <= n and d_hi <= n-1-S.
-    int64_t need = sub_len + d_hi + 1;
-    if (ref_len - d_lo + 1 > need) need = ref_len - d_lo + 1;
-    if (sub_len > need) need = sub_len;
-    if (ref_len > need) need = ref_len;
-    const int64_t n = next_pow2(need);
+    // lags d in [d_lo, d_hi] of a length-n circular correlation equal the linear ones iff no product
+    // wraps: S' + d_hi <= n and R' - d_lo <= n for the prefixes (S', R') that reach the window at all
+    int64_t s_eff, r_eff;
+    effective_lengths(ref_len, sub_len, d_lo, d_hi, &s_eff, &r_eff);
+    int64_t need = s_eff + d_hi + 1;
+    if (r_eff - d_lo + 1 > need) need = r_eff - d_lo + 1;
+    if (s_eff > need) need = s_eff;
+    if (r_eff > need) need = r_eff;
+    int64_t n = next_pow2(need);
+    // three quarters of that is enough for many inputs (a 2 h pair at 100 Hz needs 726 001 points:
+    // 3 * 2^18 = 786 432 instead of 2^20), and the column passes handle one factor of three
+    const char* e = getenv("FFS_DISABLE_RADIX3");
+    if (!(e && e[0] == '1') && n / 4 * 3 >= need && radix3_length(n / 4 * 3)) n = n / 4 * 3;
     return n < n_ref ? n : n_ref;
 }
 
 int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand, ffs_plan** out) {
     if (!out) return fail(FFS_E_INVALID, "out is null");
     *out = nullptr;
-    if (n_fft < 2 || n_fft > kMaxFftN || (n_fft & (n_fft - 1)))
-        return fail(FFS_E_INVALID, "n_fft must be a power of two in [2, 2^24], got %lld", (long long)n_fft);
+    const bool r3 = radix3_length(n_fft);
+    if (n_fft < 2 || n_fft > kMaxFftN || ((n_fft & (n_fft - 1)) && !r3))
+        return fail(FFS_E_INVALID, "n_fft must be a power of two in [2, 2^24] or 3*2^k in [12288, 3145728], got %lld",
+                    (long long)n_fft);
     if (pairs_in_flight < 1 || max_cand < 1) return fail(FFS_E_INVALID, "pairs_in_flight and max_cand must be >= 1");
     HIP_TRY(hipSetDevice(device));
     ffs_plan* p = new ffs_plan();
@@ -521,10 +566,15 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         *out = p;
         return FFS_OK;
     }
-    const int lg = ilog2(n_fft);
-    const int lg2 = lg - 4 < 12 ? lg - 4 : 12;
-    p->N2 = 1 << lg2;
-    p->N1 = (int)(n_fft >> lg2);
+    if (r3) {
+        p->N2 = n_fft >= 48 * 4096 ? 4096 : (int)(n_fft / 48);
+        p->N1 = (int)(n_fft / p->N2);
+    } else {
+        const int lg = ilog2(n_fft);
+        const int lg2 = lg - 4 < 12 ? lg - 4 : 12;
+        p->N2 = 1 << lg2;
+        p->N1 = (int)(n_fft >> lg2);
+    }
     p->C = tile_cols(p->N1);
     p->log2C = ilog2(p->C);
     p->log2CL = p->log2C < 6 ? 6 : p->log2C;
@@ -532,14 +582,19 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     const int64_t N = n_fft;
     const int N1 = p->N1, N2 = p->N2, LT1 = N1 / 16, LT2 = N2 / 16;
     int rc;
-    if ((rc = upload(&p->tw1, make_stage_tables(N1), &p->workspace_bytes))) return rc;
+    const int LI1 = r3 ? N1 / 3 : N1;  // power-of-two part of the column length
+    if ((rc = upload(&p->tw1, make_stage_tables(LI1), &p->workspace_bytes))) return rc;
     if ((rc = upload(&p->tw2, make_stage_tables(N2), &p->workspace_bytes))) return rc;
     {
         std::vector<cf> tb((size_t)LT1 * N2), ts((size_t)16 * N2);
-        for (int u = 0; u < LT1; ++u)
-            for (int n2 = 0; n2 < N2; ++n2) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * u);
+        // thread u of a column ends up with the outputs k1 = out_base(u) + ostep*q (ColShape in ffs_fft.h)
+        const int ostep = LI1 / 16;
+        for (int u = 0; u < LT1; ++u) {
+            const int ob = r3 ? (u / 3) + LI1 * (u % 3) : u;
+            for (int n2 = 0; n2 < N2; ++n2) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * ob);
+        }
         for (int q = 0; q < 16; ++q)
-            for (int n2 = 0; n2 < N2; ++n2) ts[(size_t)q * N2 + n2] = wn(N, (int64_t)n2 * LT1 * q);
+            for (int n2 = 0; n2 < N2; ++n2) ts[(size_t)q * N2 + n2] = wn(N, (int64_t)n2 * ostep * q);
         if ((rc = upload(&p->tbA, tb, &p->workspace_bytes))) return rc;
         if ((rc = upload(&p->tsA, ts, &p->workspace_bytes))) return rc;
     }
@@ -614,7 +669,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
     // Odd candidate counts leave the imaginary half of the last packed transform free: put the reference
     // there (k_mid_packed) instead of spending a fifth transform on it.
-    const bool packed_ref = !p->direct_only && p->allow_packed_ref && (n_cand % 2 == 1) && p->N2 == 4096 &&
+    const bool packed_ref = !p->direct_only && p->allow_packed_ref && (n_cand % 2 == 1) && p->N2 == 4096 && p->N1 % 3 != 0 &&
                             (p->N2 / 16) >= (1 << p->log2CL) && p->N1 >= 2;
     const int xf_per_pair = packed_ref ? n_packed : n_slots;
     const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
@@ -645,13 +700,24 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
         const size_t b = (size_t)pi * stride;
         VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
         std::vector<VecView> subs(n_cand);
+        int64_t ref_used = 1;
         for (int j = 0; j < n_cand; ++j) {
             subs[j] = VecView{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
             if (!ref.ptr || !subs[j].ptr) {
                 if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
             }
+            const CandDesc& cd = hc[(size_t)pi * n_cand + j];
             if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
+            // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
+            // keeps working on the whole vectors through the candidate descriptor)
+            int64_t s_eff, r_eff;
+            effective_lengths(ref.len, subs[j].len, cd.d_lo, cd.d_hi, &s_eff, &r_eff);
+            if (!(cd.flags & FFS_FLAG_EMPTY_WINDOW)) {
+                subs[j].len = s_eff;
+                if (r_eff > ref_used) ref_used = r_eff;
+            }
         }
+        ref.len = ref_used;
         if (packed_ref) {
             for (int k = 0; k < n_packed; ++k)
                 fill_xform(&hx[(size_t)pi * xf_per_pair + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : &ref);

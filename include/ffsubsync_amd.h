@@ -66,15 +66,18 @@ typedef struct ffs_pair_result {
  * 2**ceil(log2(R+S)) (aligners.py:67-68).  Returns 0 if either length is <= 0. */
 int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len);
 
-/* Smallest power-of-two transform length a plan needs for one (reference, candidate) solve.
+/* Smallest supported transform length (2^k, or 3*2^k in [12288, 3145728]) a plan needs for one
+ * (reference, candidate) solve.
  * Without a lag window this is ffs_fft_length (the full linear correlation).  With
  * max_offset_samples >= 0 only lags inside the reference's window [d_lo, d_hi] are ever looked at,
  * and a circular correlation of any length n >= max(S + d_hi, R - d_lo) + 1 reproduces those lags
  * exactly (no aliasing reaches them), so a shorter transform gives bit-identical results:
- * 2^20 instead of 2^21 for 2 h @ 100 Hz inputs with the default +-6000 window. */
+ * 3*2^18 = 786 432 instead of 2^21 for 2 h @ 100 Hz inputs with the default +-6000 window.
+ * (FFS_DISABLE_RADIX3=1 in the environment restricts the answer to powers of two.) */
 int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_samples);
 
-/* Create a plan for transform length n_fft (power of two, 2 <= n_fft <= 2^24) on `device`.
+/* Create a plan for transform length n_fft (a power of two in [2, 2^24], or 3*2^k in
+ * [12288, 3145728]) on `device`.
  * pairs_in_flight: how many (reference, candidates) problems share one sweep of the
  * A/mid/C kernels (sizes the workspace: pairs_in_flight * (1+ceil(max_cand/2)) * n_fft * 8 B).
  * Replaces: the per-call np.fft plan + temporaries of FFTAligner.fit (aligners.py:67-74). */

@@ -70,8 +70,40 @@ def stockham_fft(x, dtype=np.complex64):
     return cur
 
 
+def column_fft(x, dtype=np.complex64):
+    """Forward DFT along axis 0 for the column lengths of pass A / pass C: powers of two, or
+    L = 3*LI as the kernels' col_fft does it -- thread u12 = 3u + g holds x[u12 + (L/16) q] =
+    x[3 (u + LI/16 q) + g] (the inputs of sub-transform g), the three length-LI sub-transforms are
+    twiddled by W_L^(g k') and combined by a radix-3 butterfly; thread (u, g) ends up with the outputs
+    X[(u + LI g) + (LI/16) q]."""
+    L = x.shape[0]
+    if L % 3:
+        return stockham_fft(x, dtype)
+    LI, LT, LTI = L // 3, L // E, L // 3 // E
+    out = np.empty(x.shape, dtype)
+    w3 = np.exp(-2j * np.pi / 3)
+    F = []
+    for g in range(3):
+        sub = np.empty((LI,) + x.shape[1:], dtype)
+        for u in range(LTI):
+            u12 = 3 * u + g
+            for q in range(E):
+                sub[u + LTI * q] = x[u12 + LT * q]  # register slot q of thread u12
+        f = stockham_fft(sub, dtype)
+        k = np.arange(LI).reshape((LI,) + (1,) * (x.ndim - 1))
+        F.append(f * np.exp(-2j * np.pi * g * k / L).astype(dtype))
+    for r in range(3):
+        out[LI * r: LI * (r + 1)] = F[0] + (w3 ** r) * F[1] + (w3 ** (2 * r)) * F[2]
+    return out.astype(dtype)
+
+
 def split_n(N):
-    """N = N1 * N2 (N1: column length of pass A/C, N2: row length of the mid pass)."""
+    """N = N1 * N2 (N1: column length of pass A/C, N2: row length of the mid pass).  Lengths
+    3 * 2^k keep the factor three in N1 (48..768 columns)."""
+    if N % 3 == 0:
+        assert N >= 48 * 256 and N <= 768 * 4096 and (N // 3) & (N // 3 - 1) == 0
+        N2 = 4096 if N >= 48 * 4096 else N // 48
+        return N // N2, N2
     p = int(np.log2(N))
     assert 1 << p == N and p >= 8
     p2 = min(12, p - 4)
@@ -103,7 +135,7 @@ def correlate_model(ref_pm, sa_pm, sb_pm, N):
     def pass_a(x):
         # columns n2: FFT over n1 of x[N2*n1 + n2], times W_N^(n2*k1); tiled store
         X = x.reshape(N1, N2)
-        Y = stockham_fft(X)  # [k1, n2]
+        Y = column_fft(X)  # [k1, n2]
         k1 = np.arange(N1)[:, None]
         n2 = np.arange(N2)[None, :]
         Y = Y * inter_twiddle(N, n2, k1)
@@ -128,5 +160,5 @@ def correlate_model(ref_pm, sa_pm, sb_pm, N):
     T2[tile_offset(m1, k1, N1)] = Y2
     # pass C: columns m1, FFT over k1 -> out[m1 + N2*m2]
     cols = T2[tile_offset(m1, k1, N1)]  # [k1, m1]
-    O = stockham_fft(cols)  # [m2, m1]
+    O = column_fft(cols)  # [m2, m1]
     return O.reshape(N)  # index m2*N2 + m1

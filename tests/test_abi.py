@@ -47,12 +47,19 @@ def test_plan_length_never_exceeds_reference_length():
         r, s = int(rng.randint(1, 900000)), int(rng.randint(1, 900000))
         mo = [None, 0, 100, 6000, 10 ** 7][rng.randint(5)]
         n_ref, n = _native.fft_length(r, s), _native.plan_length(r, s, mo)
-        assert n <= n_ref and (n & (n - 1)) == 0
+        m = n // 3 if n % 3 == 0 else n  # a power of two, or three times one (column passes take a factor 3)
+        assert n <= n_ref and (m & (m - 1)) == 0
         if mo is None:
             assert n == n_ref
         elif n > 2:
-            assert n >= max(r, s)  # both vectors fit without wrapping onto themselves
-    assert _native.plan_length(720000, 750751, 6000) == 1 << 20
+            # the prefixes that can reach the lag window fit without wrapping onto themselves
+            assert n >= max(min(s, r + mo), min(r, s + mo))
+    assert _native.plan_length(720000, 750751, 6000) == 3 << 18   # 786 432 >= 750 751 + 6000 + 1
+    assert _native.plan_length(720000, 790000, 6000) == 3 << 18   # only 726 000 candidate samples reach the window
+    assert _native.plan_length(790000, 720000, 6000) == 3 << 18   # ... and 726 000 reference samples
+    assert _native.plan_length(790000, 790000, 6000) == 1 << 20   # needs 796 001
+    assert _native.plan_length(720000, 750751, 10 ** 7) == 1 << 21  # window as wide as the reference's
+    assert _native.plan_length(3000, 3000, 100) == 4096            # below the 3*2^k range
 
 
 def test_bad_arguments_are_reported_not_thrown():

@@ -14,7 +14,15 @@ def test_stockham_stages_match_numpy(L):
     assert np.abs(got - np.fft.fft(x, axis=0)).max() < 1e-5 * np.sqrt(L)
 
 
-@pytest.mark.parametrize("N", [4096, 8192, 1 << 15, 1 << 17])
+@pytest.mark.parametrize("L", [48, 96, 192, 384, 768])
+def test_radix3_columns_match_numpy(L):
+    rng = np.random.RandomState(L)
+    x = rng.randn(L, 3) + 1j * rng.randn(L, 3)
+    got = fm.column_fft(x, np.complex128)
+    assert np.abs(got - np.fft.fft(x, axis=0)).max() < 1e-5 * np.sqrt(L)
+
+
+@pytest.mark.parametrize("N", [4096, 8192, 1 << 15, 1 << 17, 3 << 12, 3 << 14, 3 << 16])
 def test_pipeline_matches_direct_correlation(N):
     rng = np.random.RandomState(N % 97)
     R, Sa, Sb = N // 2 - 3, N // 3, N // 2 - 100
@@ -39,3 +47,6 @@ def test_split_rule():
     for p in range(12, 25):
         n1, n2 = fm.split_n(1 << p)
         assert n1 * n2 == 1 << p and 16 <= n1 <= 4096 and 256 <= n2 <= 4096
+    for p in range(12, 21):
+        n1, n2 = fm.split_n(3 << p)
+        assert n1 * n2 == 3 << p and n1 % 3 == 0 and 48 <= n1 <= 768 and 256 <= n2 <= 4096

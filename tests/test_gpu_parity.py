@@ -59,6 +59,62 @@ def test_raw_correlation_u8_matches_fp64(torch, log2n):
     plan.close()
 
 
+@pytest.mark.parametrize("n", [3 << 12, 3 << 13, 3 << 14, 3 << 15, 3 << 16, 3 << 17, 3 << 18, 3 << 19, 3 << 20])
+def test_raw_correlation_three_times_power_of_two(torch, n):
+    """Transform lengths 3*2^k (one radix-3 step in the column passes): N1 = 48 with N2 = 256..4096,
+    then N1 = 96..768 with N2 = 4096; u8 and f32 inputs."""
+    from ffsubsync_amd import _native
+
+    rng = np.random.RandomState(n % 1009)
+    R, Sa, Sb = n // 2 - 5, n // 2 - 77, n // 3 + 1
+    ref = (rng.rand(R) < 0.35).astype(np.uint8)
+    a = (rng.rand(Sa) < 0.35).astype(np.uint8)
+    b = (rng.rand(Sb) < 0.6).astype(np.uint8)
+    plan = _native.Plan(n, 1, 2)
+    d = lambda x: torch.from_numpy(x).cuda()
+    out_a, out_b = plan.correlate_full(_native.FFS_DTYPE_U8, d(ref), (0, 1), d(a), (0, 1), d(b), (0.0, 0.96))
+    torch.cuda.synchronize()
+    ea = _direct_corr(2.0 * ref - 1, 2.0 * a - 1, n)
+    eb = _direct_corr(2.0 * ref - 1, 2.0 * (0.96 * b) - 1, n)
+    tol = 1.0 * 6e-8 * np.log2(n) * np.sqrt(R * Sa)
+    err_a = np.abs(out_a.cpu().numpy() - ea).max()
+    err_b = np.abs(out_b.cpu().numpy() - eb).max()
+    print("N=%d max abs err a=%.4g b=%.4g (margin %.4g)" % (n, err_a, err_b, tol))
+    assert err_a < tol / 8 and err_b < tol / 8
+    if n <= 3 << 16:
+        fa = rng.rand(Sa).astype(np.float32)
+        out_f, _ = plan.correlate_full(_native.FFS_DTYPE_F32, d(ref.astype(np.float32)), (0, 1), d(fa), (0, 1))
+        ef = _direct_corr(2.0 * ref - 1, 2.0 * fa.astype(float) - 1, n)
+        assert np.abs(out_f.cpu().numpy() - ef).max() < tol / 4
+    plan.close()
+
+
+def test_three_times_power_of_two_plans_give_identical_records(torch, monkeypatch):
+    """ffs_plan_length may pick 3*2^k; results must equal those of the power-of-two plan and of the
+    reference-length plan, with the pruned and the full last pass."""
+    from ffsubsync_amd import _native, batch, synth
+
+    assert _native.plan_length(720000, 750751, 6000) == 3 << 18
+    specs = [synth.make_pair_spec(500 + i, duration_s=d) for i, d in enumerate((7200.0, 6900.0, 3500.0, 1700.0))]
+    for group in (specs[:2], specs[2:3], specs[3:]):
+        db = batch.build_device_batch(group)
+        n3 = db.required_fft_length(6000)
+        assert n3 % 3 == 0, n3
+        n2 = 1 << int(np.ceil(np.log2(n3)))
+        n_full = db.required_fft_length(None)
+        a = batch.BatchAligner(n3, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        b = batch.BatchAligner(n2, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        c = batch.BatchAligner(n_full, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        monkeypatch.setenv("FFS_DISABLE_PRUNED_PASS_C", "1")
+        e = batch.BatchAligner(n3, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        monkeypatch.delenv("FFS_DISABLE_PRUNED_PASS_C")
+        for other in (b, c, e):
+            assert np.array_equal(a[0]["offset"], other[0]["offset"]) and np.array_equal(a[0]["score"], other[0]["score"])
+            assert np.array_equal(a[1], other[1])
+        for p, sp in enumerate(group):
+            assert a[1][p]["best_cand"] == sp.true_ratio_index
+
+
 def test_raw_correlation_f32_single_candidate(torch):
     from ffsubsync_amd import _native
 
@@ -273,7 +329,7 @@ def test_window_shortened_transform_equals_full_length(torch):
     from ffsubsync_amd import _native, batch, synth
     from ffsubsync_amd.aligners import _Vec, solve_pairs
 
-    assert _native.plan_length(720000, 750751, 6000) == 1 << 20 and _native.fft_length(720000, 750751) == 1 << 21
+    assert _native.plan_length(720000, 750751, 6000) == 3 << 18 and _native.fft_length(720000, 750751) == 1 << 21
     for name in ("config1_6000", "pipeline_10min", "mask100", "mask_negative_index", "sparse2"):
         c = SMALL[name]
         pair = [(_Vec(c["ref"]), [_Vec(s) for s in c["cands"]])]
