@@ -137,6 +137,11 @@ FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
     return in ? val : 0.0f;
 }
 
+// value of `x` in the neighbour lane (lane ^ 1): one DPP move, quad_perm [1,0,3,2]
+FFS_DEV float from_neighbour(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
 // Tile layout of the intermediate arrays: element (x, k1) of a transform (x = n2 or m1, k1 the
 // column-transform index) lives at ((x / CL)*N1 + k1)*CL + x % CL with CL = 2^log2CL >= C columns, so
 // a row k1 is a sequence of CL*8-byte chunks (256 B for CL = 32) and a block's C-column tile is a
@@ -211,13 +216,22 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         }
         __syncthreads();
         const int piece = (u % UPW) * PPR + c / 16;
+        // all 32 byte reads are issued back to back; the empty asm keeps the compiler from sinking each
+        // one into its own "n < len" branch (one exposed LDS round trip per element otherwise)
+        unsigned ba[16], bb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            ba[q] = stage[(q * 4 + piece) * 16 + (c & 15)];
+            bb[q] = stage[1024 + (q * 4 + piece) * 16 + (c & 15)];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(ba[q]), "+v"(bb[q]));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = (u + LT * q) * N2 + n2;
-            const unsigned char ba = stage[(q * 4 + piece) * 16 + (c & 15)];
-            const unsigned char bb = stage[1024 + (q * 4 + piece) * 16 + (c & 15)];
-            v[q].x = (n < d.len_a) ? (ba ? d.a1 : d.a0) : 0.0f;
-            v[q].y = (n < d.len_b) ? (bb ? d.b1 : d.b0) : 0.0f;
+            const float xa = ba[q] ? d.a1 : d.a0, xb = bb[q] ? d.b1 : d.b0;
+            v[q].x = (n < d.len_a) ? xa : 0.0f;
+            v[q].y = (n < d.len_b) ? xb : 0.0f;
         }
     } else {
 #pragma unroll
@@ -250,16 +264,21 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
         // the even-c lane writes rows q = 0,2,.. of columns (c, c+1), the odd-c lane rows q = 1,3,..
         // (a wave store then covers 8 full 128-byte rows).
+        // Even lanes end up with (own v[2j], neighbour's v[2j]), odd lanes with (neighbour's v[2j+1], own
+        // v[2j+1]); the exchange is a DPP move feeding a select (no LDS permute).
         const bool odd = c & 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const cf mine = odd ? v[2 * j + 1] : v[2 * j];   // stays in this lane's store
-            const cf give = odd ? v[2 * j] : v[2 * j + 1];   // goes to the partner lane
-            cf got;
-            got.x = __shfl_xor(give.x, 1, 64);
-            got.y = __shfl_xor(give.y, 1, 64);
+            const cf e = v[2 * j], o = v[2 * j + 1];
+            // (every lane executes all four moves: a DPP read of a lane that is masked off returns nothing)
+            const float nox = from_neighbour(o.x), noy = from_neighbour(o.y);
+            const float nex = from_neighbour(e.x), ney = from_neighbour(e.y);
+            float4 pk;
+            pk.x = odd ? nox : e.x;
+            pk.y = odd ? noy : e.y;
+            pk.z = odd ? o.x : nex;
+            pk.w = odd ? o.y : ney;
             const int k1 = ob + CS::OSTEP * (2 * j + (odd ? 1 : 0));
-            float4 pk = odd ? make_float4(got.x, got.y, mine.x, mine.y) : make_float4(mine.x, mine.y, got.x, got.y);
             *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, c & ~1, log2CL) + ((size_t)k1 << log2CL)]) = pk;
         }
     } else {
