@@ -261,6 +261,9 @@ def main():
         for i, sp in enumerate(specs)
     )
     ambiguous = int(((cres["flags"] & 2) != 0).sum())
+    # health of the fp32 transform chain itself (the exact re-evaluation would mask a damaged one as long
+    # as the true peak still gets nominated): fp32 value of every winning lag vs its exact score
+    fp32_err = float(np.abs(cres["score_f32"].astype(np.float64) - cres["score"]).max())
 
     solves_per_s = world * P * args.steps / elapsed
     result = {
@@ -285,7 +288,8 @@ def main():
             "pairs_in_flight": args.pairs_in_flight,
             "parallelism": "pairs sharded by rank, all-gather of 24 B/pair results" if world > 1 else "single GPU",
         },
-        "offset_match": {"pairs_matching_ground_truth": truth_ok, "pairs": P, "ambiguous_flags": ambiguous},
+        "offset_match": {"pairs_matching_ground_truth": truth_ok, "pairs": P, "ambiguous_flags": ambiguous,
+                         "max_abs_fp32_error_at_winning_lags": fp32_err},
         "solve_normaliser": {
             "bytes_per_solve": 168 * n_ref,
             "achieved_GBps": solves_per_s * 168 * n_ref / 1e9,

@@ -399,7 +399,8 @@ struct ColShape {
 #define FFS_SQRT3_HALF 0.86602540378443864676f
 
 // Forward DFT of one column of a C-column tile.  In: v[q] = x[u12 + LT*q].  Out: v[q] =
-// X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L), used only for L = 3*LI.
+// X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L) in LDS, outside the L*C elements at `lds`; used only
+// for L = 3*LI.
 template <int L, int C>
 FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
                      const cf* __restrict__ tw3) {
@@ -410,13 +411,12 @@ FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape
     } else {
         constexpr int LI = CS::LI, LTI = CS::LTI;
         const int u = u12 / 3, g = u12 % 3;
-        cf wg[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) wg[q] = tw3[g * (u + LTI * q)];  // W_L^(g k'), requested early
         ColAddr<LI, C> addr(u, c);
         fft_regs<LI>(v, lds + g * (LI * C), u, addr, twr);
+        // W_L^(g k') from the block's LDS copy of the table (a global load issued up front would pin
+        // sixteen register pairs across the whole sub-transform)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], wg[q]);
+        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], tw3[g * (u + LTI * q)]);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 16; ++q) lds[(g * LI + u + LTI * q) * C + c] = v[q];

@@ -137,6 +137,31 @@ FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
     return in ? val : 0.0f;
 }
 
+// Two-level bytes -> mapped sample values, zero beyond the end of the vector.  Element q of the thread
+// is sample n_base + LT*N2*q.  The zero-padding test is skipped for the leading QF values of q when the
+// whole block (columns < col_end, all LT row phases) is inside the vector there -- a block-uniform
+// condition, so the three variants are selected by scalar branches.
+template <int LT, int QF>
+FFS_DEV void map_bytes_from(const unsigned (&b)[16], float v0, float v1, int len, int n_base, int N2, float (&out)[16]) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float x = b[q] ? v1 : v0;
+        out[q] = (q < QF || n_base + LT * N2 * q < len) ? x : 0.0f;
+    }
+}
+template <int LT>
+FFS_DEV void map_bytes(const unsigned (&b)[16], float v0, float v1, int len, int n_base, int N2, int col_end,
+                       float (&out)[16]) {
+    const int rows_full = (len >= col_end) ? (len - col_end) / N2 + 1 : 0;  // rows r with r*N2 + col_end - 1 < len
+    const int q_full = rows_full / LT;                                      // q with every row u + LT*q inside
+    if (q_full >= 12)
+        map_bytes_from<LT, 12>(b, v0, v1, len, n_base, N2, out);
+    else if (q_full >= 6)
+        map_bytes_from<LT, 6>(b, v0, v1, len, n_base, N2, out);
+    else
+        map_bytes_from<LT, 0>(b, v0, v1, len, n_base, N2, out);
+}
+
 // value of `x` in the neighbour lane (lane ^ 1): one DPP move, quad_perm [1,0,3,2]
 FFS_DEV float from_neighbour(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
@@ -176,6 +201,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // every table value this thread needs is requested up front, together with the inputs
     TwRegs<CS::LI> twr;
     twr.load(tw, CS::R3 ? u / 3 : u);
+    cf* s_tw3 = lds + L * C;  // block copy of W_L^k for the radix-3 combine (behind the column tile)
+    if constexpr (CS::R3) {
+        for (int i = threadIdx.x; i < L; i += LT * C) s_tw3[i] = tw3[i];
+        __syncthreads();
+    }
     // W_N^(n2*k1), k1 = ob + OSTEP*q (ob = out_base(u)):  tb[u][n2] * g^q with g = W_N^(n2*OSTEP) (the
     // host lays the tables out per column shape).  Only g, g^2, g^4, g^8 are
     // fetched (ts rows 1, 2, 4, 8); the other powers are built with at most three multiplications
@@ -226,13 +256,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(ba[q]), "+v"(bb[q]));
+        float xa[16], xb[16];
+        map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, xa);
+        map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, xb);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int n = (u + LT * q) * N2 + n2;
-            const float xa = ba[q] ? d.a1 : d.a0, xb = bb[q] ? d.b1 : d.b0;
-            v[q].x = (n < d.len_a) ? xa : 0.0f;
-            v[q].y = (n < d.len_b) ? xb : 0.0f;
-        }
+        for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -241,7 +269,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
         }
     }
-    col_fft<L, C>(v, lds, u, c, twr, tw3);
+    col_fft<L, C>(v, lds, u, c, twr, s_tw3);
     // v[q] = Y[k1 = ob + OSTEP*q][n2]
     const int ob = CS::out_base(u);
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
@@ -653,7 +681,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     cf v[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
-    col_fft<L, C>(v, lds, u, c, twr, tw3);
+    cf* s_tw3 = lds + L * C;
+    if constexpr (CS::R3) {
+        for (int i = tid; i < L; i += NT) s_tw3[i] = tw3[i];
+        __syncthreads();
+    }
+    col_fft<L, C>(v, lds, u, c, twr, s_tw3);
     // v[q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = ob + OSTEP*q
     const int m1 = tile * C + c;
     const int ob = CS::out_base(u);

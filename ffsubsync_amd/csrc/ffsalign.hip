@@ -62,6 +62,7 @@ int tile_cols(int L) {
 
 size_t col_lds_bytes(int L) {
     size_t t = (L > 16) ? (size_t)L * tile_cols(L) * sizeof(cf) : 0;
+    if (L % 3 == 0) t += (size_t)L * sizeof(cf);  // W_L^k for the radix-3 combine
     return t < 1024 ? 1024 : t;
 }
 size_t row_lds_bytes(int L) {

@@ -113,6 +113,10 @@ def test_three_times_power_of_two_plans_give_identical_records(torch, monkeypatc
             assert np.array_equal(a[1], other[1])
         for p, sp in enumerate(group):
             assert a[1][p]["best_cand"] == sp.true_ratio_index
+        # the fp32 chain itself is healthy (exact re-evaluation would hide a damaged transform as long as
+        # the true peak is still nominated): fp32 value at the winning lag vs the exact score
+        for res in (a, b, c, e):
+            assert np.abs(res[0]["score_f32"].astype(np.float64) - res[0]["score"]).max() < 0.5
 
 
 def test_raw_correlation_f32_single_candidate(torch):
