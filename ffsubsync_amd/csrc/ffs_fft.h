@@ -398,6 +398,32 @@ struct ColShape {
 
 #define FFS_SQRT3_HALF 0.86602540378443864676f
 
+// First half of a length-3*LI column transform: the three sub-transforms, twiddled, left in LDS as
+// F'[g][k'][c] = W_L^(g k') F_g[k'] at lds[(g*LI + k')*C + c] (followed by a barrier).
+template <int L, int C>
+FFS_DEV void col_fft3_front(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
+                            const cf* __restrict__ tw3) {
+    constexpr int LI = ColShape<L>::LI, LTI = ColShape<L>::LTI;
+    const int u = u12 / 3, g = u12 % 3;
+    ColAddr<LI, C> addr(u, c);
+    fft_regs<LI>(v, lds + g * (LI * C), u, addr, twr);
+    // W_L^(g k') from the block's LDS copy of the table (a global load issued up front would pin
+    // sixteen register pairs across the whole sub-transform)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], tw3[g * (u + LTI * q)]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) lds[(g * LI + u + LTI * q) * C + c] = v[q];
+    __syncthreads();
+}
+
+// X_r = a + W_3^r b + W_3^(2r) cc  with W_3 = -1/2 - i*sqrt(3)/2:  a + alpha*(b + cc) + beta*(-i)*(b - cc),
+// (alpha, beta) = (1, 0), (-1/2, sqrt3/2), (-1/2, -sqrt3/2) for r = 0, 1, 2
+FFS_DEV cf radix3_out(cf a, cf b, cf cc, float alpha, float beta) {
+    const cf t = cadd(b, cc), d = csub(b, cc);
+    return mk(a.x + alpha * t.x + beta * d.y, a.y + alpha * t.y - beta * d.x);
+}
+
 // Forward DFT of one column of a C-column tile.  In: v[q] = x[u12 + LT*q].  Out: v[q] =
 // X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L) in LDS, outside the L*C elements at `lds`; used only
 // for L = 3*LI.
@@ -411,27 +437,13 @@ FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape
     } else {
         constexpr int LI = CS::LI, LTI = CS::LTI;
         const int u = u12 / 3, g = u12 % 3;
-        ColAddr<LI, C> addr(u, c);
-        fft_regs<LI>(v, lds + g * (LI * C), u, addr, twr);
-        // W_L^(g k') from the block's LDS copy of the table (a global load issued up front would pin
-        // sixteen register pairs across the whole sub-transform)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], tw3[g * (u + LTI * q)]);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 16; ++q) lds[(g * LI + u + LTI * q) * C + c] = v[q];
-        __syncthreads();
-        // W_3 = -1/2 - i*sqrt(3)/2:  X_r = a + alpha*(b + cc) + beta*(-i)*(b - cc),
-        // (alpha, beta) = (1, 0), (-1/2, sqrt3/2), (-1/2, -sqrt3/2) for r = 0, 1, 2
+        col_fft3_front<L, C>(v, lds, u12, c, twr, tw3);
         const float alpha = (g == 0) ? 1.0f : -0.5f;
         const float beta = (g == 0) ? 0.0f : (g == 1 ? FFS_SQRT3_HALF : -FFS_SQRT3_HALF);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int k = (u + LTI * q) * C + c;
-            const cf a = lds[k], b = lds[LI * C + k], cc = lds[2 * LI * C + k];
-            const cf t = cadd(b, cc), d = csub(b, cc);
-            v[q].x = a.x + alpha * t.x + beta * d.y;
-            v[q].y = a.y + alpha * t.y - beta * d.x;
+            v[q] = radix3_out(lds[k], lds[LI * C + k], lds[2 * LI * C + k], alpha, beta);
         }
     }
 }

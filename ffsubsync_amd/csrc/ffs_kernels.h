@@ -211,11 +211,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // fetched (ts rows 1, 2, 4, 8); the other powers are built with at most three multiplications
     // each, which trades eleven table loads per thread for eleven packed complex multiplies.
     cf wq[16];
-    wq[0] = tb[u * N2 + n2];
-    wq[1] = ts[1 * N2 + n2];
-    wq[2] = ts[2 * N2 + n2];
-    wq[4] = ts[4 * N2 + n2];
-    wq[8] = ts[8 * N2 + n2];
+    if constexpr (!CS::R3) {
+        wq[0] = tb[u * N2 + n2];
+        wq[1] = ts[1 * N2 + n2];
+        wq[2] = ts[2 * N2 + n2];
+        wq[4] = ts[4 * N2 + n2];
+        wq[8] = ts[8 * N2 + n2];
+    }
     cf v[16];
     if constexpr (DT == 0 && (C == 16 || C == 32 || C == 64)) {
         // Byte inputs: the 64 sixteen-byte pieces a wave needs per candidate (64/C rows x C/16 pieces
@@ -269,25 +271,70 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
         }
     }
-    col_fft<L, C>(v, lds, u, c, twr, s_tw3);
-    // v[q] = Y[k1 = ob + OSTEP*q][n2]
-    const int ob = CS::out_base(u);
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
-    wq[3] = cmul(wq[1], wq[2]);
-    wq[5] = cmul(wq[4], wq[1]);
-    wq[6] = cmul(wq[4], wq[2]);
-    wq[7] = cmul(wq[4], wq[3]);
-    wq[9] = cmul(wq[8], wq[1]);
-    wq[10] = cmul(wq[8], wq[2]);
-    wq[11] = cmul(wq[8], wq[3]);
-    wq[12] = cmul(wq[8], wq[4]);
-    wq[13] = cmul(wq[8], wq[5]);
-    wq[14] = cmul(wq[8], wq[6]);
-    wq[15] = cmul(wq[8], wq[7]);
+    if constexpr (CS::R3) {
+        // Radix-3 columns: the last step (the combine) reads its inputs from LDS anyway, so the outputs
+        // are re-dealt for the store: thread (cp, rg) produces the rows k1 = kg + 2*LTI*j + LI*r (j < 8;
+        // rg = r*2*LTI + kg) of the column pair (2cp, 2cp+1) -- eight 16-byte stores with no lane
+        // exchange, 16-byte LDS reads, and r is wave-uniform.
+        constexpr int LI = CS::LI, KG = 2 * CS::LTI;
+        static_assert(C % 2 == 0 && (C / 2) * KG % 64 == 0, "r must be wave-uniform");
+        col_fft3_front<L, C>(v, lds, u, c, twr, s_tw3);
+        const int cp = threadIdx.x % (C / 2), rg = threadIdx.x / (C / 2);
+        const int r = __builtin_amdgcn_readfirstlane(rg / KG), kg = rg % KG;
+        const float alpha = (r == 0) ? 1.0f : -0.5f;
+        const float beta = (r == 0) ? 0.0f : (r == 1 ? FFS_SQRT3_HALF : -FFS_SQRT3_HALF);
+        // W_N^(n2*k1) for both columns: h_j = tb[rg][n2] * g^j, g = W_N^(n2*KG) (ts rows 1, 2, 4)
+        const int n2p = tile * C + 2 * cp;
+        const float4 t0 = *reinterpret_cast<const float4*>(&tb[(size_t)rg * N2 + n2p]);
+        const float4 t1 = *reinterpret_cast<const float4*>(&ts[(size_t)1 * N2 + n2p]);
+        const float4 t2 = *reinterpret_cast<const float4*>(&ts[(size_t)2 * N2 + n2p]);
+        const float4 t4 = *reinterpret_cast<const float4*>(&ts[(size_t)4 * N2 + n2p]);
+        cf h[2][8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], (q == 0) ? wq[0] : cmul(wq[0], wq[q]));
+        for (int e = 0; e < 2; ++e) {
+            const cf g1 = e ? mk(t1.z, t1.w) : mk(t1.x, t1.y), g2 = e ? mk(t2.z, t2.w) : mk(t2.x, t2.y);
+            const cf g4 = e ? mk(t4.z, t4.w) : mk(t4.x, t4.y);
+            h[e][0] = e ? mk(t0.z, t0.w) : mk(t0.x, t0.y);
+            h[e][1] = cmul(h[e][0], g1);
+            h[e][2] = cmul(h[e][0], g2);
+            h[e][3] = cmul(h[e][1], g2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[e][4 + j] = cmul(h[e][j], g4);
+        }
+        const float4* l4 = reinterpret_cast<const float4*>(lds);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ((kg + KG * j) * C + 2 * cp) / 2;  // float4 index of F'[0][k'][2cp]
+            const float4 a = l4[k], b = l4[k + LI * C / 2], cc = l4[k + LI * C];
+            const cf x0 = cmul(radix3_out(mk(a.x, a.y), mk(b.x, b.y), mk(cc.x, cc.y), alpha, beta), h[0][j]);
+            const cf x1 = cmul(radix3_out(mk(a.z, a.w), mk(b.z, b.w), mk(cc.z, cc.w), alpha, beta), h[1][j]);
+            const int k1 = kg + KG * j + LI * r;
+            *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, 2 * cp, log2CL) + ((size_t)k1 << log2CL)]) =
+                make_float4(x0.x, x0.y, x1.x, x1.y);
+        }
+        return;
+    }
+    col_fft<L, C>(v, lds, u, c, twr, s_tw3);
+    // v[q] = Y[k1 = u + LT*q][n2];  twiddle W_N^(n2*k1) = h_q = wq[0] * g^q, built as h_(q-b) * g^b
+    const int ob = CS::out_base(u);
+    wq[3] = cmul(wq[0], wq[1]);   // h_1
+    wq[5] = cmul(wq[0], wq[2]);   // h_2
+    wq[6] = cmul(wq[3], wq[2]);   // h_3
+    wq[7] = cmul(wq[0], wq[4]);   // h_4
+    wq[9] = cmul(wq[3], wq[4]);   // h_5
+    wq[10] = cmul(wq[5], wq[4]);  // h_6
+    wq[11] = cmul(wq[6], wq[4]);  // h_7
+    {
+        const cf h[8] = {wq[0], wq[3], wq[5], wq[6], wq[7], wq[9], wq[10], wq[11]};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[q] = cmul(v[q], h[q]);
+            v[q + 8] = cmul(v[q + 8], cmul(h[q], wq[8]));
+        }
+    }
     if constexpr (C >= 2) {
         // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
         // the even-c lane writes rows q = 0,2,.. of columns (c, c+1), the odd-c lane rows q = 1,3,..

@@ -587,11 +587,13 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     if ((rc = upload(&p->tw1, make_stage_tables(LI1), &p->workspace_bytes))) return rc;
     if ((rc = upload(&p->tw2, make_stage_tables(N2), &p->workspace_bytes))) return rc;
     {
-        std::vector<cf> tb((size_t)LT1 * N2), ts((size_t)16 * N2);
-        // thread u of a column ends up with the outputs k1 = out_base(u) + ostep*q (ColShape in ffs_fft.h)
-        const int ostep = LI1 / 16;
-        for (int u = 0; u < LT1; ++u) {
-            const int ob = r3 ? (u / 3) + LI1 * (u % 3) : u;
+        // Power-of-two columns: thread u holds the outputs k1 = u + LT1*q.  3*2^k columns (k_pass_a's
+        // radix-3 branch): store thread rg = r*KG + kg holds k1 = kg + LI*r + KG*j, KG = 2*(LI/16).
+        const int KG = 2 * (LI1 / 16);
+        const int nb = r3 ? 3 * KG : LT1, ostep = r3 ? KG : LT1;
+        std::vector<cf> tb((size_t)nb * N2), ts((size_t)16 * N2);
+        for (int u = 0; u < nb; ++u) {
+            const int ob = r3 ? (u % KG) + LI1 * (u / KG) : u;
             for (int n2 = 0; n2 < N2; ++n2) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * ob);
         }
         for (int q = 0; q < 16; ++q)
