@@ -115,6 +115,7 @@ struct ffs_plan {
     int N1 = 0, N2 = 0, C = 0, log2C = 0;
     int log2CL = 0;  // tile layout T[x/CL][k1][x%CL]: CL = max(C, 64) columns (512-byte row chunks)
     int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
+    int pass_a_prefetch = 3;  // grid rows the input prefetch blocks of pass A run ahead (FFS_PASS_A_PREFETCH, 0 = off)
     bool direct_only = false;
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
     bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
@@ -212,9 +213,14 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     const size_t lds = col_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
-    dim3 grid(p->N2 / C, n_xf);
+    const int nt = p->N2 / C;
+    // byte inputs: one prefetch block per 128-column line group and grid row (see the kernel)
+    const int groups = p->N2 / 128;
+    const int pf = (DT == 0 && p->pass_a_prefetch > 0 && nt % 8 == 0 && groups % 8 == 0) ? groups : 0;
+    dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair);
+                       p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, p->pass_a_prefetch,
+                       (unsigned*)p->bnom);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -558,6 +564,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_pruned = !(e && e[0] == '1');
         // measured neutral (pass A -2.0 us/pair, mid +2.0 us/pair: the second row of every pair re-reads
         // and re-transforms the last slot's rows), so the simpler separate-reference layout is the default
+        const char* e3 = getenv("FFS_PASS_A_PREFETCH");
+        if (e3) p->pass_a_prefetch = atoi(e3);
         const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
         p->allow_packed_ref = (e2 && e2[0] == '1');
     }
