@@ -788,6 +788,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
 // handful of multiply-adds per element, no LDS exchange of the data.  Used when the union of bins
 // over the call's candidates has at most MAXBINS entries; otherwise k_pass_c runs.
 constexpr int MAXBINS = 8;
+// W_16^e = exp(-2*pi*i*e/16), (re, im) pairs
+static __constant__ float c_w16[32] = {
+    1.0f, -0.0f, FFS_COS_PI_8, -FFS_SIN_PI_8, FFS_SQRT_HALF, -FFS_SQRT_HALF, FFS_SIN_PI_8, -FFS_COS_PI_8,
+    0.0f, -1.0f, -FFS_SIN_PI_8, -FFS_COS_PI_8, -FFS_SQRT_HALF, -FFS_SQRT_HALF, -FFS_COS_PI_8, -FFS_SIN_PI_8,
+    -1.0f, 0.0f, -FFS_COS_PI_8, FFS_SIN_PI_8, -FFS_SQRT_HALF, FFS_SQRT_HALF, -FFS_SIN_PI_8, FFS_COS_PI_8,
+    0.0f, 1.0f, FFS_SIN_PI_8, FFS_COS_PI_8, FFS_SQRT_HALF, FFS_SQRT_HALF, FFS_COS_PI_8, FFS_SIN_PI_8};
 struct BinList {
     int n;
     int b[MAXBINS];  // signed bin offsets (m2 or m2 - N1)
@@ -806,8 +812,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
     constexpr int NW = NT / 64;
-    constexpr int UPW = (C < 64) ? (64 / C) : 1;  // distinct u per wave
-    constexpr int NG = LT / UPW;                   // partial sums per (bin, column)
+    constexpr int NG = LT;                         // partial sums per (bin, column): one per thread row u
     cf* s_tw = reinterpret_cast<cf*>(smem + 1024);                     // [L]   W_L^k
     cf* s_part = reinterpret_cast<cf*>(smem + 1024 + L * sizeof(cf));  // [MAXBINS][NG][C]
     const int tid = threadIdx.x;
@@ -828,26 +833,18 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
     for (int i = tid; i < L; i += NT) s_tw[i] = twn1[i];
     __syncthreads();
-    const int lane = tid % 64;
+    // W_L^(b*(u + LT*q)) = W_L^(b*u) * W_16^(b*q)  (L = 16*LT): the second factor is the same for the
+    // whole block, so the sum over q runs on scalar constants (two packed FMAs per term) and the
+    // per-thread factor is applied once per bin.
     for (int i = 0; i < bins.n; ++i) {
         const unsigned b = (unsigned)(bins.b[i] + L) % L;
         cf a = mk(0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const cf w = s_tw[((unsigned)(u + LT * q) * b) % L];
-            a.x = fmaf(v[q].x, w.x, fmaf(-v[q].y, w.y, a.x));
-            a.y = fmaf(v[q].x, w.y, fmaf(v[q].y, w.x, a.y));
+            const unsigned e = (b * q) & 15u;
+            a = cmac_k(a, v[q], c_w16[2 * e], c_w16[2 * e + 1]);
         }
-        if constexpr (C < 64) {
-#pragma unroll
-            for (int sft = C; sft < 64; sft <<= 1) {  // lanes with equal c hold different u
-                a.x += __shfl_xor(a.x, sft, 64);
-                a.y += __shfl_xor(a.y, sft, 64);
-            }
-            if (lane < C) s_part[(i * NG + u / UPW) * C + c] = a;
-        } else {
-            s_part[(i * NG + u) * C + c] = a;
-        }
+        s_part[(i * NG + u) * C + c] = cmul(a, s_tw[((unsigned)u * b) % L]);
     }
     __syncthreads();
     // thread t finishes (bin, column) pairs t, t + NT, ...  (more than one only when LT < MAXBINS)

@@ -336,8 +336,7 @@ int launch_pass_c(const ffs_plan* p, const CandDesc* cands, int first_cand, int 
 
 size_t pruned_lds_bytes(int L) {
     const int C = tile_cols(L), LT = L / 16;
-    const int upw = C < 64 ? 64 / C : 1;
-    return 1024 + (size_t)L * sizeof(cf) + (size_t)MAXBINS * (LT / upw) * C * sizeof(cf);
+    return 1024 + (size_t)L * sizeof(cf) + (size_t)MAXBINS * LT * C * sizeof(cf);
 }
 
 template <int L, int C, bool EXH>
