@@ -699,14 +699,19 @@ FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int n
     }
 }
 
-// Which of a transform's two candidates need the exhaustive pass (nominee overflow, flag 2)?
+// Flagged candidates (nominee overflow, flag 2) of a sub-batch, appended by k_nominees: xlist[0] = count,
+// xlist[1 + e] = local candidate index.  The exhaustive instantiations of the last pass walk this list
+// (grid.y = a few rows, entry e handled by row e % gridDim.y) instead of launching one block per
+// transform and tile that would nearly always exit at once.
+//
+// Does the listed half of transform kp need the exhaustive pass?
 FFS_DEV bool exhaustive_wanted(const NomList* __restrict__ noms, const CandDesc* __restrict__ cands, int cand0, int kp,
-                               int n_cand, int (&ci)[2], bool (&want)[2], float (&thr)[2]) {
+                               int n_cand, int only_half, int (&ci)[2], bool (&want)[2], float (&thr)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const bool present = (2 * kp + h) < n_cand;
         ci[h] = cand0 + (present ? 2 * kp + h : 0);
-        want[h] = present && (noms[ci[h]].flags & 2) != 0;
+        want[h] = present && h == only_half && (noms[ci[h]].flags & 2) != 0;
         thr[h] = want[h] ? noms[ci[h]].gmax - eff_margin(cands[ci[h]].margin, noms[ci[h]].gmax) : INFINITY;
     }
     return want[0] || want[1];
@@ -725,7 +730,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
                                                          BlockNom* __restrict__ bnom, float* __restrict__ out_a,
                                                          float* __restrict__ out_b, const NomList* __restrict__ noms,
                                                          PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries,
-                                                         int log2CL, const cf* __restrict__ tw3) {
+                                                         int log2CL, const cf* __restrict__ tw3,
+                                                         const int* __restrict__ xlist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -736,13 +742,21 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     const int c = tid % C;
     const int u = tid / C;
     const int tile = blockIdx.x;
-    const int ly = blockIdx.y;
+    for (int e = (MODE == 2) ? (int)blockIdx.y : 0;; e += gridDim.y) {
+    int ly = blockIdx.y, only_half = -1;
+    if (MODE == 2) {
+        if (e >= xlist[0]) return;
+        const int lc = xlist[1 + e];
+        ly = (lc / n_cand) * n_packed + (lc % n_cand) / 2;
+        only_half = (lc % n_cand) & 1;
+        __syncthreads();  // the previous entry's LDS traffic is over
+    }
     const int lp = ly / n_packed, kp = ly % n_packed;
     int xci[2];
     bool xwant[2];
     float xthr[2];
     if (MODE == 2) {
-        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
+        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, only_half, xci, xwant, xthr)) continue;
     }
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     typedef ColShape<L> CS;
@@ -773,11 +787,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     if (MODE == 2) {
         block_collect_all<16>(
             v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, xci, xwant, xthr, pool, entries);
-        return;
+        continue;
     }
     block_nominees<16, NW>(
         v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, smem, tid,
         &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
+    return;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -807,7 +823,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                                                                 BlockNom* __restrict__ bnom, BinList bins,
                                                                 const NomList* __restrict__ noms,
                                                                 PoolHeader* __restrict__ pool,
-                                                                PoolEntry* __restrict__ entries, int log2CL) {
+                                                                PoolEntry* __restrict__ entries, int log2CL,
+                                                                const int* __restrict__ xlist) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -819,13 +836,21 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     const int c = tid % C;
     const int u = tid / C;
     const int tile = blockIdx.x;
-    const int ly = blockIdx.y;
+    for (int e = EXH ? (int)blockIdx.y : 0;; e += gridDim.y) {
+    int ly = blockIdx.y, only_half = -1;
+    if (EXH) {
+        if (e >= xlist[0]) return;
+        const int lc = xlist[1 + e];
+        ly = (lc / n_cand) * n_packed + (lc % n_cand) / 2;
+        only_half = (lc % n_cand) & 1;
+        __syncthreads();  // the previous entry's LDS traffic is over
+    }
     const int lp = ly / n_packed, kp = ly % n_packed;
     int xci[2];
     bool xwant[2];
     float xthr[2];
     if (EXH) {
-        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, xci, xwant, xthr)) return;
+        if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, only_half, xci, xwant, xthr)) continue;
     }
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     cf v[16];
@@ -871,11 +896,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     if (EXH) {
         block_collect_all<NVF>(
             val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries);
-        return;
+        continue;
     }
     block_nominees<NVF, NW>(
         val, [&](int j) { return mm[j]; }, wp, (int)N, smem, tid, &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile],
         &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
+    return;
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -883,7 +910,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
 // block-nominee row (local transform, half) = (lx, h) given by cand_xf[ci - first_cand].
 __global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bnom, int tiles, int n_cand,
                                                  int n_packed, const CandDesc* __restrict__ cands,
-                                                 NomList* __restrict__ noms, int first_cand) {
+                                                 NomList* __restrict__ noms, int first_cand,
+                                                 int* __restrict__ xlist) {
     const int ci = first_cand + blockIdx.x;
     const int lp = blockIdx.x / n_cand, jc = blockIdx.x % n_cand;
     const int row = (lp * n_packed + jc / 2) * 2 + (jc & 1);
@@ -934,6 +962,7 @@ __global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bn
         nl.count = s_count < KNOM ? s_count : KNOM;
         nl.flags = s_flags;
         nl.gmax = g;
+        if (s_flags & 2) xlist[1 + atomicAdd(&xlist[0], 1)] = blockIdx.x;  // exhaustive sweep wanted
     }
 }
 

@@ -40,6 +40,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
 constexpr unsigned kPoolCapacity = 1u << 20;
+constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
 int ilog2(int64_t x) {
     int p = 0;
@@ -127,6 +128,7 @@ struct ffs_plan {
     cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
     BlockNom* bnom = nullptr;                 // [pairs_in_flight*n_packed*2][tiles]
     PoolEntry* pool_entries = nullptr;        // [kPoolCapacity] exhaustive fallback for flagged candidates
+    int* xlist = nullptr;                     // [1 + pairs_in_flight*max_cand] flagged candidates of the sub-batch
     // per-call descriptor storage (grown on demand)
     void* dev_desc = nullptr;
     size_t dev_desc_bytes = 0;
@@ -301,10 +303,10 @@ int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand,
     const size_t lds = col_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_c<L, C, MODE>, lds))) return rc_lds;
-    dim3 grid(p->N2 / C, n_pairs * n_packed);
+    dim3 grid(p->N2 / C, MODE == 2 ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
                        cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->twn1);
+                       p->twn1, p->xlist);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -345,9 +347,10 @@ int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int firs
     const size_t lds = pruned_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_c_pruned<L, C, EXH>, lds))) return rc_lds;
-    dim3 grid(p->N2 / C, n_pairs * n_packed);
+    dim3 grid(p->N2 / C, EXH ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
-                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL);
+                       p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL,
+                       p->xlist);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -628,6 +631,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     const size_t bn_bytes = (size_t)pairs_in_flight * (p->max_slots - 1) * 2 * (N2 / p->C) * sizeof(BlockNom);
     HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
     p->workspace_bytes += (int64_t)bn_bytes;
+    HIP_TRY(hipMalloc((void**)&p->xlist, (1 + (size_t)pairs_in_flight * max_cand) * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
     p->workspace_bytes += (int64_t)kPoolCapacity * sizeof(PoolEntry);
     guard.p = nullptr;
@@ -649,6 +653,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->work);
     (void)hipFree(p->bnom);
     (void)hipFree(p->pool_entries);
+    (void)hipFree(p->xlist);
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -789,14 +794,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                             : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
             }
             if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(p->xlist, 0, sizeof(int), st));
             {
                 ProfSpan sp(p, st, FFS_K_NOMINEES);
                 hipLaunchKernelGGL(k_nominees, dim3(np * n_cand), dim3(64), 0, st, p->bnom, tiles, n_cand, n_packed, dc,
-                                   dn, first_cand);
+                                   dn, first_cand, p->xlist);
             }
             HIP_TRY(hipGetLastError());
-            // candidates whose nominee lists overflowed: sweep their transforms again, exhaustively
-            // (blocks of unflagged transforms exit at once)
+            // candidates whose nominee lists overflowed (listed by k_nominees): sweep their transforms again,
+            // exhaustively; with an empty list the few blocks of this launch exit at once
             rc = pruned ? launch_pass_c_pruned<true>(p, dc, first_cand, n_cand, n_packed, slot_map, np, bins, pa, st)
                         : launch_pass_c<2>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
             if (rc) return rc;

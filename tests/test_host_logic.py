@@ -194,3 +194,43 @@ def test_install_swaps_the_classes_the_caller_binds(monkeypatch):
     c0 = golden_cases.build_cases(include_large=False)["mask_all"]
     with pytest.raises(RefFailed, match="Synchronization failed"):
         MaxScoreAligner(OracleBackedAligner, None, 100, 0).fit_transform(c0["ref"], list(c0["cands"]))
+
+
+def test_plan_length_is_alias_free_for_the_window():
+    """ffs_plan_length's claim, checked in numpy: a circular correlation of that length over the
+    prefixes that can reach the lag window reproduces the reference's masked `convolve` values at
+    every lag of the window (aligners.py:31-43, 67-74)."""
+    from ffsubsync_amd import _native
+    from oracle import aligners_oracle as orc
+
+    rng = np.random.RandomState(5)
+    seen_r3 = seen_short = 0
+    for trial in range(60):
+        R = int(rng.randint(30, 9000))
+        S = int(max(10, R * rng.uniform(0.3, 1.7)))
+        mo = int(rng.choice([0, 7, 100, 600, 6000, 3 * R]))
+        ref = (rng.rand(R) < 0.4).astype(float)
+        sub = (rng.rand(S) < 0.4).astype(float) * 0.97
+        conv, _ = orc.convolve_full(ref, sub)
+        masked = orc.mask_extreme_offsets(conv, S, mo)
+        n_ref = len(conv)
+        n = _native.plan_length(R, S, mo)
+        ks = np.flatnonzero(np.isfinite(masked))
+        if ks.size == 0:
+            assert n == 2
+            continue
+        seen_r3 += n % 3 == 0
+        seen_short += n < n_ref
+        d = n_ref - 1 - S - ks  # lag of every surviving k
+        d_lo, d_hi = int(d.min()), int(d.max())
+        s_eff = max(1, min(S, R - d_lo))  # samples that meet the other vector at some lag of the window
+        r_eff = max(1, min(R, S + d_hi))
+        assert n >= max(s_eff + d_hi, r_eff - d_lo)
+        a = np.zeros(n)
+        a[:s_eff] = 2.0 * sub[:s_eff] - 1.0
+        b = np.zeros(n)
+        b[:r_eff] = 2.0 * ref[:r_eff] - 1.0
+        circ = np.real(np.fft.ifft(np.conj(np.fft.fft(a)) * np.fft.fft(b)))  # circ[m] = sum_i a[i] b[(i+m) % n]
+        got = circ[np.where(d >= 0, d, d + n)]
+        assert np.abs(got - masked[ks]).max() < 1e-6 * max(1.0, np.abs(masked[ks]).max()), (trial, R, S, mo, n)
+    assert seen_short > 10 and seen_r3 > 0
