@@ -321,7 +321,8 @@ def main():
             "executed_frac": per_kernel[dom]["executed_GBps"] / (HBM_PEAK / 1e9),
             "note": "achieved = SURVEY 8(d) share of the reference's 168*N(=2^21) bytes per solve / launch time; "
                     "the device moves fewer bytes (packed candidates, reference spectrum kept in registers, "
-                    "window-shortened N): executed_* uses the bytes this kernel really has to move",
+                    "transform length 3*2^18 instead of 2^21 under the lag window): executed_* uses the bytes this "
+                    "kernel really has to move, traffic = PMC-measured HBM bytes per launch",
         }
 
     if rank == 0 and world == 1 and not args.full_length and not args.skip_full_length_record and n_dev != n_ref:
