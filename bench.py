@@ -341,6 +341,30 @@ def main():
             result["full_length"]["kernels"] = {k: {kk: v[kk] for kk in ("avg_ms", "achieved_GBps", "executed_GBps") if kk in v}
                                                for k, v in kernel_table(kt2, st2, n_ref).items()}
 
+    if rank == 0 and world == 1 and not args.skip_full_length_record:
+        # single-ratio FFTAligner solves/s (BASELINE config 2 as a batch: every pair against
+        # the candidate rasterised at its true ratio), with the production lag window and without one
+        sdb = db.select_candidates([sp.true_ratio_index for sp in specs])
+        single = {}
+        for label, mo in (("max_offset_6000", 6000), ("max_offset_none", None)):
+            al = batch.BatchAligner(sdb.required_fft_length(mo), 1, max_offset_samples=mo, pairs_in_flight=args.pairs_in_flight)
+            al.solve_async(sdb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                c1, p1 = al.solve_async(sdb)
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / 3
+            c1 = c1.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:P]
+            single[label] = {
+                "n_fft_device": int(al.plan.n_fft),
+                "solves_per_s": P / el,
+                "offsets_within_0.3s_of_truth": int(sum(abs(int(c1[i]["offset"]) - sp.true_offset_samples) <= 30
+                                                        for i, sp in enumerate(specs))),
+            }
+            al.plan.close()
+        result["single_ratio"] = single
+
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         from oracle import aligners_oracle as orc
 

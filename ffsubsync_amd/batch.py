@@ -33,6 +33,14 @@ class DeviceBatch:
     def n_cand(self) -> int:
         return self.offs.shape[1] - 1
 
+    def select_candidates(self, index: Sequence[int]) -> "DeviceBatch":
+        """View with one candidate per pair (``index[p]`` of pair p's candidates), sharing ``data``:
+        the single-ratio FFTAligner problem of every pair."""
+        rows = np.arange(self.n_pairs)
+        cols = 1 + np.asarray(index, dtype=np.int64)
+        pick = lambda a: np.ascontiguousarray(np.stack([a[:, 0], a[rows, cols]], axis=1))
+        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi))
+
     def required_fft_length(self, max_offset_samples: Optional[int] = None) -> int:
         """Plan length for the whole batch: the reference's N = 2^ceil(log2(R+S)) without a lag window,
         the alias-free (possibly shorter) length with one (``_native.plan_length``)."""

@@ -185,7 +185,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
                                                          const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
                                                          int slots_per_pair, int nt, int pf_ahead,
-                                                         unsigned* __restrict__ pf_sink) {
+                                                         unsigned* __restrict__ pf_sink, int ref_half) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     typedef ColShape<L> CS;
@@ -297,6 +297,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+    // ref_half: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
+    // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all
+    const int k1_end = (ref_half && blockIdx.y % xf_per_pair == 0) ? L / 2 + 1 : L;
     if constexpr (CS::R3) {
         // Radix-3 columns: the last step (the combine) reads its inputs from LDS anyway, so the outputs
         // are re-dealt for the store: thread (cp, rg) produces the rows k1 = kg + 2*LTI*j + LI*r (j < 8;
@@ -335,8 +338,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             const cf x0 = cmul(radix3_out(mk(a.x, a.y), mk(b.x, b.y), mk(cc.x, cc.y), alpha, beta), h[0][j]);
             const cf x1 = cmul(radix3_out(mk(a.z, a.w), mk(b.z, b.w), mk(cc.z, cc.w), alpha, beta), h[1][j]);
             const int k1 = kg + KG * j + LI * r;
-            *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, 2 * cp, log2CL) + ((size_t)k1 << log2CL)]) =
-                make_float4(x0.x, x0.y, x1.x, x1.y);
+            if (k1 < k1_end)
+                *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, 2 * cp, log2CL) + ((size_t)k1 << log2CL)]) =
+                    make_float4(x0.x, x0.y, x1.x, x1.y);
         }
         return;
     }
@@ -377,12 +381,23 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             pk.z = odd ? o.x : nex;
             pk.w = odd ? o.y : ney;
             const int k1 = ob + CS::OSTEP * (2 * j + (odd ? 1 : 0));
-            *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, c & ~1, log2CL) + ((size_t)k1 << log2CL)]) = pk;
+            if (k1 < k1_end)
+                *reinterpret_cast<float4*>(&out[tile_base<L, C>(tile, c & ~1, log2CL) + ((size_t)k1 << log2CL)]) = pk;
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];
+        for (int q = 0; q < 16; ++q)
+            if (ob + CS::OSTEP * q < k1_end) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];
     }
+}
+
+template <int L, int... Q>
+FFS_DEV void mirror_store(const cf (&v)[16], cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
+    ((lds[addr.template gather<Q>()] = v[Q]), ...);
+}
+template <int L, int... Q>
+FFS_DEV void mirror_load(cf (&v)[16], const cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
+    ((v[Q] = lds[addr.template gather_mirror<Q>()]), ...);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -393,7 +408,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 template <int L, bool SEP>
 __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                 float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
-                                                const cf* __restrict__ ts) {
+                                                const cf* __restrict__ ts, int ref_half) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -421,11 +436,30 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     TwRegs<L> twr;
     twr.load(tw, u);
     cf rr[16];
+    // ref_half (one row per block only): pass A stored the reference rows 0..N1/2; for k1 > N1/2,
+    // conj(R[k1][k2]) = R[N1-k1][N2-1-k2] (Hermitian spectrum of a real signal in the four-step index
+    // k = k1 + N1*k2), i.e. the transformed row N1-k1 read backwards -- one more exchange through LDS.
+    const bool mirrored = (L == 4096) && SEP && ref_half && k1 > N1 / 2;
+    if (mirrored) {
+        const unsigned offr = (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1)));
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rr[q] = at(base, q);
+        for (int q = 0; q < 16; ++q) rr[q] = (base + q * qstride)[offr];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rr[q] = at(base, q);
+    }
     fft_regs<L>(rr, lds, u, addr, twr);
+    if constexpr (L == 4096) {
+        if (mirrored) {
+            __syncthreads();
+            mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+            __syncthreads();
+            mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+        }
+    }
+    const float sgn = mirrored ? inv_n : -inv_n;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, -rr[q].y * inv_n);  // conj(R)/N
+    for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R)/N
 
     const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
     for (int s = 1; s < n_slots; ++s) {
@@ -443,15 +477,6 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
             at(buf, q) = cmul(v[q], w);
         }
     }
-}
-
-template <int L, int... Q>
-FFS_DEV void mirror_store(const cf (&v)[16], cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
-    ((lds[addr.template gather<Q>()] = v[Q]), ...);
-}
-template <int L, int... Q>
-FFS_DEV void mirror_load(cf (&v)[16], const cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
-    ((v[Q] = lds[addr.template gather_mirror<Q>()]), ...);
 }
 
 // --------------------------------------------------------------------------------------------

@@ -120,6 +120,7 @@ struct ffs_plan {
     bool direct_only = false;
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
     bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
+    bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
@@ -211,7 +212,7 @@ struct ProfSpan {
 // ---- kernel dispatch -------------------------------------------------------------------------
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
-                       hipStream_t st) {
+                       bool ref_half, hipStream_t st) {
     const size_t lds = col_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
@@ -222,49 +223,53 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
                        p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, p->pass_a_prefetch,
-                       (unsigned*)p->bnom);
+                       (unsigned*)p->bnom, ref_half ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 template <int DT>
-int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, hipStream_t st) {
+int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, bool ref_half,
+                  hipStream_t st) {
     switch (p->N1) {
-        case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 192: return launch_pass_a_inst<192, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 384: return launch_pass_a_inst<384, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 768: return launch_pass_a_inst<768, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
-        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, st);
+        case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 192: return launch_pass_a_inst<192, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 384: return launch_pass_a_inst<384, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 768: return launch_pass_a_inst<768, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
     }
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
 
 template <int L, bool SEP>
-int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
+int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipStream_t st) {
     const size_t lds = row_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_mid<L, SEP>, lds))) return rc_lds;
     constexpr int ROWS = 256 / (L / 16);
     dim3 grid(p->N1 / ROWS, n_pairs);
     hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2CL, (long long)p->N, n_slots,
-                       (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM);
+                       (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM, ref_half ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
-int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, hipStream_t st) {
+// the reference slot may hold only its rows 0..N1/2 (see k_mid) when one block handles one row
+bool ref_half_ok(const ffs_plan* p) { return p->allow_ref_half && p->N2 == 4096 && (p->N2 / 16) >= (1 << p->log2CL) && p->N1 % 2 == 0; }
+
+int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipStream_t st) {
     const bool sep = (p->N2 / 16) >= (1 << p->log2CL);
 #define FFS_MID(L) \
-    case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, st)
+    case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, ref_half, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, ref_half, st)
     switch (p->N2) {
         FFS_MID(256);
         FFS_MID(512);
@@ -566,6 +571,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_pruned = !(e && e[0] == '1');
         // measured neutral (pass A -2.0 us/pair, mid +2.0 us/pair: the second row of every pair re-reads
         // and re-transforms the last slot's rows), so the simpler separate-reference layout is the default
+        const char* e4 = getenv("FFS_DISABLE_REF_HALF");
+        p->allow_ref_half = !(e4 && e4[0] == '1');
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = atoi(e3);
         const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
@@ -687,6 +694,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const bool packed_ref = !p->direct_only && p->allow_packed_ref && (n_cand % 2 == 1) && p->N2 == 4096 && p->N1 % 3 != 0 &&
                             (p->N2 / 16) >= (1 << p->log2CL) && p->N1 >= 2;
     const int xf_per_pair = packed_ref ? n_packed : n_slots;
+    const bool ref_half = !packed_ref && !p->direct_only && ref_half_ok(p);
     const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
     const size_t n_cands = (size_t)n_pairs * n_cand;
     const size_t n_xf = (size_t)n_pairs * xf_per_pair;
@@ -778,14 +786,14 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
                 if (dtype == FFS_DTYPE_U8)
-                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, st);
+                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, ref_half, st);
                 else
-                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, st);
+                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, ref_half, st);
             }
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_MID);
-                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, st);
+                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, ref_half, st);
             }
             if (rc) return rc;
             {
@@ -850,11 +858,11 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     HIP_TRY(hipEventRecord(p->upload_done, st));
     const XformDesc* dx = (const XformDesc*)p->dev_desc;
     if (dtype == FFS_DTYPE_U8)
-        rc = launch_pass_a<0>(p, dx, 2, 2, 2, st);
+        rc = launch_pass_a<0>(p, dx, 2, 2, 2, ref_half_ok(p), st);
     else
-        rc = launch_pass_a<1>(p, dx, 2, 2, 2, st);
+        rc = launch_pass_a<1>(p, dx, 2, 2, 2, ref_half_ok(p), st);
     if (rc) return rc;
-    if ((rc = launch_mid(p, 1, 2, st))) return rc;
+    if ((rc = launch_mid(p, 1, 2, ref_half_ok(p), st))) return rc;
     const PoolArgs none{nullptr, nullptr, nullptr};
     return launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st);
 }

@@ -327,6 +327,25 @@ def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
         assert pruned[1][p]["best_cand"] == sp.true_ratio_index
 
 
+def test_reference_half_rows_equal_all_rows(torch, monkeypatch):
+    """The reference transform's rows k1 > N1/2 are rebuilt from the Hermitian mirror rows in the mid
+    pass instead of being stored; storing all rows must give the same records."""
+    from ffsubsync_amd import batch, synth
+
+    specs = [synth.make_pair_spec(700 + i, duration_s=d) for i, d in enumerate((7200.0, 5400.0, 2500.0))]
+    db = batch.build_device_batch(specs)
+    for mo in (6000, None):
+        n_fft = db.required_fft_length(mo)
+        half = batch.BatchAligner(n_fft, 7, max_offset_samples=mo, pairs_in_flight=2).solve(db)
+        monkeypatch.setenv("FFS_DISABLE_REF_HALF", "1")
+        full = batch.BatchAligner(n_fft, 7, max_offset_samples=mo, pairs_in_flight=2).solve(db)
+        monkeypatch.delenv("FFS_DISABLE_REF_HALF")
+        assert np.array_equal(half[0]["offset"], full[0]["offset"]) and np.array_equal(half[0]["score"], full[0]["score"])
+        assert np.array_equal(half[1], full[1])
+        assert np.abs(half[0]["score_f32"] - full[0]["score_f32"]).max() < 0.25
+        assert np.abs(half[0]["score_f32"].astype(np.float64) - half[0]["score"]).max() < 0.5
+
+
 def test_window_shortened_transform_equals_full_length(torch):
     """With a lag window the plan may use a transform shorter than the reference's N (no aliasing
     reaches the windowed lags, ffs_plan_length): every result record must equal the full-length one."""

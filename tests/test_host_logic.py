@@ -234,3 +234,16 @@ def test_plan_length_is_alias_free_for_the_window():
         got = circ[np.where(d >= 0, d, d + n)]
         assert np.abs(got - masked[ks]).max() < 1e-6 * max(1.0, np.abs(masked[ks]).max()), (trial, R, S, mo, n)
     assert seen_short > 10 and seen_r3 > 0
+
+
+def test_select_candidates_view():
+    from ffsubsync_amd.batch import DeviceBatch
+
+    offs = np.arange(12).reshape(3, 4) * 64
+    lens = offs + 5
+    lo, hi = np.zeros((3, 4)), np.arange(12).reshape(3, 4) / 10.0
+    db = DeviceBatch(None, offs, lens, lo, hi)
+    one = db.select_candidates([2, 0, 1])
+    assert one.n_pairs == 3 and one.n_cand == 1
+    assert one.offs.tolist() == [[0, 192], [256, 320], [512, 640]]
+    assert one.hi[:, 1].tolist() == [0.3, 0.5, 1.0] and one.lens[:, 0].tolist() == [5, 261, 517]
