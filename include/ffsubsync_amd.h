@@ -69,9 +69,11 @@ int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len);
 /* Smallest supported transform length (2^k, or 3*2^k in [12288, 3145728]) a plan needs for one
  * (reference, candidate) solve.
  * Without a lag window this is ffs_fft_length (the full linear correlation).  With
- * max_offset_samples >= 0 only lags inside the reference's window [d_lo, d_hi] are ever looked at,
- * and a circular correlation of any length n >= max(S + d_hi, R - d_lo) + 1 reproduces those lags
- * exactly (no aliasing reaches them), so a shorter transform gives bit-identical results:
+ * max_offset_samples >= 0 only lags inside the reference's window [d_lo, d_hi] are ever looked at:
+ * only the prefixes S' = min(S, R - d_lo) and R' = min(R, S + d_hi) of the two vectors can meet at
+ * such a lag (the rest is multiplied by zero padding), and a circular correlation of any length
+ * n >= max(S' + d_hi, R' - d_lo) + 1 over them reproduces those lags exactly (no product wraps), so
+ * a shorter transform gives bit-identical results:
  * 3*2^18 = 786 432 instead of 2^21 for 2 h @ 100 Hz inputs with the default +-6000 window.
  * (FFS_DISABLE_RADIX3=1 in the environment restricts the answer to powers of two.) */
 int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_samples);
