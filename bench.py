@@ -232,8 +232,9 @@ def main():
     # pass A = 14 halves, mid = 21, pass C = 7.
     share = {"pass_a": 56, "mid": 84, "pass_c": 28}
     # bytes the kernels actually have to move per pair at device length n:
-    # pass A writes 5 transforms, mid reads 5 + writes 4, pass C reads 4 (8n bytes each)
-    executed = {"pass_a": 5 * 8, "mid": 9 * 8, "pass_c": 4 * 8}
+    # pass A writes 4 candidate transforms + the lower half of the reference's rows, mid reads those
+    # 4.5 + writes 4, pass C reads 4 (8n bytes each)
+    executed = {"pass_a": 4.5 * 8, "mid": 8.5 * 8, "pass_c": 4 * 8}
 
     def kernel_table(ktimes, steps, n_fft):
         per_kernel = {}
