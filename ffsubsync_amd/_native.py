@@ -82,6 +82,13 @@ def load():
                 "or `make -C ffsubsync_amd/csrc` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback." % path
             )
+        # torch first: its wheel bundles a HIP runtime (libamdhip64) with the same SONAME the library links
+        # against.  Loaded in that order both share one runtime; the other way round the process ends
+        # up with two, and the second one finds no device ("no ROCm-capable device is detected").
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(path)
         c = ctypes
         lib.ffs_fft_length.restype = c.c_int64

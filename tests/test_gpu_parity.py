@@ -218,6 +218,30 @@ def test_gss_through_the_dropin(torch):
     assert score == pytest.approx(float(g["score"]), rel=SCORE_RTOL)
 
 
+def test_float_inputs_with_window_and_three_times_power_of_two_length(torch):
+    """Non-two-level float vectors (fp64 exact re-evaluation) through the drop-in classes, with lag
+    windows that select transform lengths 3*2^k, candidates longer and shorter than the reference."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+
+    rng = np.random.RandomState(21)
+    seen = set()
+    for R, S, off, mo in ((9000, 14000, 310, 700), (30000, 21000, -1200, 2500), (80000, 90000, 3000, 5000)):
+        ref = np.repeat(rng.rand(R // 20 + 1) < 0.4, 20)[:R] * rng.choice([0.25, 0.5, 1.0], size=R)
+        idx = np.arange(S) - off  # sub[i] = ref[i + off]  ->  best offset = +off ... as the reference defines it
+        sub = np.where((idx + 2 * off >= 0) & (idx + 2 * off < R), ref[np.clip(idx + 2 * off, 0, R - 1)], 0.0)
+        sub = sub * 0.9 + 0.05 * (rng.rand(S) < 0.1)
+        seen.add(_native.plan_length(R, S, mo))
+        got_s, got_o = FFTAligner(max_offset_samples=mo).fit_transform(ref, sub, get_score=True)
+        exp_s, exp_o = orc.fft_align(ref, sub, mo)
+        assert got_o == exp_o and got_s == pytest.approx(exp_s, rel=SCORE_RTOL), (R, S, mo)
+        sub_b = np.roll(sub, 7)
+        (s, o), win = MaxScoreAligner(FFTAligner, None, 100, mo / 100.0).fit_transform(ref, [sub_b, sub])
+        (es, eo), ei = orc.max_score_align(ref, [sub_b, sub], mo)
+        assert (o, win is [sub_b, sub][ei]) == (eo, True) and s == pytest.approx(es, rel=SCORE_RTOL)
+    assert any(n % 3 == 0 for n in seen), seen
+
+
 def test_batch_api_against_oracle(torch):
     """Throughput path: several 15-minute problems in one ffs_align_batch call, generated on the
     GPU, checked pair by pair against the CPU oracle on the same vectors."""
