@@ -178,7 +178,8 @@ FFS_DEV size_t tile_base(int tile, int c, int log2CL) {
 }
 
 // --------------------------------------------------------------------------------------------
-// pass A.  grid = (N2/C, n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
+// pass A.  grid = (N2/C column tiles [+ N2/128 prefetch blocks for byte inputs], n_transforms);
+// block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
 template <int L, int C, int DT>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
