@@ -388,6 +388,31 @@ def main():
             "host_cpus": os.cpu_count(),
         }
         result["offset_match"]["gpu_equals_cpu_oracle_on_sample"] = bool(agree)
+        # SURVEY 8(d) baseline (ii): the same restatement on many host cores at once (separate process: it
+        # forks workers, which must not happen in a process that has initialised the GPU runtime)
+        try:
+            import subprocess
+
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            try:  # cgroup v2 CPU quota of this container, if any
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if quota != "max":
+                    usable = min(usable, max(1, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
+            procs = max(1, min(64, usable // 2 if usable > 2 else usable))
+            out = subprocess.run([sys.executable, "-m", "oracle.cpu_parallel_baseline", str(procs), "2", str(args.duration)],
+                                 cwd=ROOT, capture_output=True, text=True, timeout=240,
+                                 env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1"))
+            par = json.loads(out.stdout.strip().splitlines()[-1])
+            result["cpu_baseline"]["parallel"] = {
+                "value": par["value"], "unit": "7-ratio solves/s", "cores": par["cores"], "usable_cpus": usable,
+                "sample": "%d processes x 2 pairs each, same restatement, %.1f s per solve per process when all run "
+                          "(1-process figure above: memory-bound FFTs do not scale with cores), %d/%d ratios recovered"
+                          % (par["cores"], par["mean_solve_s"], par["recovered"], par["solves"]),
+            }
+        except Exception as exc:  # a baseline figure must never take the bench line down
+            result["cpu_baseline"]["parallel"] = {"error": repr(exc)[:200]}
 
     if rank == 0 and world == 1 and not args.no_vad:
         result["vad"] = vad_figures(torch, _native)
