@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
-    ap.add_argument("--pairs-in-flight", type=int, default=128)
+    ap.add_argument("--pairs-in-flight", type=int, default=512)
     ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-vad", action="store_true", help="skip the VAD frame-energy sweep figures")
@@ -407,9 +407,9 @@ def main():
             par = json.loads(out.stdout.strip().splitlines()[-1])
             result["cpu_baseline"]["parallel"] = {
                 "value": par["value"], "unit": "7-ratio solves/s", "cores": par["cores"], "usable_cpus": usable,
-                "sample": "%d processes x 2 pairs each, same restatement, %.1f s per solve per process when all run "
-                          "(1-process figure above: memory-bound FFTs do not scale with cores), %d/%d ratios recovered"
-                          % (par["cores"], par["mean_solve_s"], par["recovered"], par["solves"]),
+                "sample": "%d processes (half of the %d CPUs this container may use) x 2 pairs each, same restatement, "
+                          "%.1f s per solve per process, %d/%d ratios recovered"
+                          % (par["cores"], usable, par["mean_solve_s"], par["recovered"], par["solves"]),
             }
         except Exception as exc:  # a baseline figure must never take the bench line down
             result["cpu_baseline"]["parallel"] = {"error": repr(exc)[:200]}
