@@ -162,3 +162,32 @@ def correlate_model(ref_pm, sa_pm, sb_pm, N):
     cols = T2[tile_offset(m1, k1, N1)]  # [k1, m1]
     O = column_fft(cols)  # [m2, m1]
     return O.reshape(N)  # index m2*N2 + m1
+
+
+def segmented_window_correlation(ref_pm, sub_pm, d_lo, d_hi, M):
+    """Model of the block-segmented scheme in DESIGN.md section 8 (not implemented on the device yet):
+    lags d in [d_lo, d_hi] of c(d) = sum_i sub[i] * ref[i + d] from length-M circular transforms of
+    blocks of the candidate, with the K spectrum products added before ONE transform back.
+
+    Block k covers sub[kB, (k+1)B) with B = M - (d_hi - d_lo); it is correlated with
+    ref[kB + d_lo, kB + d_lo + M) (zero outside the vector), so lag d sits at index d - d_lo and no
+    product wraps.  Returns c(d) for d = d_lo..d_hi (float64 arithmetic: the identity, not the error
+    budget, is what this checks)."""
+    sub_pm = np.asarray(sub_pm, dtype=np.float64)
+    ref_pm = np.asarray(ref_pm, dtype=np.float64)
+    W = d_hi - d_lo + 1
+    B = M - (W - 1)
+    assert B > 0
+    K = -(-len(sub_pm) // B)
+    acc = np.zeros(M, dtype=np.complex128)
+    for k in range(K):
+        s = np.zeros(M)
+        blk = sub_pm[k * B:(k + 1) * B]
+        s[: len(blk)] = blk
+        r = np.zeros(M)
+        lo = k * B + d_lo
+        src_lo, src_hi = max(lo, 0), min(lo + M, len(ref_pm))
+        if src_hi > src_lo:
+            r[src_lo - lo: src_hi - lo] = ref_pm[src_lo:src_hi]
+        acc += np.conj(np.fft.fft(s)) * np.fft.fft(r)  # sum_i s[i] r[(i + m) % M] in the spectrum domain
+    return np.real(np.fft.ifft(acc))[:W], K

@@ -50,3 +50,19 @@ def test_split_rule():
     for p in range(12, 21):
         n1, n2 = fm.split_n(3 << p)
         assert n1 * n2 == 3 << p and n1 % 3 == 0 and 48 <= n1 <= 768 and 256 <= n2 <= 4096
+
+
+@pytest.mark.parametrize("R,S,d_lo,d_hi,M", [(5000, 5300, -600, 600, 2048), (5000, 4100, -599, 600, 4096),
+                                              (72000, 75075, -600, 600, 32768), (3000, 9000, -50, 2000, 4096)])
+def test_block_segmented_accumulation_identity(R, S, d_lo, d_hi, M):
+    """The next-round scheme of DESIGN.md section 8: window lags from K block transforms whose
+    spectrum products are summed before one inverse transform."""
+    rng = np.random.RandomState(R + S)
+    ref = 2.0 * (rng.rand(R) < 0.4) - 1
+    sub = 0.97 * (2.0 * (rng.rand(S) < 0.4) - 1)
+    got, K = fm.segmented_window_correlation(ref, sub, d_lo, d_hi, M)
+    assert K >= 2
+    rp = np.concatenate([np.zeros(max(0, -d_lo)), ref, np.zeros(S + d_hi)])
+    off = max(0, -d_lo)
+    exp = np.array([np.dot(sub, rp[off + d: off + d + S]) for d in range(d_lo, d_hi + 1)])
+    assert np.abs(got - exp).max() < 1e-7 * max(1.0, np.abs(exp).max())
