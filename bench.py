@@ -235,6 +235,10 @@ def main():
     # pass A writes 4 candidate transforms + the lower half of the reference's rows, mid reads those
     # 4.5 + writes 4, pass C reads 4 (8n bytes each)
     executed = {"pass_a": 4.5 * 8, "mid": 8.5 * 8, "pass_c": 4 * 8}
+    if n_dev % 3 == 0 and n_dev // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1" and not args.full_length:
+        # block-segmented mode (three length-n/3 blocks per candidate, spectrum products added in the mid
+        # pass): mid writes and the last pass reads a third of the candidate slots
+        executed = {"pass_a": 4.5 * 8, "mid": (4.5 + 4 / 3) * 8, "pass_c": (4 / 3) * 8}
 
     def kernel_table(ktimes, steps, n_fft):
         per_kernel = {}

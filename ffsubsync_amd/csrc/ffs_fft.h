@@ -46,6 +46,13 @@ FFS_DEV cf cmul_k(cf a, float kx, float ky) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
     return r;
 }
+// acc + a*b: two packed FMAs
+FFS_DEV cf cmac(cf acc, cf a, cf b) {
+    cf t, r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    return r;
+}
 // acc + a*k with a wave-uniform k (SGPR pair): two packed FMAs
 FFS_DEV cf cmac_k(cf acc, cf a, float kx, float ky) {
     const cf b = {kx, ky};

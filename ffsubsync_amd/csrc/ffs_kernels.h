@@ -34,6 +34,10 @@ struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: 
     const void* b;
     int32_t len_a, len_b;
     float a0, a1, b0, b1;  // u8: mapped sample values x' for byte == 0 / != 0
+    // Samples [lead, len) of the transform input are a[lead .. len); positions below `lead` are zero
+    // padding and `a` may point in front of the vector there (block-segmented mode: the stretch of the
+    // reference that block 0 meets starts |d_lo| samples before the vector).  Never dereferenced.
+    int32_t lead_a, lead_b;
 };
 
 struct CandDesc {  // one candidate (one FFTAligner solve)
@@ -125,9 +129,9 @@ FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 
 // Branch-free sample fetch: the load is always issued (index clamped to element 0, so the sixteen
 // loads of a thread are in flight together) and the zero padding is applied by a select.
 template <int DT>
-FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1) {
-    const bool in = n < len;
-    const int idx = in ? n : 0;
+FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1, int lead = 0) {
+    const bool in = n < len && n >= lead;
+    const int idx = in ? n : lead;
     float val;
     if (DT == 0) {
         val = (reinterpret_cast<const unsigned char*>(p)[idx] != 0) ? v1 : v0;
@@ -151,7 +155,15 @@ FFS_DEV void map_bytes_from(const unsigned (&b)[16], float v0, float v1, int len
 }
 template <int LT>
 FFS_DEV void map_bytes(const unsigned (&b)[16], float v0, float v1, int len, int n_base, int N2, int col_end,
-                       float (&out)[16]) {
+                       int lead, float (&out)[16]) {
+    if (lead > 0) {  // rare (one reference block per pair in block-segmented mode): test both ends
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n_base + LT * N2 * q;
+            out[q] = (n >= lead && n < len) ? (b[q] ? v1 : v0) : 0.0f;
+        }
+        return;
+    }
     const int rows_full = (len >= col_end) ? (len - col_end) / N2 + 1 : 0;  // rows r with r*N2 + col_end - 1 < len
     const int q_full = rows_full / LT;                                      // q with every row u + LT*q inside
     if (q_full >= 12)
@@ -207,8 +219,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         for (int row = threadIdx.x; row < L; row += LT * C) {
             const int n0 = row * N2 + grp * 128;
             unsigned wa = 0, wb = 0;
-            if (n0 + 4 <= dn.len_a) __builtin_memcpy(&wa, reinterpret_cast<const unsigned char*>(dn.a) + n0, 4);
-            if (n0 + 4 <= dn.len_b) __builtin_memcpy(&wb, reinterpret_cast<const unsigned char*>(dn.b) + n0, 4);
+            if (n0 + 4 <= dn.len_a && n0 >= dn.lead_a) __builtin_memcpy(&wa, reinterpret_cast<const unsigned char*>(dn.a) + n0, 4);
+            if (n0 + 4 <= dn.len_b && n0 >= dn.lead_b) __builtin_memcpy(&wb, reinterpret_cast<const unsigned char*>(dn.b) + n0, 4);
             acc |= wa | wb;
         }
         if (acc == 0xdeadbeefu && pf_sink) *pf_sink = acc;  // keeps the loads alive (pf_sink is scratch)
@@ -259,13 +271,14 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         for (int h = 0; h < 2; ++h) {
             const unsigned char* src = reinterpret_cast<const unsigned char*>(h ? d.b : d.a);
             const int len = h ? d.len_b : d.len_a;
+            const int lead = h ? d.lead_b : d.lead_a;
             uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (n0 + 16 <= len) {
+            if (n0 >= lead && n0 + 16 <= len) {
                 __builtin_memcpy(&w, src + n0, 16);
-            } else if (n0 < len) {  // the one piece that straddles the end of the vector
+            } else if (n0 < len && n0 + 16 > lead) {  // a piece that straddles either end of the data
                 unsigned char tmp[16];
 #pragma unroll
-                for (int k = 0; k < 16; ++k) tmp[k] = (n0 + k < len) ? src[n0 + k] : (unsigned char)0;
+                for (int k = 0; k < 16; ++k) tmp[k] = (n0 + k < len && n0 + k >= lead) ? src[n0 + k] : (unsigned char)0;
                 __builtin_memcpy(&w, tmp, 16);
             }
             *reinterpret_cast<uint4*>(stage + h * 1024 + lane * 16) = w;
@@ -283,16 +296,16 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(ba[q]), "+v"(bb[q]));
         float xa[16], xb[16];
-        map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, xa);
-        map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, xb);
+        map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
+        map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = (u + LT * q) * N2 + n2;
-            v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1);
-            v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1);  // absent candidate: len_b == 0
+            v[q].x = load_mapped<DT>(d.a, d.len_a, n, d.a0, d.a1, d.lead_a);
+            v[q].y = load_mapped<DT>(d.b, d.len_b, n, d.b0, d.b1, d.lead_b);  // absent candidate: len_b == 0
         }
     }
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
@@ -481,6 +494,68 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 }
 
 // --------------------------------------------------------------------------------------------
+// mid pass, block-segmented mode (N2 = 4096: one row per block).  A pair is n_blocks groups of n_slots
+// length-N buffers (N = the block transform length M): group k holds the pass-A output of block k of
+// the reference (slot 0, rows 0..N1/2 when ref_half) and of the candidate transforms (slots 1..).
+// For every candidate slot the spectrum products of the blocks are ADDED, then one row transform goes
+// back:  acc = sum_k FFT(S_k row) * conj(FFT(R_k row)) / N.  The result replaces group 0's slot (its
+// own input row was consumed two blocks earlier), so mid writes and the last pass reads 1/n_blocks of
+// what the unsegmented pipeline moves.  The reference rows are transformed again for every slot
+// (keeping n_blocks spectra would not fit in registers); the row-transform count per pair is the same
+// as in k_mid at three times the transform length.
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                                    int n_blocks, float inv_n, const cf* __restrict__ tw,
+                                                    const cf* __restrict__ tb, const cf* __restrict__ ts, int ref_half) {
+    static_assert(L == 4096, "one row per 256-thread block");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    const int u = threadIdx.x;
+    const int k1 = blockIdx.x;
+    RowAddr<L> addr(0, u);
+    const int C = 1 << log2C;
+    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
+    const bool mirrored = ref_half && k1 > N1 / 2;
+    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
+    const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
+    const size_t qstride = (size_t)LT * N1;
+    const float sgn = mirrored ? inv_n : -inv_n;
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    for (int s = 1; s < n_slots; ++s) {
+        cf acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = mk(0.f, 0.f);
+        for (int k = 0; k < n_blocks; ++k) {
+            cf* grp = base + (size_t)k * n_slots * N;
+            cf rr[16], v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)s * N + q * qstride)[off0];
+            fft_regs<L>(rr, lds, u, addr, twr);
+            if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+                __syncthreads();
+                mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+                __syncthreads();
+                mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+            }
+            fft_regs<L>(v, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], mk(rr[q].x * inv_n, rr[q].y * sgn));
+        }
+        fft_regs<L>(acc, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+            (base + (size_t)s * N + q * qstride)[off0] = cmul(acc[q], w);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // mid pass, packed-reference layout (odd candidate counts, N2 = 4096).  The last candidate transform
 // is z = c_last + i*r, so after the row transform  Z[k] = C[k] + i*R[k]  with C, R Hermitian:
 //     R[k] = (Z[k] - conj(Z[N-k])) / 2i,   C[k] = (Z[k] + conj(Z[N-k])) / 2.
@@ -588,10 +663,21 @@ FFS_DEV int cand_slot(int n_slots, int kp, int n_packed) {
 struct WinParams {
     int lo[2], hi[2];
     float marg[2];
+    int seg, shift;  // block-segmented mode: output index m is lag m + shift (no wrap-around)
 };
 
-FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand) {
+// lag of output index m: circular (lags 0..d_hi at m = d, negative ones at m = d + N) or, in
+// block-segmented mode, the plain shift
+FFS_DEV int lag_of(const WinParams& wp, int h, int m, int nN) {
+    if (wp.seg) return m + wp.shift;
+    return (m <= wp.hi[h]) ? m : m - nN;
+}
+
+FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand, int seg_shift = 0,
+                              int seg = 0) {
     WinParams w;
+    w.seg = seg;
+    w.shift = seg_shift;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const bool present = (2 * kp + h) < n_cand;
@@ -616,7 +702,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
         const int m = m_of(q);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
+            const int d = lag_of(wp, h, m, nN);
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && better(val, d, bv[h], bd[h])) {
@@ -670,7 +756,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const int m = m_of(q);
-            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
+            const int d = lag_of(wp, h, m, nN);
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && val >= thr) {
@@ -706,7 +792,7 @@ FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int n
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!want[h]) continue;
-            const int d = (m <= wp.hi[h]) ? m : m - nN;  // lags 0..d_hi sit at m = d, negative ones at m = d + N
+            const int d = lag_of(wp, h, m, nN);
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && val >= thr[h]) {
@@ -850,7 +936,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                                                                 const NomList* __restrict__ noms,
                                                                 PoolHeader* __restrict__ pool,
                                                                 PoolEntry* __restrict__ entries, int log2CL,
-                                                                const int* __restrict__ xlist) {
+                                                                const int* __restrict__ xlist, int seg, int seg_shift) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -918,7 +1004,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
             mm[j] = tile * C + cc + N2 * m2;
         }
     }
-    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, seg_shift, seg);
     if (EXH) {
         block_collect_all<NVF>(
             val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries);

@@ -40,6 +40,7 @@ int fail(int code, const char* fmt, ...) {
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
 constexpr unsigned kPoolCapacity = 1u << 20;
+constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
 int ilog2(int64_t x) {
@@ -130,6 +131,10 @@ struct ffs_plan {
     BlockNom* bnom = nullptr;                 // [pairs_in_flight*n_packed*2][tiles]
     PoolEntry* pool_entries = nullptr;        // [kPoolCapacity] exhaustive fallback for flagged candidates
     int* xlist = nullptr;                     // [1 + pairs_in_flight*max_cand] flagged candidates of the sub-batch
+    // Block-segmented mode (n_fft = 3*M, M = 2^k >= 2^16): a complete power-of-two plan of length M with
+    // room for three blocks per pair; used when the lag window is narrow enough (ffs_align_batch)
+    ffs_plan* seg = nullptr;
+    bool allow_seg = true;                    // FFS_DISABLE_SEGMENTED=1
     // per-call descriptor storage (grown on demand)
     void* dev_desc = nullptr;
     size_t dev_desc_bytes = 0;
@@ -281,6 +286,17 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipSt
     return fail(FFS_E_INVALID, "unsupported row length %d", p->N2);
 }
 
+int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, bool ref_half, hipStream_t st) {
+    const size_t lds = row_lds_bytes(4096);
+    int rc_lds;
+    if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096>, lds))) return rc_lds;
+    hipLaunchKernelGGL((k_mid_seg<4096>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1, sp->log2CL,
+                       (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
+                       ref_half ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
 struct PoolArgs {
     const NomList* noms;
     PoolHeader* header;
@@ -348,23 +364,24 @@ size_t pruned_lds_bytes(int L) {
 
 template <int L, int C, bool EXH>
 int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed,
-                              int n_slots, int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st) {
+                              int n_slots, int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st, int seg,
+                              int seg_shift) {
     const size_t lds = pruned_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_c_pruned<L, C, EXH>, lds))) return rc_lds;
     dim3 grid(p->N2 / C, EXH ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
                        p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->xlist);
+                       p->xlist, seg, seg_shift);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 template <bool EXH>
 int launch_pass_c_pruned(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
-                         int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st) {
+                         int n_pairs, const BinList& bins, const PoolArgs& pa, hipStream_t st, int seg = 0, int seg_shift = 0) {
 #define FFS_PCP(L, C) \
-    case L: return launch_pass_c_pruned_inst<L, C, EXH>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, pa, st)
+    case L: return launch_pass_c_pruned_inst<L, C, EXH>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, bins, pa, st, seg, seg_shift)
     switch (p->N1) {
         FFS_PCP(48, 64);
         FFS_PCP(96, 32);
@@ -422,6 +439,7 @@ struct VecView {
     const void* ptr;
     int64_t len;
     double lo, hi;
+    int64_t lead = 0;  // positions [0, lead) of the transform input are zero padding (see XformDesc)
 };
 
 // The reference's lag window for (R, S): allowed k in [kA, kB) of its length-n_ref convolve array
@@ -493,16 +511,18 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
     return FFS_OK;
 }
 
-void fill_xform(XformDesc* x, const VecView* a, const VecView* b) {
+void fill_xform(XformDesc* x, const VecView* a, const VecView* b, const void* safe = nullptr) {
     memset(x, 0, sizeof *x);
     x->a = a->ptr;
     x->len_a = (int32_t)a->len;
+    x->lead_a = (int32_t)a->lead;
     x->a0 = (float)mapped(a->lo);
     x->a1 = (float)mapped(a->hi);
-    x->b = a->ptr;  // absent second candidate: any valid address with length 0 (reads are clamped)
+    x->b = safe ? safe : a->ptr;  // absent second candidate: any valid address with length 0 (reads are clamped)
     if (b) {
         x->b = b->ptr;
         x->len_b = (int32_t)b->len;
+        x->lead_b = (int32_t)b->lead;
         x->b0 = (float)mapped(b->lo);
         x->b1 = (float)mapped(b->hi);
     }
@@ -571,6 +591,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_pruned = !(e && e[0] == '1');
         // measured neutral (pass A -2.0 us/pair, mid +2.0 us/pair: the second row of every pair re-reads
         // and re-transforms the last slot's rows), so the simpler separate-reference layout is the default
+        const char* e6 = getenv("FFS_DISABLE_SEGMENTED");
+        p->allow_seg = !(e6 && e6[0] == '1');
         const char* e4 = getenv("FFS_DISABLE_REF_HALF");
         p->allow_ref_half = !(e4 && e4[0] == '1');
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
@@ -641,6 +663,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     HIP_TRY(hipMalloc((void**)&p->xlist, (1 + (size_t)pairs_in_flight * max_cand) * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
     p->workspace_bytes += (int64_t)kPoolCapacity * sizeof(PoolEntry);
+    if (r3 && p->allow_seg && p->N2 == 4096 && n_fft / 3 >= 65536) {
+        if ((rc = ffs_plan_create(device, n_fft / 3, pairs_in_flight * kSegBlocks, max_cand, &p->seg))) return rc;
+        p->workspace_bytes += p->seg->workspace_bytes;
+    }
     guard.p = nullptr;
     *out = p;
     return FFS_OK;
@@ -661,6 +687,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->bnom);
     (void)hipFree(p->pool_entries);
     (void)hipFree(p->xlist);
+    if (p->seg) (void)ffs_plan_destroy(p->seg);
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -697,13 +724,14 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const bool ref_half = !packed_ref && !p->direct_only && ref_half_ok(p);
     const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
     const size_t n_cands = (size_t)n_pairs * n_cand;
-    const size_t n_xf = (size_t)n_pairs * xf_per_pair;
+    size_t n_xf = (size_t)n_pairs * xf_per_pair;
+    const size_t n_xf_alloc = p->seg ? (size_t)n_pairs * kSegBlocks * n_slots : n_xf;  // block-segmented mode needs more
     // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
     const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
     const size_t o_cand = 64;
     const size_t o_xf = o_cand + n_cands * sizeof(CandDesc);
-    const size_t host_bytes = o_xf + n_xf * sizeof(XformDesc);
-    const size_t o_nom = (host_bytes + 255) & ~(size_t)255;
+    const size_t host_bytes_max = o_xf + (n_xf_alloc > n_xf ? n_xf_alloc : n_xf) * sizeof(XformDesc);
+    const size_t o_nom = (host_bytes_max + 255) & ~(size_t)255;
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
     const size_t o_pbest = o_acc + n_cands * KNOM * sizeof(RescoreAcc);  // zeroed together with acc
     const size_t total = o_pbest + n_cands * sizeof(PoolBest);
@@ -719,6 +747,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     CandDesc* hc = (CandDesc*)(hb + o_cand);
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     const int stride = 1 + n_cand;
+    std::vector<VecView> views((size_t)n_pairs * stride);  // per pair: reference, candidates (reachable prefixes)
     for (int pi = 0; pi < n_pairs; ++pi) {
         const size_t b = (size_t)pi * stride;
         VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
@@ -741,6 +770,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             }
         }
         ref.len = ref_used;
+        views[b] = ref;
+        for (int j = 0; j < n_cand; ++j) views[b + 1 + j] = subs[j];
         if (packed_ref) {
             for (int k = 0; k < n_packed; ++k)
                 fill_xform(&hx[(size_t)pi * xf_per_pair + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : &ref);
@@ -758,7 +789,67 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     memset(&bins, 0, sizeof bins);
     bins.n = (int)bin_set.size();
     for (int i = 0; i < bins.n; ++i) bins.b[i] = bin_set[i];
-    const bool pruned = p->allow_pruned && !bins_overflow && bins.n > 0 && bins.n * 2 <= p->N1;
+    bool pruned = p->allow_pruned && !bins_overflow && bins.n > 0 && bins.n * 2 <= p->N1;
+    // Block-segmented mode (see k_mid_seg): every candidate is cut into n_blocks <= 3 blocks of B samples,
+    // block k is correlated with the reference stretch [kB + D_lo, kB + D_lo + M) by a length-M transform
+    // (lag d at output index d - D_lo, nothing wraps), the blocks' spectrum products are added in the
+    // mid pass.  [D_lo, D_hi] = union of the call's lag windows.
+    bool seg = false;
+    int seg_blocks = 0;
+    int64_t seg_lo = 0;
+    if (p->seg && p->allow_seg && p->allow_pruned && !p->direct_only && !packed_ref && max_offset_samples >= 0 && p->seg->N2 == 4096 &&
+        ref_half_ok(p->seg)) {
+        const ffs_plan* sp = p->seg;
+        int64_t d_lo = INT64_MAX, d_hi = INT64_MIN, s_max = 1;
+        for (size_t i = 0; i < n_cands; ++i) {
+            if (hc[i].flags & FFS_FLAG_EMPTY_WINDOW) continue;
+            if (hc[i].d_lo < d_lo) d_lo = hc[i].d_lo;
+            if (hc[i].d_hi > d_hi) d_hi = hc[i].d_hi;
+            const int64_t sl = views[(i / n_cand) * stride + 1 + i % n_cand].len;
+            if (sl > s_max) s_max = sl;
+        }
+        if (d_lo <= d_hi) {
+            const int64_t W = d_hi - d_lo + 1, B = sp->N - (W - 1);
+            const int64_t nb = (W - 1) / sp->N2 + 1;
+            if (B >= 1 && nb <= MAXBINS && nb * 2 <= sp->N1 && (s_max + B - 1) / B <= kSegBlocks) {
+                seg = true;
+                seg_blocks = (int)((s_max + B - 1) / B);
+                seg_lo = d_lo;
+                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : 4;
+                n_xf = (size_t)n_pairs * seg_blocks * n_slots;
+                for (int pi = 0; pi < n_pairs; ++pi) {
+                    const VecView& ref = views[(size_t)pi * stride];
+                    for (int k = 0; k < seg_blocks; ++k) {
+                        XformDesc* x = &hx[((size_t)pi * seg_blocks + k) * n_slots];
+                        VecView rb = ref;  // positions [lead, len) of the block input = ref[start + n]
+                        const int64_t start = (int64_t)k * B + d_lo;
+                        rb.lead = start < 0 ? -start : 0;
+                        rb.len = ref.len - start < sp->N ? ref.len - start : sp->N;
+                        if (rb.len <= rb.lead) {
+                            rb.len = rb.lead = 0;  // nothing of the reference in this stretch
+                        } else {
+                            rb.ptr = (const char*)ref.ptr + start * (int64_t)esz;  // may point in front of the vector (lead)
+                        }
+                        fill_xform(x, &rb, nullptr, ref.ptr);
+                        std::vector<VecView> sb(n_cand);
+                        for (int j = 0; j < n_cand; ++j) {
+                            sb[j] = views[(size_t)pi * stride + 1 + j];
+                            const int64_t left = sb[j].len - (int64_t)k * B;
+                            sb[j].len = left <= 0 ? 0 : (left < B ? left : B);
+                            if (sb[j].len > 0) sb[j].ptr = (const char*)sb[j].ptr + (int64_t)k * B * (int64_t)esz;
+                        }
+                        for (int kk = 0; kk < n_packed; ++kk)
+                            fill_xform(x + 1 + kk, &sb[2 * kk], (2 * kk + 1 < n_cand) ? &sb[2 * kk + 1] : nullptr, ref.ptr);
+                    }
+                }
+                memset(&bins, 0, sizeof bins);
+                bins.n = (int)nb;
+                for (int i = 0; i < bins.n; ++i) bins.b[i] = i;
+                pruned = true;
+            }
+        }
+    }
+    const size_t host_bytes = o_xf + n_xf * sizeof(XformDesc);
     char* db = (char*)p->dev_desc;
     HIP_TRY(hipMemcpyAsync(db, hb, host_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(p->upload_done, st));
@@ -780,7 +871,53 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     } else {
         HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
         const int tiles = p->N2 / p->C;
-        for (int p0 = 0; p0 < n_pairs; p0 += p->pairs_in_flight) {
+        for (int p0 = 0; seg && p0 < n_pairs; p0 += p->pairs_in_flight) {
+            // block-segmented pipeline on the length-M sub-plan: 3x shorter transforms, the blocks'
+            // spectrum products are added in the mid pass, last pass over one third of the data
+            ffs_plan* sp = p->seg;
+            const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
+            const int first_cand = p0 * n_cand;
+            const int tiles_s = sp->N2 / sp->C;
+            const XformDesc* dxs = dx + (size_t)p0 * seg_blocks * n_slots;
+            {
+                ProfSpan span(p, st, FFS_K_PASS_A);
+                if (dtype == FFS_DTYPE_U8)
+                    rc = launch_pass_a<0>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st);
+                else
+                    rc = launch_pass_a<1>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st);
+            }
+            if (rc) return rc;
+            {
+                ProfSpan span(p, st, FFS_K_MID);
+                rc = launch_mid_seg(sp, np, n_slots, seg_blocks, true, st);
+            }
+            if (rc) return rc;
+            {
+                ProfSpan span(p, st, FFS_K_PASS_C);
+                rc = launch_pass_c_pruned<false>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, pa, st, 1,
+                                                 (int)seg_lo);
+            }
+            if (rc) return rc;
+            HIP_TRY(hipMemsetAsync(sp->xlist, 0, sizeof(int), st));
+            {
+                ProfSpan span(p, st, FFS_K_NOMINEES);
+                hipLaunchKernelGGL(k_nominees, dim3(np * n_cand), dim3(64), 0, st, sp->bnom, tiles_s, n_cand, n_packed, dc, dn,
+                                   first_cand, sp->xlist);
+            }
+            HIP_TRY(hipGetLastError());
+            if ((rc = launch_pass_c_pruned<true>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, pa, st, 1,
+                                                 (int)seg_lo)))
+                return rc;
+            {
+                ProfSpan span(p, st, FFS_K_RESCORE);
+                if (dtype == FFS_DTYPE_U8)
+                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
+                else
+                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        for (int p0 = 0; !seg && p0 < n_pairs; p0 += p->pairs_in_flight) {
             const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
             const int first_cand = p0 * n_cand;
             {

@@ -370,6 +370,40 @@ def test_reference_half_rows_equal_all_rows(torch, monkeypatch):
         assert np.abs(half[0]["score_f32"].astype(np.float64) - half[0]["score"]).max() < 0.5
 
 
+def test_block_segmented_mode_equals_single_transform(torch, monkeypatch):
+    """With a narrow lag window a 3*2^k plan cuts every candidate into three blocks, correlates each
+    with its stretch of the reference by a transform of a third of the length and adds the spectrum
+    products before the way back; the records must equal those of the one-transform pipeline."""
+    from ffsubsync_amd import batch, synth
+
+    specs = [synth.make_pair_spec(900 + i, duration_s=d) for i, d in enumerate((7200.0, 7100.0, 6500.0, 3500.0, 1700.0))]
+    for group, n_cand_used in ((specs[:3], 7), (specs[3:4], 7), (specs[4:], 7)):
+        db = batch.build_device_batch(group)
+        n_fft = db.required_fft_length(6000)
+        assert n_fft % 3 == 0 and n_fft // 3 >= 65536, n_fft
+        a = batch.BatchAligner(n_fft, n_cand_used, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        monkeypatch.setenv("FFS_DISABLE_SEGMENTED", "1")
+        b = batch.BatchAligner(n_fft, n_cand_used, max_offset_samples=6000, pairs_in_flight=2).solve(db)
+        monkeypatch.delenv("FFS_DISABLE_SEGMENTED")
+        assert np.array_equal(a[0]["offset"], b[0]["offset"]) and np.array_equal(a[0]["score"], b[0]["score"])
+        assert np.array_equal(a[1], b[1])
+        assert np.abs(a[0]["score_f32"].astype(np.float64) - a[0]["score"]).max() < 0.5
+        for p, sp in enumerate(group):
+            assert a[1][p]["best_cand"] == sp.true_ratio_index
+    # single candidate, asymmetric window, float inputs (generic load path with a leading-zero reference block)
+    from ffsubsync_amd.aligners import FFTAligner
+    from ffsubsync_amd._native import plan_length as _native_plan_length
+
+    rng = np.random.RandomState(33)
+    ref = np.repeat(rng.rand(15000) < 0.4, 20)[:300000] * rng.choice([0.5, 1.0], size=300000)
+    sub = np.concatenate([np.zeros(4321), ref[:290000]]) * 0.9
+    assert _native_plan_length(300000, 294321, 4500) % 3 == 0
+    for mo in (6000, 4500):
+        got = FFTAligner(max_offset_samples=mo).fit_transform(ref, sub, get_score=True)
+        exp = orc.fft_align(ref, sub, mo)
+        assert got[1] == exp[1] == -4321 and got[0] == pytest.approx(exp[0], rel=SCORE_RTOL)
+
+
 def test_window_shortened_transform_equals_full_length(torch):
     """With a lag window the plan may use a transform shorter than the reference's N (no aliasing
     reaches the windowed lags, ffs_plan_length): every result record must equal the full-length one."""
