@@ -28,7 +28,8 @@ for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
             continue
         if "ffsa::k_" in kn and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = row["Kernel_Name"].split("ffsa::k_")[1].split("<")[0].split("(")[0]
-            acc[k.replace("pass_c_pruned", "pass_c")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+            k = k.replace("pass_c_pruned", "pass_c").replace("mid_seg", "mid")  # bench.py's kernel ids
+            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, c in acc.items():
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
