@@ -81,7 +81,9 @@ int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_sam
 /* Create a plan for transform length n_fft (a power of two in [2, 2^24], or 3*2^k in
  * [12288, 3145728]) on `device`.
  * pairs_in_flight: how many (reference, candidates) problems share one sweep of the
- * A/mid/C kernels (sizes the workspace: pairs_in_flight * (1+ceil(max_cand/2)) * n_fft * 8 B).
+ * A/mid/C kernels (sizes the workspace: pairs_in_flight * (1+ceil(max_cand/2)) * n_fft * 8 B; twice
+ * that for n_fft = 3*2^k >= 3*2^16, which also carries the block-segmented pipeline used under
+ * narrow lag windows).
  * Replaces: the per-call np.fft plan + temporaries of FFTAligner.fit (aligners.py:67-74). */
 int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand, ffs_plan** out);
 int ffs_plan_destroy(ffs_plan* plan);
