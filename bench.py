@@ -1,20 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: seven-ratio MaxScoreAligner(FFTAligner) solves per second on 2 h @ 100 Hz
-activity vectors (BASELINE.json metric; workload = configs[2], 1024 pairs x 7 framerate ratios per
-GPU, N = 2^21, max_offset_samples = 6000).
+activity vectors (BASELINE.json metric; workload = configs[2]: batches of 1024 pairs x 7 framerate
+ratios, max_offset_samples = 6000, reference transform length N = 2^21).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong]
 
-One "step" = one pass of the hot path (ffs_align_batch: pass A -> mid -> pass C -> nominees ->
-exact re-evaluation -> max over ratios) over this rank's batch, inputs already resident in HBM,
-plus the all-gather of the 24-byte per-pair results when N > 1.  Pairs are sharded by rank with
-no data exchange during solves (weak scaling: every rank owns --pairs problems).  Prints ONE JSON
-line on rank 0.
+One "step" = one pass of the hot path (ffs_align_batch: pass A -> mid -> pass C -> nominees -> exact
+re-evaluation -> max over ratios) over this rank's pairs -- by default eight 1024-pair batches
+(`--pairs 8192`, seeds 0..8191, ~0.13 s on one MI355X, so that 20 steps time > 2 s) --, inputs already
+resident in HBM (bit-packed, FFS_DTYPE_U1), plus the RCCL all-gather of the 24-byte per-pair results when
+N > 1.  Pairs are sharded by rank, no data exchange during solves.  `--scaling weak` (default): every
+rank owns --pairs problems; `--scaling strong`: the same --pairs problems are split over the ranks
+(BASELINE configs[3]).  With --gpus N > 1 and no launcher in the environment the script starts itself
+under torch.distributed.run (one process per GPU).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,22 +32,36 @@ HBM_COPY_CEILING = 6.29e12  # measured float4-copy ceiling, same guide
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=1024, help="problems per GPU per step")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=8192, help="problems per step (per GPU when weak, in total when strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
     ap.add_argument("--pairs-in-flight", type=int, default=512)
-    ap.add_argument("--cpu-pairs", type=int, default=12, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--input-format", choices=("bits", "bytes"), default="bits",
+                    help="bits = FFS_DTYPE_U1 (native), bytes = FFS_DTYPE_U8")
+    ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-vad", action="store_true", help="skip the VAD frame-energy sweep figures")
-    ap.add_argument("--e2e-files", type=int, default=8,
+    ap.add_argument("--e2e-files", type=int, default=32,
                     help="files in the end-to-end PCM -> VAD -> rasterise -> align figure (0 = skip)")
-    ap.add_argument("--skip-full-length-record", action="store_true",
-                    help="do not append the secondary full-length measurement (used by the PMC runs)")
-    ap.add_argument("--full-length", action="store_true",
+    ap.add_argument("--skip-secondary", action="store_true",
+                    help="headline measurement only (used by the rocprofv3 / PMC runs)")
+    ap.add_argument("--reference-length", action="store_true",
                     help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
                          "alias-free length the lag window allows")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: run this script under torch.distributed.run, one process per GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def vad_figures(torch, _native, minutes=90.0, iters=20):
@@ -92,19 +110,25 @@ def vad_figures(torch, _native, minutes=90.0, iters=20):
         "labels_match_cpu_oracle_first_chunk": ok_oracle,
         "speech_bounds": [lo, hi],
         "cpu_oracle_audio_hours_per_s": (cpu_n / 48000.0 / 3600.0) / cpu_s,
+        "parity": "unpinned (auditok 0.1.5 absent: oracle/vad_oracle.py restates its published energy rule)",
     }
 
 
-def e2e_figures(torch, _native, n_files, minutes=90.0):
-    """BASELINE config 5 at single-GPU scale: per file, 48 kHz s16le PCM resident in HBM -> frame-energy
-    VAD -> 100 Hz activity vector; its subtitle file -> seven rasterised framerate-ratio candidates
-    (from interval lists); then one batched MaxScoreAligner solve over all files.  Ground truth:
-    every file's subtitles were stretched by one of the seven ratios and shifted by a known offset."""
+def e2e_figures(torch, _native, n_files, minutes=90.0, cpu_files=1):
+    """BASELINE configs[4] at one GPU's share (256 files / 8 GPUs = 32 files x 90 min): per file, 48 kHz s16le PCM
+    streamed from PINNED HOST memory in the reference's 100 s buffers (H2D on a copy stream overlapped with
+    the frame-energy sweep, ``detect_pinned_stream``) -> 100 Hz activity vector (stays in HBM, bit-packed);
+    its subtitle file -> seven rasterised framerate-ratio candidates (from interval lists, bit-packed);
+    then one batched MaxScoreAligner solve over all files.  Ground truth: every file's subtitles were
+    stretched by one of the seven ratios and shifted by a known offset.  The PCIe rate is measured, not
+    estimated; the same files' first `cpu_files` go through the CPU oracles for the wall-clock next to it."""
     import numpy as np
 
-    from ffsubsync_amd import batch, synth
+    from ffsubsync_amd import batch
     from ffsubsync_amd.constants import candidate_ratios
+    from ffsubsync_amd.speech_transformers import detect_pinned_stream, frames_per_window
     from ffsubsync_amd.subtitle_raster import DeviceRaster, rasterize_candidates
+    from workloads import synth
 
     ratios = candidate_ratios()
     frame, n_frames = 480, int(minutes * 60 * 100)
@@ -122,77 +146,142 @@ def e2e_figures(torch, _native, n_files, minutes=90.0):
         sigma = torch.where(speech, 3000.0, 30.0).repeat_interleave(frame)
         pcm = (torch.randn(n_frames * frame, generator=g, device="cuda") * sigma).round().clamp(-32768, 32767).to(torch.int16)
         del sigma
-        files.append((pcm, (s_us, e_us, meta)))
+        host = torch.empty(pcm.numel(), dtype=torch.int16).pin_memory()
+        host.copy_(pcm)
+        del pcm
+        files.append((host, (s_us, e_us, meta)))
         truth.append((idx, shift))
     torch.cuda.synchronize()
+    chunk = frames_per_window(100, 48000) * 10000
+    staging = ([torch.empty(chunk, dtype=torch.int16, device="cuda") for _ in range(2)], torch.cuda.Stream())
 
     def run():
         pairs = []
-        for pcm, (s_us, e_us, meta) in files:
-            labels = _native.vad_energy(pcm, frame, 50.0, 0.0)
-            ref = DeviceRaster((labels > 0.5).to(torch.uint8), 0.0, 1.0)
+        t_v = time.perf_counter()
+        for host, (s_us, e_us, meta) in files:
+            labels = detect_pinned_stream(host, 100, 48000, 0.0, staging=staging)
+            ref = DeviceRaster(_native.pack_bits(labels, 0.5), 0.0, 1.0, labels.numel())
             pairs.append((ref, rasterize_candidates(s_us, e_us, meta, ratios)))
+        torch.cuda.synchronize()
+        t_v = time.perf_counter() - t_v
         db = batch.pack_pairs(pairs)
         al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=min(128, n_files))
         _, pres = al.solve(db)
         al.plan.close()
-        return pres
+        return pres, t_v
 
     run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    pres = run()
+    pres, t_vad = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = sum(int(pres[i]["best_cand"]) == truth[i][0] and abs(int(pres[i]["offset"]) - truth[i][1]) <= 2
              for i in range(n_files))
     pcm_bytes = 2 * n_frames * frame
-    return {
-        "workload": "%d files x %.0f min: 48 kHz PCM (in HBM) -> VAD -> 7 rasterised candidates -> batched solve" % (n_files, minutes),
-        "files_per_s_pcm_resident": n_files / dt,
-        "ms_per_file_pcm_resident": 1e3 * dt / n_files,
+    out = {
+        "workload": "%d files x %.0f min: 48 kHz PCM streamed from pinned host memory -> VAD -> 7 rasterised "
+                    "candidates -> batched solve (one GPU's share of configs[4])" % (n_files, minutes),
+        "files_per_s": n_files / dt,
+        "ms_per_file": 1e3 * dt / n_files,
+        "pcie_GBps_achieved_during_vad": n_files * pcm_bytes / t_vad / 1e9,
+        "vad_share_of_wall": t_vad / dt,
         "recovered_ratio_and_offset": "%d/%d" % (ok, n_files),
-        "pcie_bound_files_per_s_estimate": 63e9 / pcm_bytes,
-        "note": "host-side per-file work here is the interval arithmetic of the rasteriser and Python launch overhead; "
-                "streaming the PCM over PCIe Gen5 (63 GB/s spec) would cap one GPU at the estimate above",
     }
+    if cpu_files > 0:
+        from oracle import aligners_oracle as orc
+        from oracle import raster_oracle as ro
+        from oracle import vad_oracle as vo
+
+        t1 = time.perf_counter()
+        agree = True
+        for i in range(min(cpu_files, n_files)):
+            host, (s_us, e_us, meta) = files[i]
+            lab = vo.chunked_detect(host.numpy())
+            cands = [ro.rasterize(s_us, e_us, meta, r, 100, 0) * min(1.0 / r, 1.0) for r in ratios]
+            (sc, off), idx = orc.max_score_align(lab, cands, 6000)
+            agree &= (idx == int(pres[i]["best_cand"]) and off == int(pres[i]["offset"])
+                      and abs(sc - pres[i]["score"]) <= 1e-5 * abs(sc))
+        cpu_s = (time.perf_counter() - t1) / min(cpu_files, n_files)
+        out["cpu_oracle_s_per_file_1core"] = cpu_s
+        out["gpu_equals_cpu_oracle_on_sample"] = bool(agree)
+        out["speedup_vs_1core"] = cpu_s / (dt / n_files)
+    return out
+
+
+def load_headline_golden():
+    path = os.path.join(ROOT, "tests", "golden", "headline_golden.json")
+    if not os.path.exists(path):
+        return {}
+    return {g["seed"]: g for g in json.load(open(path))["pairs"]}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = os.environ.get("FFS_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
 
     n_cand = 7
-    P = args.pairs
-    specs = [synth.make_pair_spec(rank * P + i, duration_s=args.duration) for i in range(P)]
-    db = batch.build_device_batch(specs)
-    n_ref = db.required_fft_length(None)  # the reference's N = 2^ceil(log2(R+S)) (aligners.py:67-68)
+    strong = args.scaling == "strong"
+    if strong:
+        lo, hi = batch.shard_bounds(args.pairs, rank, world)
+        seeds = list(range(lo, hi))
+    else:
+        seeds = [rank * args.pairs + i for i in range(args.pairs)]
+    P = len(seeds)
+    per = (args.pairs + world - 1) // world if strong else args.pairs  # records per rank in the gather
+    specs = [synth.make_pair_spec(s, duration_s=args.duration) for s in seeds]
+    db = synth.build_device_batch(specs, packed=(args.input_format == "bits"))
+    n_ref = db.required_fft_length(6000, reference_length=True)  # the reference's N = 2^ceil(log2(R+S)) (aligners.py:67-68)
     # the +-6000 lag window lets the device use the shortest alias-free transform (ffs_plan_length)
-    n_dev = n_ref if args.full_length else db.required_fft_length(6000)
-    cand_out = torch.empty(P * n_cand * 24, dtype=torch.uint8, device="cuda")
-    pair_out = torch.empty(P * 24, dtype=torch.uint8, device="cuda")
-    use_dist = world > 1 or force_dist
-    gathered = torch.empty(world * P * 24, dtype=torch.uint8, device="cuda") if use_dist else None
+    n_dev = n_ref if args.reference_length else db.required_fft_length(6000)
+    cand_out = torch.empty(max(P, 1) * n_cand * 24, dtype=torch.uint8, device="cuda")
+    pair_out = torch.zeros(per * 24, dtype=torch.uint8, device="cuda")
+    gathered = torch.empty(world * per * 24, dtype=torch.uint8, device="cuda") if use_dist else None
     profile = not args.no_profile
+    gather_impl = None
+    comm = None
+    if use_dist:
+        # the library's own collective (ffs_gather_results, RCCL C API); checked once against torch's
+        try:
+            comm = batch.make_comm(rank, world)
+            probe = (torch.arange(per * 24, dtype=torch.int32, device="cuda") + rank).to(torch.uint8)
+            a = comm.gather_pair_results(probe)
+            b = torch.empty_like(a)
+            dist.all_gather_into_tensor(b, probe)
+            torch.cuda.synchronize()
+            if not torch.equal(a, b):
+                raise RuntimeError("ffs_gather_results disagrees with all_gather_into_tensor")
+            gather_impl = "ffs_gather_results (RCCL ncclAllGather via the C ABI)"
+        except Exception as exc:  # keep the scaling record: fall back to torch.distributed's RCCL binding
+            comm = None
+            gather_impl = "torch.distributed.all_gather_into_tensor (ffs_comm_create failed: %s)" % repr(exc)[:120]
+        # every rank must take the same branch
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            gather_impl = "torch.distributed.all_gather_into_tensor (ffs_comm_create failed on another rank)"
 
     def fence():
         torch.cuda.synchronize()
@@ -200,14 +289,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_fft, steps, warmup):
-        """W untimed + K timed passes over this rank's batch with a plan of length n_fft."""
-        aligner = batch.BatchAligner(n_fft, n_cand, max_offset_samples=6000, pairs_in_flight=args.pairs_in_flight)
+    def timed(n_fft, steps, warmup, max_offset=6000, the_db=None, cands=n_cand):
+        """W untimed + K timed passes over this rank's pairs with a plan of length n_fft."""
+        the_db = db if the_db is None else the_db
+        aligner = batch.BatchAligner(n_fft, cands, max_offset_samples=max_offset, pairs_in_flight=args.pairs_in_flight)
 
         def step():
-            aligner.solve_async(db, 0, P, cand_out, pair_out)
-            if use_dist:
-                dist.all_gather_into_tensor(gathered, pair_out)
+            aligner.solve_async(the_db, 0, P, cand_out, pair_out)
+            if use_dist and cands == n_cand:
+                if comm is not None:
+                    comm.gather_pair_results(pair_out, gathered)
+                else:
+                    dist.all_gather_into_tensor(gathered, pair_out)
 
         for _ in range(warmup):
             step()
@@ -224,43 +317,64 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
+        seg = (n_fft % 3 == 0 and n_fft // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1"
+               and max_offset is not None)
         aligner.plan.close()
-        return elapsed, ktimes
+        return elapsed, ktimes, seg
 
-    # 168*N algorithmic bytes per seven-ratio solve (N = the reference's transform length)
-    # = 42 half-transforms of 4*N bytes (each length-N fp32 transform = 8*N over two HBM passes):
-    # pass A = 14 halves, mid = 21, pass C = 7.
+    # Bytes every kernel HAS to move per pair, in units of one complex fp32 transform
+    # slot U = 8*n bytes (n = device transform length): a pair is 1 reference + ceil(cands/2) packed candidate
+    # transforms; the reference's spectrum is real-input Hermitian, so only half of its rows are stored.
+    def must_move(n_fft, seg, cands):
+        slots = (cands + 1) // 2
+        unit = 8.0 * n_fft
+        in_bytes = float(np.mean(db.lens.sum(axis=1))) / (8.0 if db.dtype == _native.FFS_DTYPE_U1 else 1.0)
+        if cands != n_cand:
+            in_bytes *= (1 + cands) / (1 + n_cand)
+        if seg:  # three blocks of n/3 per candidate, spectrum products added in the mid pass
+            return {"pass_a": (slots + 0.5) * unit + in_bytes, "mid": (slots + 0.5 + slots / 3.0) * unit,
+                    "pass_c": slots / 3.0 * unit}
+        return {"pass_a": (slots + 0.5) * unit + in_bytes, "mid": (2 * slots + 0.5) * unit, "pass_c": slots * unit}
+
+    # SURVEY 8(d) normaliser: 168*N bytes per seven-ratio solve (N = the reference's 2^21), apportioned
+    # by transform halves: pass A = 14 halves of 4*N, mid = 21, pass C = 7
     share = {"pass_a": 56, "mid": 84, "pass_c": 28}
-    # bytes the kernels actually have to move per pair at device length n:
-    # pass A writes 4 candidate transforms + the lower half of the reference's rows, mid reads those
-    # 4.5 + writes 4, pass C reads 4 (8n bytes each)
-    executed = {"pass_a": 4.5 * 8, "mid": 8.5 * 8, "pass_c": 4 * 8}
-    if n_dev % 3 == 0 and n_dev // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1" and not args.full_length:
-        # block-segmented mode (three length-n/3 blocks per candidate, spectrum products added in the mid
-        # pass): mid writes and the last pass reads a third of the candidate slots
-        executed = {"pass_a": 4.5 * 8, "mid": (4.5 + 4 / 3) * 8, "pass_c": (4 / 3) * 8}
 
-    def kernel_table(ktimes, steps, n_fft):
+    def kernel_table(ktimes, steps, n_fft, seg, cands=n_cand):
+        mm = must_move(n_fft, seg, cands)
         per_kernel = {}
         for k, (ms, n) in ktimes.items():
             if n == 0:
                 continue
             pairs_per_launch = P * steps / n
-            entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms}
-            if k in share:
-                entry["algorithmic_bytes_per_launch"] = share[k] * n_ref * pairs_per_launch
-                entry["achieved_GBps"] = entry["algorithmic_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
-                entry["executed_bytes_per_launch"] = executed[k] * n_fft * pairs_per_launch
-                entry["executed_GBps"] = entry["executed_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+            entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms, "us_per_pair": 1e3 * ms / (P * steps)}
+            if k in mm:
+                entry["must_move_bytes_per_launch"] = mm[k] * pairs_per_launch
+                entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+                entry["frac_of_8TBps"] = entry["must_move_GBps"] * 1e9 / HBM_PEAK
+                if cands == n_cand:
+                    entry["normaliser_GBps"] = share[k] * n_ref * pairs_per_launch / (ms / n * 1e-3) / 1e9
             per_kernel[k] = entry
         return per_kernel
 
-    elapsed, ktimes = timed(n_dev, args.steps, args.warmup)
+    elapsed, ktimes, seg_mode = timed(n_dev, args.steps, args.warmup)
 
-    # correctness of what was timed: recovered offsets/ratios vs the generator's ground truth, and
-    # vs the CPU oracle on the sampled pairs below
-    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE).copy()
-    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(P, n_cand).copy()
+    # correctness of what was timed: every pair the reference-generated goldens cover (bench seeds 0..255,
+    # tests/golden/headline_golden.json = the UNMODIFIED reference's (ratio, offset, score)), plus the
+    # generator's ground truth for all pairs
+    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P].copy()
+    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[: P * n_cand].reshape(P, n_cand).copy()
+    golden = load_headline_golden() if args.duration == 7200.0 else {}
+    g_total = g_ok = 0
+    for i, s in enumerate(seeds):
+        g = golden.get(s)
+        if g is None:
+            continue
+        g_total += 1
+        sc = float(g["score"])
+        g_ok += int(int(pres[i]["best_cand"]) == g["index"] and int(pres[i]["offset"]) == g["offset"]
+                    and abs(float(pres[i]["score"]) - sc) <= 1e-5 * abs(sc)
+                    and all(int(cres[i, j]["offset"]) == off for j, (_, off) in enumerate(g["per_candidate"])))
     truth_ok = sum(
         int(pres[i]["best_cand"] == sp.true_ratio_index and abs(int(pres[i]["offset"]) - sp.true_offset_samples) <= 30)
         for i, sp in enumerate(specs)
@@ -268,9 +382,10 @@ def main():
     ambiguous = int(((cres["flags"] & 2) != 0).sum())
     # health of the fp32 transform chain itself (the exact re-evaluation would mask a damaged one as long
     # as the true peak still gets nominated): fp32 value of every winning lag vs its exact score
-    fp32_err = float(np.abs(cres["score_f32"].astype(np.float64) - cres["score"]).max())
+    fp32_err = float(np.abs(cres["score_f32"].astype(np.float64) - cres["score"]).max()) if P else 0.0
 
-    solves_per_s = world * P * args.steps / elapsed
+    total_pairs = args.pairs if strong else world * args.pairs
+    solves_per_s = total_pairs * args.steps / elapsed
     result = {
         "metric": "alignments/sec (2 h@100 Hz, 7 framerate ratios)",
         "value": solves_per_s,
@@ -280,31 +395,40 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "configs[2]: %d x %.0f s@100 Hz pairs per GPU, MaxScoreAligner over 7 framerate ratios, "
-                        "max_offset_samples=6000" % (P, args.duration),
+            "workload": "configs[2]: %d x %.0f s@100 Hz pairs %s (%d batches of 1024), MaxScoreAligner over 7 framerate "
+                        "ratios, max_offset_samples=6000" % (args.pairs, args.duration,
+                                                            "in total" if strong else "per GPU", max(1, args.pairs // 1024)),
             "n_fft_reference": n_ref,
             "n_fft_device": n_dev,
             "pairs_per_gpu": P,
             "pairs_in_flight": args.pairs_in_flight,
-            "parallelism": "pairs sharded by rank, all-gather of 24 B/pair results" if world > 1 else "single GPU",
+            "input_format": "bit-packed 0/1 vectors (FFS_DTYPE_U1) resident in HBM" if db.dtype == _native.FFS_DTYPE_U1
+                            else "0/1 bytes (FFS_DTYPE_U8) resident in HBM",
+            "arithmetic": "fp32 transforms nominate lags; integer (popcount) re-evaluation of the winners: offsets and "
+                          "scores are exact",
+            "parallelism": ("pairs sharded by rank, %s of 24 B/pair results" % gather_impl) if use_dist else "single GPU",
         },
-        "offset_match": {"pairs_matching_ground_truth": truth_ok, "pairs": P, "ambiguous_flags": ambiguous,
+        "offset_match": {"pairs_matching_reference_golden": "%d/%d" % (g_ok, g_total),
+                         "golden": "tests/golden/headline_golden.json (unmodified reference, bench seeds 0..255; index, "
+                                   "offset and all 7 per-candidate offsets bit-identical, score within 1e-5)",
+                         "pairs_matching_ground_truth": truth_ok, "pairs": P, "ambiguous_flags": ambiguous,
                          "max_abs_fp32_error_at_winning_lags": fp32_err},
-        "solve_normaliser": {
+        "normaliser": {
+            "what": "SURVEY 8(d): the reference's 168*N bytes per seven-ratio solve (N = 2^21) x solves/s -- measures "
+                    "algorithmic saving, not HBM efficiency (the device moves fewer bytes: see roofline)",
             "bytes_per_solve": 168 * n_ref,
-            "achieved_GBps": solves_per_s * 168 * n_ref / 1e9,
+            "GBps": solves_per_s * 168 * n_ref / 1e9,
             "frac_of_8TBps_per_gpu": solves_per_s * 168 * n_ref / (HBM_PEAK * world),
-            "frac_of_copy_ceiling_per_gpu": solves_per_s * 168 * n_ref / (HBM_COPY_CEILING * world),
         },
     }
 
     if profile and rank == 0:
-        per_kernel = kernel_table(ktimes, args.steps, n_dev)
+        per_kernel = kernel_table(ktimes, args.steps, n_dev, seg_mode)
         dom = max((k for k in per_kernel if k in share), key=lambda k: per_kernel[k]["total_ms"])
         pairs_per_launch = P * args.steps / per_kernel[dom]["launches"]
         traffic = None
@@ -314,89 +438,102 @@ def main():
             if dom in tj:
                 traffic = tj[dom] * pairs_per_launch
         result["kernels"] = per_kernel
+        mm_launch = per_kernel[dom]["must_move_bytes_per_launch"]
         result["roofline"] = {
-            "kernel": "k_" + dom,
+            "kernel": {"pass_a": "k_pass_a", "mid": "k_mid_seg" if seg_mode else "k_mid", "pass_c": "k_pass_c_pruned"}[dom],
             "bound": "hbm",
-            "achieved": per_kernel[dom]["achieved_GBps"],
+            "achieved": per_kernel[dom]["must_move_GBps"],
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
-            "frac": per_kernel[dom]["achieved_GBps"] / (HBM_PEAK / 1e9),
+            "frac": per_kernel[dom]["must_move_GBps"] * 1e9 / HBM_PEAK,
             "traffic": traffic,
-            "executed_GBps": per_kernel[dom]["executed_GBps"],
-            "executed_frac": per_kernel[dom]["executed_GBps"] / (HBM_PEAK / 1e9),
-            "note": "achieved = SURVEY 8(d) share of the reference's 168*N(=2^21) bytes per solve / launch time; "
-                    "the device moves fewer bytes (packed candidates, reference spectrum kept in registers, "
-                    "transform length 3*2^18 instead of 2^21 under the lag window): executed_* uses the bytes this "
-                    "kernel really has to move, traffic = PMC-measured HBM bytes per launch",
+            "wasted": (traffic / mm_launch) if traffic else None,
+            "bytes_per_launch": mm_launch,
+            "avg_launch_ms": per_kernel[dom]["avg_ms"],
+            "frac_of_copy_ceiling": per_kernel[dom]["must_move_GBps"] * 1e9 / HBM_COPY_CEILING,
+            "note": "achieved = bytes this kernel HAS to move per launch (DESIGN.md section 5: every stored row read "
+                    "once, every result row written once) / its average launch duration from HIP events on the "
+                    "launch stream; traffic = PMC-measured HBM bytes per launch (profiles/traffic_per_pair.json); "
+                    "wasted = traffic / must-move",
         }
 
-    if rank == 0 and world == 1 and not args.full_length and not args.skip_full_length_record and n_dev != n_ref:
-        # the same batch with the reference's full transform length, for the record
-        el2, kt2 = timed(n_ref, max(2, args.steps // 2), 1)
-        st2 = max(2, args.steps // 2)
-        pres2 = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
-        result["full_length"] = {
+    secondary = rank == 0 and world == 1 and not args.skip_secondary
+    if secondary and not args.reference_length and n_dev != n_ref:
+        # the same pairs with the reference's own transform length N = 2^21 (single transform), for the record
+        st2 = max(2, args.steps // 4)
+        el2, kt2, seg2 = timed(n_ref, st2, 1)
+        pres2 = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
+        result["reference_length"] = {
             "n_fft_device": n_ref,
             "value": P * st2 / el2,
             "ms_per_step": 1e3 * el2 / st2,
             "identical_pair_results": bool(np.array_equal(pres2, pres)),
-            "frac_of_8TBps": (P * st2 / el2) * 168 * n_ref / HBM_PEAK,
+            "normaliser_frac_of_8TBps": (P * st2 / el2) * 168 * n_ref / HBM_PEAK,
         }
         if profile:
-            result["full_length"]["kernels"] = {k: {kk: v[kk] for kk in ("avg_ms", "achieved_GBps", "executed_GBps") if kk in v}
-                                               for k, v in kernel_table(kt2, st2, n_ref).items()}
+            result["reference_length"]["kernels"] = {
+                k: {kk: v[kk] for kk in ("avg_ms", "us_per_pair", "must_move_GBps", "frac_of_8TBps") if kk in v}
+                for k, v in kernel_table(kt2, st2, n_ref, seg2).items()}
 
-    if rank == 0 and world == 1 and not args.skip_full_length_record:
-        # single-ratio FFTAligner solves/s (BASELINE config 2 as a batch: every pair against
+    if secondary:
+        # single-ratio FFTAligner solves/s (BASELINE configs[1] as a batch: every pair against
         # the candidate rasterised at its true ratio), with the production lag window and without one
         sdb = db.select_candidates([sp.true_ratio_index for sp in specs])
         single = {}
-        for label, mo in (("max_offset_6000", 6000), ("max_offset_none", None)):
-            al = batch.BatchAligner(sdb.required_fft_length(mo), 1, max_offset_samples=mo, pairs_in_flight=args.pairs_in_flight)
-            al.solve_async(sdb)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                c1, p1 = al.solve_async(sdb)
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / 3
-            c1 = c1.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:P]
+        for label, mo, key in (("max_offset_6000", 6000, "single_6000"), ("max_offset_none", None, "single_none")):
+            n1 = sdb.required_fft_length(mo)
+            st1 = max(2, args.steps // 4)
+            el, kt1, seg1 = timed(n1, st1, 1, max_offset=mo, the_db=sdb, cands=1)
+            c1 = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:P]
+            hits = [(int(c1[i]["offset"]) == golden[s][key][1]
+                     and abs(float(c1[i]["score"]) - float(golden[s][key][0])) <= 1e-5 * abs(float(golden[s][key][0])))
+                    for i, s in enumerate(seeds) if s in golden]
             single[label] = {
-                "n_fft_device": int(al.plan.n_fft),
-                "solves_per_s": P / el,
-                "offsets_within_0.3s_of_truth": int(sum(abs(int(c1[i]["offset"]) - sp.true_offset_samples) <= 30
-                                                        for i, sp in enumerate(specs))),
+                "n_fft_device": int(n1),
+                "solves_per_s": P * st1 / el,
+                "pairs_matching_reference_golden": "%d/%d" % (sum(hits), len(hits)),
             }
-            al.plan.close()
+            if profile:
+                single[label]["kernels"] = {
+                    k: {kk: v[kk] for kk in ("us_per_pair", "must_move_GBps", "frac_of_8TBps") if kk in v}
+                    for k, v in kernel_table(kt1, st1, n1, seg1, cands=1).items()}
         result["single_ratio"] = single
 
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
         from oracle import aligners_oracle as orc
 
+        # SURVEY 8(d) CPU baseline on this box's host cores.  /root/reference does not exist here, so the timed
+        # code is the numpy restatement of aligners.py:50-167 (oracle/aligners_oracle.py), which is pinned to the
+        # unmodified reference by tests/golden/*.json; the unmodified reference itself is timed in the build
+        # container (profiles/r02_cpu_reference_baseline.json).
         n_s = min(args.cpu_pairs, P)
         inputs = [synth.pair_float_arrays(specs[i]) for i in range(n_s)]
-        t1 = time.perf_counter()
-        cpu = [orc.max_score_align(r, c, 6000) for r, c in inputs]
-        cpu_t = time.perf_counter() - t1
+        runs = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            cpu = [orc.max_score_align(r, c, 6000) for r, c in inputs]
+            runs.append(time.perf_counter() - t1)
+            if sum(runs) > 40.0:
+                break
         agree = all(
             int(pres[i]["best_cand"]) == idx and int(pres[i]["offset"]) == off and abs(pres[i]["score"] - sc) <= 1e-5 * abs(sc)
             for i, ((sc, off), idx) in enumerate(cpu)
         )
         result["cpu_baseline"] = {
-            "value": n_s / cpu_t,
+            "value": n_s / min(runs),
             "unit": "7-ratio solves/s",
             "cores": 1,
             "kind": "port",
-            "sample": "%d of the same pairs (seeds 0..%d), numpy complex128 restatement of aligners.py:50-167 "
-                      "(oracle/aligners_oracle.py), single thread, %.1f s" % (n_s, n_s - 1, cpu_t),
+            "sample": "%d of the same pairs (seeds 0..%d), best of %d runs (%s s): numpy complex128 restatement of "
+                      "aligners.py:50-167 (oracle/aligners_oracle.py, golden-pinned to the unmodified reference), single "
+                      "thread" % (n_s, n_s - 1, len(runs), "/".join("%.1f" % r for r in runs)),
             "host_cpus": os.cpu_count(),
+            "unmodified_reference_in_build_container": "profiles/r02_cpu_reference_baseline.json",
         }
         result["offset_match"]["gpu_equals_cpu_oracle_on_sample"] = bool(agree)
         # SURVEY 8(d) baseline (ii): the same restatement on many host cores at once (separate process: it
         # forks workers, which must not happen in a process that has initialised the GPU runtime)
         try:
-            import subprocess
-
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             try:  # cgroup v2 CPU quota of this container, if any
                 quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -405,30 +542,44 @@ def main():
             except (OSError, ValueError):
                 pass
             procs = max(1, min(64, usable // 2 if usable > 2 else usable))
-            out = subprocess.run([sys.executable, "-m", "oracle.cpu_parallel_baseline", str(procs), "2", str(args.duration)],
-                                 cwd=ROOT, capture_output=True, text=True, timeout=240,
-                                 env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1"))
-            par = json.loads(out.stdout.strip().splitlines()[-1])
+            best = None
+            for _ in range(2):
+                out = subprocess.run([sys.executable, "-m", "oracle.cpu_parallel_baseline", str(procs), "2", str(args.duration)],
+                                     cwd=ROOT, capture_output=True, text=True, timeout=240,
+                                     env=dict(os.environ, HIP_VISIBLE_DEVICES="", OMP_NUM_THREADS="1"))
+                par = json.loads(out.stdout.strip().splitlines()[-1])
+                if best is None or par["value"] > best["value"]:
+                    best = par
             result["cpu_baseline"]["parallel"] = {
-                "value": par["value"], "unit": "7-ratio solves/s", "cores": par["cores"], "usable_cpus": usable,
-                "sample": "%d processes (half of the %d CPUs this container may use) x 2 pairs each, same restatement, "
-                          "%.1f s per solve per process, %d/%d ratios recovered"
-                          % (par["cores"], usable, par["mean_solve_s"], par["recovered"], par["solves"]),
+                "value": best["value"], "unit": "7-ratio solves/s", "cores": best["cores"], "usable_cpus": usable,
+                "sample": "best of 2: %d processes (half of the %d CPUs this container may use) x 2 pairs each, same "
+                          "restatement, %.1f s per solve per process, %d/%d ratios recovered"
+                          % (best["cores"], usable, best["mean_solve_s"], best["recovered"], best["solves"]),
             }
         except Exception as exc:  # a baseline figure must never take the bench line down
             result["cpu_baseline"]["parallel"] = {"error": repr(exc)[:200]}
 
-    if rank == 0 and world == 1 and not args.no_vad:
+    if rank == 0 and world == 1 and not args.no_vad and not args.skip_secondary:
         result["vad"] = vad_figures(torch, _native)
-    if rank == 0 and world == 1 and args.e2e_files > 0:
-        result["end_to_end"] = e2e_figures(torch, _native, args.e2e_files)
+    if rank == 0 and world == 1 and args.e2e_files > 0 and not args.skip_secondary:
+        try:
+            result["end_to_end"] = e2e_figures(torch, _native, args.e2e_files)
+        except Exception as exc:  # e.g. not enough pinnable host memory on the box
+            result["end_to_end"] = {"error": repr(exc)[:300]}
 
+    if use_dist:
+        # every rank's records arrived, in rank order
+        mine = gathered[rank * per * 24:(rank + 1) * per * 24]
+        assert bool(torch.equal(mine, pair_out)), "all-gathered records differ from the local ones"
+        if rank == 0:
+            allp = gathered.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
+            result["gathered_records"] = int(allp.size)
+            result["gathered_best_cand_valid"] = int((allp["best_cand"][: (args.pairs if strong else world * per)] >= 0).sum())
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
-        if rank == 0:
-            ok = bool(torch.equal(gathered[rank * P * 24:(rank + 1) * P * 24], pair_out))
-            assert ok, "all-gathered records differ from the local ones"
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -3,10 +3,11 @@
 Public surface (mirrors the reference modules of the same names):
     ffsubsync_amd.aligners            FFTAligner, MaxScoreAligner, FailedToFindAlignmentException
     ffsubsync_amd.golden_section_search.gss
-    ffsubsync_amd.speech_transformers _make_energy_detector, PCMSpeechTransformer,
-                                      ComputeSpeechFrameBoundariesMixin
+    ffsubsync_amd.speech_transformers _make_energy_detector / _make_auditok_detector (factory seam),
+                                      PCMSpeechTransformer, ComputeSpeechFrameBoundariesMixin,
+                                      assemble_sparse_reference, load_speech_batch
     ffsubsync_amd.batch               BatchAligner / DeviceBatch (throughput path, multi-GPU sharding)
-    ffsubsync_amd.install()           patch an importable ``ffsubsync`` to use the GPU aligner
+    ffsubsync_amd.install()           patch an importable ``ffsubsync`` to use the GPU aligner + detector
 """
 from .aligners import (  # noqa: F401
     MAX_FRAMERATE_RATIO,
@@ -19,9 +20,15 @@ from .aligners import (  # noqa: F401
 __version__ = "0.1.0"
 
 
-def install() -> None:
-    """Swap the GPU aligner into an importable ffsubsync: the caller binds the classes by name
-    (ffsubsync/ffsubsync.py:14), the same seam tests/test_quality_gate.py:98-102 patches."""
+def install(detectors: bool = True) -> None:
+    """Swap the GPU path into an importable ffsubsync.
+
+    Aligner: the caller binds the classes by name (ffsubsync/ffsubsync.py:14), the same seam
+    tests/test_quality_gate.py:98-102 patches.  VAD (``detectors``): the reference's
+    ``VideoSpeechTransformer`` picks its detector factory as a module attribute
+    (speech_transformers.py:655-679); the auditok factory is replaced by the GPU frame-energy sweep +
+    token smoothing, everything around it (ffmpeg pipe, embedded-subtitle shortcut, progress, the
+    multi-segment thread pool) stays the reference's own code."""
     import ffsubsync.aligners as ref_aligners
     import ffsubsync.ffsubsync as ref_main
 
@@ -34,3 +41,11 @@ def install() -> None:
 
     _al.FailedToFindAlignmentException = ref_aligners.FailedToFindAlignmentException
     FailedToFindAlignmentException = ref_aligners.FailedToFindAlignmentException
+    if detectors:
+        try:
+            import ffsubsync.speech_transformers as ref_st
+        except Exception:  # the VAD side of ffsubsync is not importable here: aligner-only install
+            return
+        from .speech_transformers import install_detectors
+
+        install_detectors(ref_st)

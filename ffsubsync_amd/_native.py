@@ -17,6 +17,7 @@ _lib_lock = threading.Lock()
 
 FFS_DTYPE_U8 = 0
 FFS_DTYPE_F32 = 1
+FFS_DTYPE_U1 = 2  # one bit per sample, numpy.packbits(..., bitorder="little") order, 32-bit words
 FLAG_EMPTY_WINDOW = 1
 FLAG_AMBIGUOUS = 2
 FLAG_FILTERED = 4
@@ -47,6 +48,13 @@ EXPORTED_SYMBOLS = (
     "ffs_raster_length",
     "ffs_raster_intervals",
     "ffs_rasterize_subtitles",
+    "ffs_rasterize_subtitles_bits",
+    "ffs_pack_bits",
+    "ffs_scatter_segments",
+    "ffs_comm_unique_id",
+    "ffs_comm_create",
+    "ffs_gather_results",
+    "ffs_comm_destroy",
     "ffs_plan_profile",
     "ffs_plan_profile_read",
     "ffs_last_error",
@@ -130,6 +138,21 @@ def load():
         lib.ffs_rasterize_subtitles.restype = c.c_int
         lib.ffs_rasterize_subtitles.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_double,
                                                 c.c_double, c.c_void_p, c.c_int64, c.c_void_p]
+        lib.ffs_rasterize_subtitles_bits.restype = c.c_int
+        lib.ffs_rasterize_subtitles_bits.argtypes = lib.ffs_rasterize_subtitles.argtypes
+        lib.ffs_pack_bits.restype = c.c_int
+        lib.ffs_pack_bits.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_double, c.c_void_p, c.c_void_p]
+        lib.ffs_scatter_segments.restype = c.c_int
+        lib.ffs_scatter_segments.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int, c.c_void_p, c.c_int64,
+                                             c.c_void_p]
+        lib.ffs_comm_unique_id.restype = c.c_int
+        lib.ffs_comm_unique_id.argtypes = [c.c_void_p]
+        lib.ffs_comm_create.restype = c.c_int
+        lib.ffs_comm_create.argtypes = [c.c_int, c.c_int, c.c_int, c.c_void_p, c.POINTER(c.c_void_p)]
+        lib.ffs_gather_results.restype = c.c_int
+        lib.ffs_gather_results.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        lib.ffs_comm_destroy.restype = c.c_int
+        lib.ffs_comm_destroy.argtypes = [c.c_void_p]
         lib.ffs_plan_profile.restype = c.c_int
         lib.ffs_plan_profile.argtypes = [c.c_void_p, c.c_int]
         lib.ffs_plan_profile_read.restype = c.c_int
@@ -237,39 +260,69 @@ class Plan:
             cand_out.data_ptr(), pair_out.data_ptr(), st,
         ))
 
-    def correlate_full(self, dtype: int, ref, ref_levels, a, a_levels, b=None, b_levels=(0.0, 1.0)):
-        """Raw fp32 correlation arrays out_a[m], out_b[m] (m = lag mod n_fft) as CUDA tensors."""
+    def correlate_full(self, dtype: int, ref, ref_levels, a, a_levels, b=None, b_levels=(0.0, 1.0), lens=None):
+        """Raw fp32 correlation arrays out_a[m], out_b[m] (m = lag mod n_fft) as CUDA tensors.  ``lens`` =
+        (R, Sa[, Sb]) in samples when the tensors are bit-packed (default: the tensors' element counts)."""
         torch = require_gpu()
         out_a = torch.empty(self.n_fft, dtype=torch.float32, device=ref.device)
         out_b = torch.empty(self.n_fft, dtype=torch.float32, device=ref.device) if b is not None else None
+        n_ref, n_a = (ref.numel(), a.numel()) if lens is None else (int(lens[0]), int(lens[1]))
+        n_b = 0 if b is None else (b.numel() if lens is None else int(lens[2]))
         check(self.lib.ffs_correlate_full(
             self.handle, dtype,
-            ref.data_ptr(), ref.numel(), float(ref_levels[0]), float(ref_levels[1]),
-            a.data_ptr(), a.numel(), float(a_levels[0]), float(a_levels[1]),
-            b.data_ptr() if b is not None else None, b.numel() if b is not None else 0,
+            ref.data_ptr(), n_ref, float(ref_levels[0]), float(ref_levels[1]),
+            a.data_ptr(), n_a, float(a_levels[0]), float(a_levels[1]),
+            b.data_ptr() if b is not None else None, n_b,
             float(b_levels[0]), float(b_levels[1]),
             out_a.data_ptr(), out_b.data_ptr() if out_b is not None else None, current_stream_ptr(torch),
         ))
         return out_a, out_b
 
 
-_plans: Dict[Tuple[int, int, int, int, int], Plan] = {}
-_plans_lock = threading.Lock()
+class _PlanCache(threading.local):
+    """Per-thread plan cache (a plan may be driven by one host thread at a time; the reference runs
+    detectors/aligners from a small thread pool, speech_transformers.py:872-873).  Thread-local storage
+    dies with its thread, so a worker that exits releases its plans (``Plan.__del__`` destroys them);
+    within a thread the cache is an LRU bounded by an HBM budget."""
+
+    def __init__(self) -> None:
+        self.plans: "Dict[Tuple[int, int, int, int], Plan]" = {}
+        self.order: list = []
+
+
+_plan_cache = _PlanCache()
+PLAN_CACHE_BYTES = int(os.environ.get("FFS_PLAN_CACHE_BYTES", str(8 << 30)))  # per thread
 
 
 def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Optional[int] = None) -> Plan:
-    """Plan cache keyed by (thread, device, n_fft, pairs_in_flight, max_cand).  A plan owns one
-    workspace and may be driven by one host thread at a time, so every Python thread gets its own
-    (the reference runs detectors/aligners from a small thread pool, speech_transformers.py:872-873)."""
+    """Cached plan for (device, n_fft, pairs_in_flight, max_cand) of the calling thread."""
     torch = require_gpu()
     dev = torch.cuda.current_device() if device is None else int(device)
-    key = (threading.get_ident(), dev, int(n_fft), int(pairs_in_flight), int(max_cand))
-    with _plans_lock:
-        plan = _plans.get(key)
-        if plan is None:
-            plan = Plan(n_fft, pairs_in_flight, max_cand, dev)
-            _plans[key] = plan
-        return plan
+    key = (dev, int(n_fft), int(pairs_in_flight), int(max_cand))
+    cache = _plan_cache
+    plan = cache.plans.get(key)
+    if plan is None:
+        plan = Plan(n_fft, pairs_in_flight, max_cand, dev)  # hipMalloc + table upload: no lock held
+        cache.plans[key] = plan
+    else:
+        cache.order.remove(key)
+    cache.order.append(key)
+    # evict least recently used plans beyond the budget (never the one just asked for)
+    total = sum(p.workspace_bytes for p in cache.plans.values())
+    while total > PLAN_CACHE_BYTES and len(cache.order) > 1:
+        old = cache.order.pop(0)
+        victim = cache.plans.pop(old)
+        total -= victim.workspace_bytes
+        victim.close()
+    return plan
+
+
+def clear_plan_cache() -> None:
+    """Destroy the calling thread's cached plans (frees their HBM)."""
+    for plan in _plan_cache.plans.values():
+        plan.close()
+    _plan_cache.plans.clear()
+    _plan_cache.order.clear()
 
 
 def vad_energy(pcm, frame_len: int, threshold_db: float, non_speech_label: float):
@@ -330,14 +383,109 @@ def raster_intervals(start_us, end_us, is_metadata, ratio, sample_rate, start_se
     return iv[:n]
 
 
-def rasterize_subtitles(start_us, end_us, is_metadata, ratio, sample_rate=100.0, start_seconds=0.0):
-    """0/1 uint8 CUDA tensor of the subtitle track rescaled by ``ratio`` (see ffs_rasterize_subtitles)."""
+def rasterize_subtitles(start_us, end_us, is_metadata, ratio, sample_rate=100.0, start_seconds=0.0, packed=False):
+    """The subtitle track rescaled by ``ratio`` as a CUDA tensor: 0/1 bytes (uint8[n]), or with
+    ``packed`` one bit per sample (int32[ceil(n/32)], FFS_DTYPE_U1) -- returns (tensor, n) then."""
     torch = require_gpu()
     start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
     n = raster_length(end_us, ratio, sample_rate)
-    out = torch.empty(n, dtype=torch.uint8, device="cuda")
-    check(load().ffs_rasterize_subtitles(start_us.ctypes.data, end_us.ctypes.data,
-                                         None if meta is None else meta.ctypes.data, start_us.size, float(ratio),
-                                         float(sample_rate), float(start_seconds), out.data_ptr(), n,
-                                         current_stream_ptr(torch)))
+    fn = load().ffs_rasterize_subtitles_bits if packed else load().ffs_rasterize_subtitles
+    out = torch.empty((n + 31) // 32, dtype=torch.int32, device="cuda") if packed else \
+        torch.empty(n, dtype=torch.uint8, device="cuda")
+    check(fn(start_us.ctypes.data, end_us.ctypes.data, None if meta is None else meta.ctypes.data, start_us.size,
+             float(ratio), float(sample_rate), float(start_seconds), out.data_ptr(), n, current_stream_ptr(torch)))
+    return (out, n) if packed else out
+
+
+def packed_words(n: int) -> int:
+    return (int(n) + 31) // 32
+
+
+def pack_bits(src, threshold: float = 0.5, out=None):
+    """FFS_DTYPE_U1 image (int32 CUDA tensor of ceil(n/32) words) of a two-level CUDA vector:
+    uint8 -> bit = (byte != 0); float32 -> bit = (x > threshold)."""
+    torch = require_gpu()
+    n = src.numel()
+    if src.dtype == torch.uint8:
+        dt = FFS_DTYPE_U8
+    elif src.dtype == torch.float32:
+        dt = FFS_DTYPE_F32
+    else:
+        raise TypeError("pack_bits needs a uint8 or float32 tensor, got %s" % src.dtype)
+    if out is None:
+        out = torch.empty(packed_words(n), dtype=torch.int32, device=src.device)
+    elif out.numel() * out.element_size() < packed_words(n) * 4:
+        raise ValueError("output too small")
+    if n:
+        check(load().ffs_pack_bits(src.data_ptr(), dt, n, float(threshold), out.data_ptr(), current_stream_ptr(torch)))
     return out
+
+
+def unpack_bits(words, n: int):
+    """uint8 0/1 CUDA tensor of the first n samples of a FFS_DTYPE_U1 vector (torch ops; diagnostics and
+    the boundary scan -- the hot kernels read the packed words directly)."""
+    torch = require_gpu()
+    w = words.view(torch.int32).reshape(-1)
+    shifts = torch.arange(32, device=w.device, dtype=torch.int32)
+    return ((w[:, None] >> shifts[None, :]) & 1).to(torch.uint8).reshape(-1)[:n]
+
+
+def scatter_segments(labels, src_off, dst_start, seg_len, out_len: int):
+    """float32 CUDA vector of ``out_len`` zeros with labels[src_off[i]:src_off[i]+seg_len[i]] copied to
+    dst_start[i] for every sampled window (see ffs_scatter_segments)."""
+    torch = require_gpu()
+    src_off = np.ascontiguousarray(src_off, dtype=np.int64)
+    dst_start = np.ascontiguousarray(dst_start, dtype=np.int64)
+    seg_len = np.ascontiguousarray(seg_len, dtype=np.int64)
+    if not (src_off.size == dst_start.size == seg_len.size):
+        raise ValueError("segment arrays must have the same length")
+    if src_off.size and int((src_off + seg_len).max()) > labels.numel():
+        raise ValueError("segment reaches beyond the label buffer")
+    out = torch.empty(int(out_len), dtype=torch.float32, device=labels.device)
+    check(load().ffs_scatter_segments(labels.data_ptr() if labels.numel() else None, src_off.ctypes.data,
+                                      dst_start.ctypes.data, seg_len.ctypes.data, int(src_off.size), out.data_ptr(),
+                                      int(out_len), current_stream_ptr(torch)))
+    return out
+
+
+class Comm:
+    """RCCL communicator behind ``ffs_gather_results`` (one per process / GPU).  ``unique_id()`` on rank 0,
+    publish the 128 bytes (e.g. through torch.distributed's store), then ``Comm(rank, world, id)`` everywhere."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        check(load().ffs_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, rank: int, world: int, uid: bytes, device: Optional[int] = None) -> None:
+        torch = require_gpu()
+        self.lib = load()
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        if len(uid) != 128:
+            raise ValueError("unique id must be 128 bytes")
+        handle = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(uid, 128)
+        check(self.lib.ffs_comm_create(self.device, self.rank, self.world, buf, ctypes.byref(handle)))
+        self.handle = handle
+
+    def gather_pair_results(self, local, out=None):
+        """All-gather this rank's uint8 tensor of n*24 result bytes; returns world*n*24 bytes in rank order."""
+        torch = require_gpu()
+        n_local = local.numel() // 24
+        if out is None:
+            out = torch.empty(self.world * n_local * 24, dtype=torch.uint8, device=local.device)
+        check(self.lib.ffs_gather_results(self.handle, local.data_ptr(), n_local, out.data_ptr(), current_stream_ptr(torch)))
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.lib.ffs_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self) -> None:  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

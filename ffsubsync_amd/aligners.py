@@ -6,13 +6,14 @@ transforms, lag-window mask, argmax, max over candidates -- runs in ``libffsalig
 GPU.  Install behind an unmodified ffsubsync with :func:`ffsubsync_amd.install`.
 """
 import logging
+import warnings
 from typing import Any, List, Optional, Sequence, Tuple, Type, Union
 
 import numpy as np
 
 from . import _native
 from .golden_section_search import gss
-from .sklearn_shim import Pipeline, TransformerMixin
+from .sklearn_shim import Pipeline, TransformerMixin  # the reference's own classes when ffsubsync is importable
 
 logger: logging.Logger = logging.getLogger(__name__)
 
@@ -32,17 +33,18 @@ def _as_array(x: Any) -> np.ndarray:
 
 
 class _Vec:
-    """One activity vector as the native library wants it: two-level bytes + (lo, hi) -- on the host
-    or already in HBM (``DeviceRaster``) -- or arbitrary floats."""
+    """One activity vector as the native library wants it: two-level samples + (lo, hi) -- 0/1 bytes on
+    the host, or a ``DeviceRaster`` already in HBM -- or arbitrary floats."""
 
-    __slots__ = ("n", "two_level", "lo", "hi", "bits", "_values", "dev")
+    __slots__ = ("n", "two_level", "lo", "hi", "bits", "_values", "dev", "raster")
 
     def __init__(self, x: Any) -> None:
         self.dev = None
+        self.raster = None
         self._values = None
         if hasattr(x, "bits") and hasattr(x, "lo") and hasattr(x, "hi") and hasattr(x.bits, "data_ptr"):
             # a DeviceRaster: nothing to convert or upload
-            self.dev, self.n = x.bits, int(x.bits.numel())
+            self.raster, self.n = x, len(x)
             self.two_level, self.lo, self.hi, self.bits = True, float(x.lo), float(x.hi), None
             return
         values = _as_array(x)
@@ -62,8 +64,7 @@ class _Vec:
 
     def host_values(self) -> np.ndarray:
         if self._values is None:
-            host = self.dev.cpu().numpy()
-            self._values = np.where(host != 0, self.hi, self.lo).astype(float)
+            self._values = np.asarray(self.raster, dtype=float)
         return self._values
 
 
@@ -97,25 +98,35 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
     if n_fft > _native.MAX_FFT_LENGTH:
         raise ValueError("inputs too long for the device transform (N=%d > 2^24)" % n_fft)
     all_two_level = all(v.two_level for v in vecs)
-    if all_two_level:
-        dtype, elem = _native.FFS_DTYPE_U8, 1
-        chunks = [None if v.dev is not None else v.bits for v in vecs]  # device-resident: no upload
-    else:
-        dtype, elem = _native.FFS_DTYPE_F32, 4
-        chunks = [v.host_values().astype(np.float32) for v in vecs]
-    # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
     lens = np.array([len(v) for v in vecs], dtype=np.int64)
+    keep_alive = []  # device tensors the descriptors point into
+    if all_two_level:
+        # bit-packed (FFS_DTYPE_U1): host vectors are packed here (an eighth of the PCIe bytes), rasters
+        # that live in HBM as bytes are packed on the device, bit-packed rasters are used in place
+        dtype = _native.FFS_DTYPE_U1
+        chunks = [None if v.raster is not None else np.packbits(v.bits, bitorder="little") for v in vecs]
+        for v in vecs:
+            if v.raster is not None:
+                v.dev = v.raster.packed_words()
+                keep_alive.append(v.dev)
+    else:
+        # float inputs (fused / weighted VAD levels): fp32 for the transforms; the winning lags are re-evaluated
+        # in fp64 from these fp32 samples, i.e. for inputs rounded to fp32 (relative 6e-8; the score tolerance
+        # of the contract is 1e-5)
+        dtype = _native.FFS_DTYPE_F32
+        chunks = [v.host_values().astype(np.float32).view(np.uint8) for v in vecs]
+    # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
     offs = np.zeros(len(chunks), dtype=np.int64)
     total = 0
     for i, c in enumerate(chunks):
         if c is None:
             continue
         offs[i] = total
-        total += (c.size * elem + 63) // 64 * 64
+        total += (c.size + 63) // 64 * 64
     host = np.zeros(max(total, 64), dtype=np.uint8)
     for c, o in zip(chunks, offs):
         if c is not None:
-            host[o:o + c.size * elem] = c.view(np.uint8)
+            host[o:o + c.size] = c
     dev = torch.from_numpy(host).cuda()
     ptrs = np.array([v.dev.data_ptr() if c is None else dev.data_ptr() + int(o)
                      for v, c, o in zip(vecs, chunks, offs)], dtype=np.uint64)
@@ -126,9 +137,21 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
     pair_out = torch.empty(n_pairs * 24, dtype=torch.uint8, device=dev.device)
     plan.align_batch(n_pairs, n_cand, dtype, ptrs, lens, lo, hi, max_offset_samples, filter_max_offset,
                      cand_out, pair_out)
-    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(n_pairs, n_cand)
-    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
-    del dev
+    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(n_pairs, n_cand).copy()
+    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE).copy()
+    del dev, keep_alive
+    # A candidate with more tied maxima than its share of the exhaustive pool keeps FFS_FLAG_AMBIGUOUS.  Its
+    # quota depends on how many candidates of the call overflowed, so solve such a pair again on its own
+    # (the whole pool to itself); if it is still ambiguous the answer is the best of a truncated list: say so.
+    amb = np.nonzero((cres["flags"] & _native.FLAG_AMBIGUOUS).any(axis=1))[0]
+    if amb.size and n_pairs > 1:
+        for p in amb:
+            c1, p1 = solve_pairs([pairs[int(p)]], max_offset_samples, filter_max_offset, full_length)
+            cres[p], pres[p] = c1[0], p1[0]
+    elif amb.size:
+        warnings.warn("alignment has more exactly tied best offsets than the device can enumerate "
+                      "(degenerate input such as a silent reference); the reported offset is one of them",
+                      RuntimeWarning)
     return cres, pres
 
 

@@ -1,9 +1,10 @@
 """Batched, device-resident driver for many (reference, candidates) alignment problems.
 
 This is the throughput path behind the headline metric (seven-ratio MaxScoreAligner solves per
-second): all activity vectors of a batch live back to back in one uint8 HBM buffer, one call into
-``ffs_align_batch`` solves every problem, and across GPUs the problems are sharded by pair (no
-data exchange during solves) with one all-gather of the 24-byte results over RCCL.
+second): all activity vectors of a batch live back to back in one HBM buffer -- bit-packed
+(``FFS_DTYPE_U1``, one bit per 10 ms frame) or as 0/1 bytes -- one call into ``ffs_align_batch`` solves
+every problem, and across GPUs the problems are sharded by pair (no data exchange during solves)
+with one all-gather of the 24-byte results over RCCL (``ffs_gather_results``).
 """
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
@@ -11,7 +12,6 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 from . import _native
-from .synth import PairSpec
 
 
 @dataclass
@@ -19,11 +19,12 @@ class DeviceBatch:
     """Packed two-level activity vectors in HBM.  Row p of the descriptor arrays holds pair p's
     reference followed by its candidates."""
 
-    data: "object"  # torch.uint8 CUDA tensor
+    data: "object"  # torch.uint8 CUDA tensor (raw bytes of the buffer, whatever the element type)
     offs: np.ndarray  # [n_pairs, 1+n_cand] byte offsets into data
-    lens: np.ndarray  # [n_pairs, 1+n_cand]
+    lens: np.ndarray  # [n_pairs, 1+n_cand] samples
     lo: np.ndarray
     hi: np.ndarray
+    dtype: int = _native.FFS_DTYPE_U8
 
     @property
     def n_pairs(self) -> int:
@@ -39,23 +40,42 @@ class DeviceBatch:
         rows = np.arange(self.n_pairs)
         cols = 1 + np.asarray(index, dtype=np.int64)
         pick = lambda a: np.ascontiguousarray(np.stack([a[:, 0], a[rows, cols]], axis=1))
-        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi))
+        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi), self.dtype)
 
-    def required_fft_length(self, max_offset_samples: Optional[int] = None) -> int:
-        """Plan length for the whole batch: the reference's N = 2^ceil(log2(R+S)) without a lag window,
-        the alias-free (possibly shorter) length with one (``_native.plan_length``)."""
+    def required_fft_length(self, max_offset_samples: Optional[int] = None, reference_length: bool = False) -> int:
+        """Plan length for the whole batch: the shortest alias-free transform for the lags the solve has
+        to evaluate (``_native.plan_length``), or with ``reference_length`` the reference's own
+        N = 2^ceil(log2(R+S))."""
         n = 2
         for p in range(self.n_pairs):
             for j in range(1, self.offs.shape[1]):
-                n = max(n, _native.plan_length(int(self.lens[p, 0]), int(self.lens[p, j]), max_offset_samples))
+                r, s = int(self.lens[p, 0]), int(self.lens[p, j])
+                n = max(n, _native.fft_length(r, s) if reference_length else _native.plan_length(r, s, max_offset_samples))
         return n
 
+    def to_bits(self) -> "DeviceBatch":
+        """The same batch bit-packed (FFS_DTYPE_U1): one device pass over the byte buffer.  Vector offsets
+        are multiples of 64 bytes, so every packed vector starts on an 8-byte boundary."""
+        if self.dtype == _native.FFS_DTYPE_U1:
+            return self
+        if self.dtype != _native.FFS_DTYPE_U8:
+            raise ValueError("only 0/1 byte batches can be bit-packed")
+        assert not (self.offs % 64).any() and self.data.numel() % 64 == 0
+        words = _native.pack_bits(self.data)
+        return DeviceBatch(words.view(self.data.dtype), self.offs // 8, self.lens, self.lo, self.hi, _native.FFS_DTYPE_U1)
 
-def pack_pairs(pairs) -> DeviceBatch:
+
+def _layout(lens: np.ndarray, bytes_per_vec: np.ndarray):
+    padded = (bytes_per_vec + 63) // 64 * 64
+    offs = np.concatenate([[0], np.cumsum(padded.ravel())[:-1]]).reshape(lens.shape).astype(np.int64)
+    return offs, int(padded.sum())
+
+
+def pack_pairs(pairs, packed: bool = True) -> DeviceBatch:
     """DeviceBatch from HBM-resident two-level vectors: ``pairs`` is a list of
-    (reference, [candidates]) whose items expose ``.bits`` (uint8 CUDA tensor), ``.lo`` and ``.hi``
-    (e.g. ``subtitle_raster.DeviceRaster``).  The vectors are copied device-to-device into one
-    buffer at 64-byte aligned offsets."""
+    (reference, [candidates]) of ``subtitle_raster.DeviceRaster`` objects (bytes or bit-packed).  The
+    vectors are copied device-to-device into one buffer at 64-byte aligned offsets, bit-packed by
+    default."""
     torch = _native.require_gpu()
     n_pairs, n_vec = len(pairs), 1 + len(pairs[0][1])
     flat = []
@@ -64,15 +84,16 @@ def pack_pairs(pairs) -> DeviceBatch:
             raise ValueError("all pairs need the same number of candidates")
         flat.append(ref)
         flat.extend(cands)
-    lens = np.array([int(v.bits.numel()) for v in flat], dtype=np.int64).reshape(n_pairs, n_vec)
-    padded = (lens + 63) // 64 * 64
-    offs = np.concatenate([[0], np.cumsum(padded.ravel())[:-1]]).reshape(n_pairs, n_vec).astype(np.int64)
-    data = torch.zeros(int(padded.sum()), dtype=torch.uint8, device=flat[0].bits.device)
-    for v, o in zip(flat, offs.ravel()):
-        data[int(o): int(o) + int(v.bits.numel())] = v.bits
+    lens = np.array([len(v) for v in flat], dtype=np.int64).reshape(n_pairs, n_vec)
+    nbytes = (lens + 31) // 32 * 4 if packed else lens
+    offs, total = _layout(lens, nbytes)
+    data = torch.zeros(total, dtype=torch.uint8, device=flat[0].bits.device)
+    for v, o, nb in zip(flat, offs.ravel(), nbytes.ravel()):
+        src = v.packed_words().view(torch.uint8) if packed else v.bytes01()
+        data[int(o): int(o) + int(nb)] = src[: int(nb)]
     lo = np.array([v.lo for v in flat], dtype=np.float64).reshape(n_pairs, n_vec)
     hi = np.array([v.hi for v in flat], dtype=np.float64).reshape(n_pairs, n_vec)
-    return DeviceBatch(data, offs, lens, lo, hi)
+    return DeviceBatch(data, offs, lens, lo, hi, _native.FFS_DTYPE_U1 if packed else _native.FFS_DTYPE_U8)
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -80,45 +101,6 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     per = (n_items + world - 1) // world
     lo = min(rank * per, n_items)
     return lo, min(lo + per, n_items)
-
-
-def build_device_batch(specs: Sequence[PairSpec], device=None, chunk_pairs: int = 32) -> DeviceBatch:
-    """Rasterise interval lists straight into HBM with torch ops (index_add + cumsum)."""
-    torch = _native.require_gpu()
-    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
-    n_pairs = len(specs)
-    n_vec = 1 + len(specs[0].cand_len)
-    lens = np.zeros((n_pairs, n_vec), dtype=np.int64)
-    lo = np.zeros((n_pairs, n_vec), dtype=np.float64)
-    hi = np.ones((n_pairs, n_vec), dtype=np.float64)
-    for p, sp in enumerate(specs):
-        lens[p, 0] = sp.ref_len
-        lens[p, 1:] = sp.cand_len
-        hi[p, 1:] = sp.cand_amp
-    padded = (lens + 63) // 64 * 64
-    offs = np.concatenate([[0], np.cumsum(padded.ravel())[:-1]]).reshape(n_pairs, n_vec).astype(np.int64)
-    total = int(padded.sum())
-    data = torch.zeros(total, dtype=torch.uint8, device=device)
-    for p0 in range(0, n_pairs, chunk_pairs):
-        p1 = min(p0 + chunk_pairs, n_pairs)
-        base = int(offs[p0, 0])
-        end = int(offs[p1 - 1, -1] + padded[p1 - 1, -1])
-        starts, ends = [], []
-        for p in range(p0, p1):
-            sp = specs[p]
-            for v, (s, e) in enumerate([(sp.ref_starts, sp.ref_ends)] + list(zip(sp.cand_starts, sp.cand_ends))):
-                n = int(lens[p, v])
-                o = int(offs[p, v]) - base
-                starts.append(np.clip(s, 0, n) + o)
-                ends.append(np.clip(e, 0, n) + o)
-        starts = torch.from_numpy(np.concatenate(starts)).to(device)
-        ends = torch.from_numpy(np.concatenate(ends)).to(device)
-        delta = torch.zeros(end - base + 1, dtype=torch.int32, device=device)
-        delta.index_add_(0, starts, torch.ones_like(starts, dtype=torch.int32))
-        delta.index_add_(0, ends, -torch.ones_like(ends, dtype=torch.int32))
-        data[base:end] = (torch.cumsum(delta[:-1], 0) > 0).to(torch.uint8)
-        del delta
-    return DeviceBatch(data, offs, lens, lo, hi)
 
 
 class BatchAligner:
@@ -145,7 +127,7 @@ class BatchAligner:
         if n > 0:
             sl = slice(pair_lo, pair_hi)
             ptrs = (batch.data.data_ptr() + batch.offs[sl]).astype(np.uint64)
-            self.plan.align_batch(n, self.n_cand, _native.FFS_DTYPE_U8, ptrs.ravel(), batch.lens[sl].ravel(),
+            self.plan.align_batch(n, self.n_cand, batch.dtype, ptrs.ravel(), batch.lens[sl].ravel(),
                                   batch.lo[sl].ravel(), batch.hi[sl].ravel(), self.max_offset_samples,
                                   self.max_offset_samples, cand_out, pair_out)
         return cand_out, pair_out
@@ -159,15 +141,33 @@ class BatchAligner:
         return cres, pres
 
 
-def gather_pair_results(local, n_total: int, world: int, group=None):
+def gather_pair_results(local, n_total: int, world: int, group=None, comm: "Optional[_native.Comm]" = None):
     """All-gather per-pair results (one 24-byte record per pair) from every rank -- the only
     collective on the path.  ``local`` is a uint8 tensor holding this rank's ceil(n/world) records
-    (zero-padded); returns a uint8 tensor with all n_total records, in pair order."""
+    (zero-padded); returns a uint8 tensor with all n_total records, in pair order.  With ``comm`` the
+    gather is the library's own ``ffs_gather_results`` (RCCL C API); otherwise torch.distributed's
+    all_gather_into_tensor on ``group`` (RCCL on GPUs, gloo in the CPU tests)."""
     import torch
-    import torch.distributed as dist
 
     per = (n_total + world - 1) // world
     assert local.numel() == per * 24
-    out = torch.empty(world * per * 24, dtype=torch.uint8, device=local.device)
-    dist.all_gather_into_tensor(out, local, group=group)
+    if comm is not None:
+        out = comm.gather_pair_results(local)
+    else:
+        import torch.distributed as dist
+
+        out = torch.empty(world * per * 24, dtype=torch.uint8, device=local.device)
+        dist.all_gather_into_tensor(out, local, group=group)
     return out[: n_total * 24]
+
+
+def make_comm(rank: int, world: int, store_key: str = "ffs_comm_id") -> "_native.Comm":
+    """``ffs_comm_create`` bootstrapped through torch.distributed's default store: rank 0 publishes the
+    128-byte RCCL unique id, everyone joins."""
+    import torch.distributed as dist
+
+    store = dist.distributed_c10d._get_default_store()
+    if rank == 0:
+        store.set(store_key, _native.Comm.unique_id())
+    uid = bytes(store.get(store_key))
+    return _native.Comm(rank, world, uid)

@@ -38,6 +38,10 @@ struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: 
     // padding and `a` may point in front of the vector there (block-segmented mode: the stretch of the
     // reference that block 0 meets starts |d_lo| samples before the vector).  Never dereferenced.
     int32_t lead_a, lead_b;
+    // bit-packed inputs (DT == 2) only: sample n of the transform input is bit off + n of the 32-bit
+    // little-endian word array at a / b (bit i of the array = (word[i >> 5] >> (i & 31)) & 1); off may be
+    // negative in front of `lead`.  Byte / float inputs move the pointer instead and leave these 0.
+    int32_t off_a, off_b;
 };
 
 struct CandDesc {  // one candidate (one FFTAligner solve)
@@ -46,11 +50,20 @@ struct CandDesc {  // one candidate (one FFTAligner solve)
     int32_t S, R;
     int32_t d_lo, d_hi;  // inclusive lag window (already intersected with [-S, Nref-1-S])
     int32_t n_ref;       // the reference's transform length for (R, S)
-    int32_t flags;       // FFS_FLAG_EMPTY_WINDOW preset by the host
+    int32_t flags;       // bit 0 preset by the host: no lag for the transform pipeline (see CAND_*)
     float margin;        // fp32 tie margin for nominee collection
-    float pad;
+    int32_t d_zero;      // CAND_HAS_ZERO: largest lag of the reference's window with an empty overlap
     double s0, s1, r0, r1;  // mapped two-level values (fp64, as the reference computes them)
 };
+
+// CandDesc.flags.  The transforms only ever evaluate lags with a non-empty overlap, d in (-S, R): every
+// other lag of the reference's window has c(d) = 0 exactly (its `convolve` entries there are fp64
+// rounding noise around 0), so they are represented by ONE virtual nominee (score 0, lag d_zero = the
+// largest such lag = the first such k, np.argmax's pick among equals) that k_finalize_cands compares
+// with the best real lag.  This is what lets a windowless solve use a transform of length >= R+S-1
+// instead of the reference's 2^ceil(log2(R+S)).
+constexpr int CAND_NO_LAGS = 1;    // nothing for the transform / nominee kernels to do
+constexpr int CAND_HAS_ZERO = 16;  // d_zero is valid
 
 struct BlockNom {
     float bmax;
@@ -105,6 +118,8 @@ struct PoolBest {  // per candidate
     unsigned long long key;  // order-preserving image of the best exact score (0 = none)
     int32_t d;               // largest lag attaining it, stored as d + POOL_D_BIAS (0 = none)
     float val;
+    unsigned int count;      // entries this candidate asked for (each candidate has its own quota)
+    unsigned int overflow;   // != 0: some of its lags did not fit -> the candidate stays FFS_FLAG_AMBIGUOUS
 };
 
 FFS_DEV unsigned long long score_key(double x) {
@@ -295,6 +310,36 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(ba[q]), "+v"(bb[q]));
+        float xa[16], xb[16];
+        map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
+        map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
+    } else if constexpr (DT == 2) {
+        // Bit-packed inputs: the tile's L rows x C columns are L windows of C (+ up to 31 alignment) bits
+        // per vector.  The block copies each window's NW dwords to LDS first (a few coalesced dword loads
+        // per thread, an eighth of the byte path's input lines), then every thread picks its 2 x 16 bits.
+        constexpr int NW = (C + 62) / 32;
+        unsigned* stage = reinterpret_cast<unsigned*>(smem);  // [2][L][NW]; the FFT's first LDS write is behind a barrier
+        const int col0 = tile * C;
+        for (int i = threadIdx.x; i < 2 * L * NW; i += LT * C) {
+            const int h = i / (L * NW), row = (i / NW) % L, j = i % NW;
+            const unsigned* src = reinterpret_cast<const unsigned*>(h ? d.b : d.a);
+            const int off = h ? d.off_b : d.off_a, len = h ? d.len_b : d.len_a, lead = h ? d.lead_b : d.lead_a;
+            const int w = ((off + row * N2 + col0) >> 5) + j;  // arithmetic shift: floor
+            unsigned val = 0;  // only dwords that hold a valid sample (bits off+lead .. off+len-1) are touched
+            if (len > lead && w >= ((off + lead) >> 5) && w <= ((off + len - 1) >> 5)) val = src[w];
+            stage[i] = val;
+        }
+        __syncthreads();
+        unsigned ba[16], bb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = u + LT * q;
+            const int pa = ((d.off_a + row * N2 + col0) & 31) + c, pb = ((d.off_b + row * N2 + col0) & 31) + c;
+            ba[q] = (stage[row * NW + (pa >> 5)] >> (pa & 31)) & 1u;
+            bb[q] = (stage[(L + row) * NW + (pb >> 5)] >> (pb & 31)) & 1u;
+        }
         float xa[16], xb[16];
         map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
         map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
@@ -705,7 +750,7 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
         const bool present = (2 * kp + h) < n_cand;
         const CandDesc& cd = cands[cand0 + (present ? 2 * kp + h : 0)];
         w.lo[h] = cd.d_lo;
-        w.hi[h] = (present && !(cd.flags & 1)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
+        w.hi[h] = (present && !(cd.flags & CAND_NO_LAGS)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
         w.marg[h] = cd.margin;
     }
     return w;
@@ -804,10 +849,13 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
 
 // Exhaustive variant for flagged candidates: append every in-window value within the margin of the
 // candidate's global fp32 maximum to the pool.
+// Every flagged candidate may append `quota` lags (the pool's capacity divided by the number of flagged
+// candidates of the call's sub-batches), so one degenerate pair -- a silent reference, a wide window --
+// cannot push its batch neighbours out of the pool: a candidate's answer never depends on the others.
 template <int NV, class MOf>
 FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int nN, const int (&ci)[2],
                                const bool (&want)[2], const float (&thr)[2], PoolHeader* __restrict__ pool,
-                               PoolEntry* __restrict__ entries) {
+                               PoolEntry* __restrict__ entries, PoolBest* __restrict__ best, unsigned quota) {
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const int m = m_of(q);
@@ -818,7 +866,8 @@ FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int n
             const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
             if (ok && val >= thr[h]) {
-                const unsigned slot = atomicAdd(&pool->count, 1u);
+                const unsigned mine = atomicAdd(&best[ci[h]].count, 1u);
+                const unsigned slot = mine < quota ? atomicAdd(&pool->count, 1u) : 0xffffffffu;
                 if (slot < pool->capacity) {
                     PoolEntry e;
                     e.ci = ci[h];
@@ -827,6 +876,8 @@ FFS_DEV void block_collect_all(const cf* v, MOf m_of, const WinParams& wp, int n
                     e.pad = 0;
                     e.score = 0.0;
                     entries[slot] = e;
+                } else {
+                    best[ci[h]].overflow = 1u;
                 }
             }
         }
@@ -865,7 +916,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
                                                          float* __restrict__ out_b, const NomList* __restrict__ noms,
                                                          PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries,
                                                          int log2CL, const cf* __restrict__ tw3,
-                                                         const int* __restrict__ xlist) {
+                                                         const int* __restrict__ xlist, PoolBest* __restrict__ pbest,
+                                                         int pool_shares) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -920,7 +972,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
     if (MODE == 2) {
         block_collect_all<16>(
-            v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, xci, xwant, xthr, pool, entries);
+            v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, xci, xwant, xthr, pool, entries, pbest,
+            pool->capacity / (unsigned)(pool_shares * (xlist[0] > 0 ? xlist[0] : 1)));
         continue;
     }
     block_nominees<16, NW>(
@@ -958,7 +1011,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                                                                 const NomList* __restrict__ noms,
                                                                 PoolHeader* __restrict__ pool,
                                                                 PoolEntry* __restrict__ entries, int log2CL,
-                                                                const int* __restrict__ xlist, int seg, int seg_shift) {
+                                                                const int* __restrict__ xlist, int seg, int seg_shift,
+                                                                PoolBest* __restrict__ pbest, int pool_shares) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -1029,7 +1083,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, seg_shift, seg);
     if (EXH) {
         block_collect_all<NVF>(
-            val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries);
+            val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries, pbest,
+            pool->capacity / (unsigned)(pool_shares * (xlist[0] > 0 ? xlist[0] : 1)));
         continue;
     }
     block_nominees<NVF, NW>(
@@ -1052,7 +1107,7 @@ __global__ __launch_bounds__(64) void k_nominees(const BlockNom* __restrict__ bn
     const CandDesc& cd = cands[ci];
     NomList& nl = noms[ci];
     const int lane = threadIdx.x;
-    if (cd.flags & 1) {
+    if (cd.flags & CAND_NO_LAGS) {
         if (lane == 0) {
             nl.count = 0;
             nl.flags = 1;
@@ -1110,6 +1165,42 @@ FFS_DEV unsigned nz_flags(unsigned w) {  // bit 7 of every byte that is non-zero
     return (((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) & 0x80808080u;
 }
 
+// Bit-packed vectors (DT == 2): bit i of a vector = (word[i >> 5] >> (i & 31)) & 1.
+FFS_DEV unsigned get_bit(const void* p, int i) { return (reinterpret_cast<const unsigned*>(p)[i >> 5] >> (i & 31)) & 1u; }
+
+// Exact counts over i in [a, b) of bit-packed s and r:  n11 += #(s[i] & r[i+d]), n1x += #s[i], nx1 += #r[i+d].
+// Thread tid of nt takes every nt-th group of four s-words (128 samples); the r side is funnel-shifted into
+// place (v_alignbit).  Requires 0 <= a, b <= S and 0 <= a + d, b + d <= R.
+FFS_DEV void bit_counts(const void* sp, const void* rp, int R, int d, int a, int b, int tid, int nt, unsigned& n11,
+                        unsigned& n1x, unsigned& nx1) {
+    if (a >= b) return;
+    const unsigned* __restrict__ s = reinterpret_cast<const unsigned*>(sp);
+    const unsigned* __restrict__ r = reinterpret_cast<const unsigned*>(rp);
+    const int w_first = a >> 5, w_last = (b - 1) >> 5, wr_max = (R - 1) >> 5;
+    for (int w0 = w_first + 4 * tid; w0 <= w_last; w0 += 4 * nt) {
+        const int bit0 = 32 * w0 + d;  // r bit under bit 0 of s-word w0
+        const int jr = bit0 >> 5;      // arithmetic shift: floor
+        const unsigned sh = (unsigned)bit0 & 31u;
+        unsigned rw[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rw[k] = (jr + k >= 0 && jr + k <= wr_max) ? r[jr + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int w = w0 + k;
+            if (w <= w_last) {
+                unsigned m = 0xffffffffu;
+                if (w == w_first) m &= 0xffffffffu << (a & 31);
+                if (w == w_last) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
+                const unsigned sw = s[w] & m;
+                const unsigned rv = __builtin_amdgcn_alignbit(rw[k + 1], rw[k], sh) & m;
+                n11 += __popc(sw & rv);
+                n1x += __popc(sw);
+                nx1 += __popc(rv);
+            }
+        }
+    }
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
                                                  RescoreAcc* __restrict__ acc, int first_cand) {
@@ -1118,7 +1209,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
     const int count = nl.count;
     if (count <= 0) return;
     const CandDesc& cd = cands[ci];
-    constexpr int VEC = (DT == 0) ? 16 : 4;  // elements per 16-byte load
+    constexpr int VEC = (DT == 0) ? 16 : (DT == 2 ? 128 : 4);  // elements per 16-byte load
     for (int ni = 0; ni < count; ++ni) {
         const int d = nl.d[ni];
         const int i0 = d < 0 ? -d : 0;
@@ -1130,7 +1221,21 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
         const int b = (a + seg) < i1 ? (a + seg) : i1;
         if (a >= b) continue;
         RescoreAcc& out = acc[(size_t)ci * KNOM + ni];
-        if (DT == 0) {
+        if (DT == 2) {
+            unsigned int n11 = 0, n1x = 0, nx1 = 0;
+            bit_counts(cd.s, cd.r, cd.R, d, a, b, (int)threadIdx.x, 256, n11, n1x, nx1);
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                n11 += __shfl_xor(n11, sft, 64);
+                n1x += __shfl_xor(n1x, sft, 64);
+                nx1 += __shfl_xor(nx1, sft, 64);
+            }
+            if ((threadIdx.x & 63) == 0 && (n1x | nx1)) {
+                atomicAdd(&out.n11, n11);
+                atomicAdd(&out.n1x, n1x);
+                atomicAdd(&out.nx1, nx1);
+            }
+        } else if (DT == 0) {
             const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
             const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
             unsigned int n11 = 0, n1x = 0, nx1 = 0;
@@ -1197,7 +1302,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
 }
 
 FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
-    if (dt != 0) {
+    if (dt == 1) {
         double sum = 0.0;
         for (int i = 0; i < RSEG; ++i) sum += a.part[i];
         return sum;
@@ -1224,11 +1329,12 @@ __global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict
         const int i0 = d < 0 ? -d : 0;
         const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
         double score = 0.0;
-        if (DT == 0) {
+        if (DT != 1) {
             const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
-            const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + d;
+            const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + (DT == 0 ? d : 0);
             unsigned int n11 = 0, n1x = 0, nx1 = 0;
-            for (int i = i0 + 16 * (int)threadIdx.x; i < i1; i += 16 * 256) {
+            if (DT == 2) bit_counts(cd.s, cd.r, cd.R, d, i0, i1, (int)threadIdx.x, 256, n11, n1x, nx1);
+            for (int i = i0 + 16 * (int)threadIdx.x; DT == 0 && i < i1; i += 16 * 256) {
                 if (i + 16 <= i1) {
                     uint4 sv, rv;
                     __builtin_memcpy(&sv, s + i, 16);
@@ -1298,6 +1404,18 @@ __global__ void k_pool_pick(const PoolHeader* __restrict__ pool, const PoolEntry
     }
 }
 
+// The window's lags with an empty overlap (exact value 0, see CAND_HAS_ZERO) against the best real lag:
+// larger score wins, equal scores go to the larger lag (np.argmax's first k).
+FFS_DEV void apply_zero_rule(const CandDesc& cd, CandResult& r) {
+    if (!(cd.flags & CAND_HAS_ZERO)) return;
+    if ((r.flags & 1) || 0.0 > r.score || (0.0 == r.score && (long long)cd.d_zero > r.offset)) {
+        r.score = 0.0;
+        r.offset = cd.d_zero;
+        r.score_f32 = 0.0f;
+        r.flags &= ~(1 | 2);
+    }
+}
+
 // one thread per candidate: best nominee by exact score (ties -> largest d = first k)
 __global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
                                  const RescoreAcc* __restrict__ acc, CandResult* __restrict__ out, int n, int dt,
@@ -1307,7 +1425,7 @@ __global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomLi
     const CandDesc& cd = cands[ci];
     const NomList& nl = noms[ci];
     CandResult r;
-    if ((cd.flags & 1) || nl.count == 0) {
+    if ((cd.flags & CAND_NO_LAGS) || nl.count == 0) {
         // every lag masked: np.argmax of all -inf is k=0 (aligners.py:45-48)
         r.score = -INFINITY;
         r.offset = (long long)cd.n_ref - 1 - cd.S;
@@ -1331,12 +1449,13 @@ __global__ void k_finalize_cands(const CandDesc* __restrict__ cands, const NomLi
         r.flags = nl.flags & 2;
         // nominee lists overflowed: the exhaustive pool holds every lag within the margin, unless the
         // pool itself overflowed (then the best-of-list answer above stands, flagged ambiguous)
-        if ((nl.flags & 2) && pool->count <= pool->capacity && pbest[ci].key != 0) {
+        if ((nl.flags & 2) && !pbest[ci].overflow && pbest[ci].key != 0) {
             r.score = key_score(pbest[ci].key);
             r.offset = pbest[ci].d - POOL_D_BIAS;
             r.flags = 0;
         }
     }
+    apply_zero_rule(cd, r);
     out[ci] = r;
 }
 
@@ -1378,18 +1497,19 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
     __shared__ int s_d[256];
     double bs = -INFINITY;
     int bd = INT32_MIN;
-    if (!(cd.flags & 1)) {
+    if (!(cd.flags & CAND_NO_LAGS)) {
         for (int d = cd.d_lo + (int)threadIdx.x; d <= cd.d_hi; d += 256) {
             const int i0 = d < 0 ? -d : 0;
             const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
             double sc;
-            if (DT == 0) {
+            if (DT != 1) {
                 const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
                 const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r);
                 RescoreAcc a;
                 a.n11 = a.n1x = a.nx1 = 0;
                 for (int i = i0; i < i1; ++i) {
-                    const unsigned int sb = s[i] != 0, rb = r[i + d] != 0;
+                    const unsigned int sb = (DT == 2) ? get_bit(s, i) : (unsigned)(s[i] != 0);
+                    const unsigned int rb = (DT == 2) ? get_bit(r, i + d) : (unsigned)(r[i + d] != 0);
                     a.n11 += sb & rb;
                     a.n1x += sb;
                     a.nx1 += rb;
@@ -1434,6 +1554,7 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
             r.score_f32 = (float)s_sc[0];
             r.flags = 8;
         }
+        apply_zero_rule(cd, r);
         out[ci] = r;
     }
 }
@@ -1573,6 +1694,73 @@ __global__ __launch_bounds__(256) void k_fill_intervals(const int2* __restrict__
         const int2 se = iv[i];
         for (int k = se.x + lane; k < se.y; k += 64) out[k] = 1;
     }
+}
+
+// bit-packed variant: one wave per interval, one word per lane and step; edge words are masked and every
+// word is OR-ed in (overlapping subtitles share words)
+__global__ __launch_bounds__(256) void k_fill_intervals_bits(const int2* __restrict__ iv, int n, unsigned* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (blockDim.x / 64) + (threadIdx.x / 64);
+    const int nw = gridDim.x * (blockDim.x / 64);
+    for (int i = wave; i < n; i += nw) {
+        const int2 se = iv[i];
+        if (se.y <= se.x) continue;
+        const int w_first = se.x >> 5, w_last = (se.y - 1) >> 5;
+        for (int w = w_first + lane; w <= w_last; w += 64) {
+            unsigned m = 0xffffffffu;
+            if (w == w_first) m &= 0xffffffffu << (se.x & 31);
+            if (w == w_last) m &= 0xffffffffu >> (31 - ((se.y - 1) & 31));
+            atomicOr(&out[w], m);
+        }
+    }
+}
+
+// Two-level vector -> bits: one thread per output word (32 samples).  SRC 0: bytes (!= 0), 1: floats (> thr).
+template <int SRC>
+__global__ __launch_bounds__(256) void k_pack_bits(const void* __restrict__ src, long long n, float thr,
+                                                   unsigned* __restrict__ dst, long long n_words) {
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (long long)gridDim.x * blockDim.x) {
+        const long long i0 = w * 32;
+        unsigned out = 0;
+        if (SRC == 0) {
+            const unsigned char* p = reinterpret_cast<const unsigned char*>(src) + i0;
+            if (i0 + 32 <= n) {
+                unsigned wd[8];
+                __builtin_memcpy(wd, p, 32);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    // non-zero flags of four bytes (bits 7, 15, 23, 31) gathered into one nibble: after >> 7 the
+                    // flags sit at bits 0, 8, 16, 24 and the multiply lines them up at bits 21..24 (no carries)
+                    const unsigned t = nz_flags(wd[k]) >> 7;
+                    out |= (((t * 0x00204081u) >> 21) & 0xfu) << (4 * k);
+                }
+            } else {
+                for (int k = 0; k < 32 && i0 + k < n; ++k) out |= (unsigned)(p[k] != 0) << k;
+            }
+        } else {
+            const float* p = reinterpret_cast<const float*>(src) + i0;
+            for (int k = 0; k < 32 && i0 + k < n; ++k) out |= (unsigned)(p[k] > thr) << k;
+        }
+        dst[w] = out;
+    }
+}
+
+// Sparse reference assembly (MultiSegmentVideoSpeechTransformer, speech_transformers.py:871-890): label runs of
+// the sampled windows copied to their place in the (zeroed) full-length vector, clipped at its end.
+constexpr int SCATTER_MAX = 32;
+struct ScatterSegs {
+    long long src_off[SCATTER_MAX], dst_start[SCATTER_MAX], len[SCATTER_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_scatter_segments(const float* __restrict__ src, ScatterSegs segs, float* __restrict__ out,
+                                                          long long out_len) {
+    const int sgm = blockIdx.y;
+    if (sgm >= segs.n) return;
+    const long long dst = segs.dst_start[sgm];
+    long long len = segs.len[sgm];
+    if (dst + len > out_len) len = out_len - dst;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+        out[dst + i] = src[segs.src_off[sgm] + i];
 }
 
 __global__ void k_bounds_init(long long* b) {

@@ -3,6 +3,7 @@
 //
 // Written for gfx950 (MI355X) only: hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -37,6 +38,21 @@ int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(FFS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
+// run `stmt` with a compile-time DT equal to the runtime element type (0 = bytes, 1 = float, 2 = bit-packed)
+#define FFS_BY_DTYPE(dtype, stmt)              \
+    do {                                       \
+        if ((dtype) == FFS_DTYPE_U8) {         \
+            constexpr int DT = 0;              \
+            stmt;                              \
+        } else if ((dtype) == FFS_DTYPE_F32) { \
+            constexpr int DT = 1;              \
+            stmt;                              \
+        } else {                               \
+            constexpr int DT = 2;              \
+            stmt;                              \
+        }                                      \
+    } while (0)
+
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
 constexpr unsigned kPoolCapacity = 1u << 20;
@@ -65,7 +81,7 @@ int tile_cols(int L) {
 size_t col_lds_bytes(int L) {
     size_t t = (L > 16) ? (size_t)L * tile_cols(L) * sizeof(cf) : 0;
     if (L % 3 == 0) t += (size_t)L * sizeof(cf);  // W_L^k for the radix-3 combine
-    return t < 1024 ? 1024 : t;
+    return t < 2048 ? 2048 : t;  // the byte / bit input staging of pass A needs up to 2 KB on its own
 }
 size_t row_lds_bytes(int L) {
     const int rows = 256 / (L / 16);
@@ -141,6 +157,11 @@ struct ffs_plan {
     void* host_desc = nullptr;                // pinned
     size_t host_desc_bytes = 0;
     hipEvent_t upload_done = nullptr;
+    // The workspace, descriptor and nominee buffers are reused by every call: a call on another stream
+    // than the previous one first waits for that one's last kernel (same-stream calls are ordered anyway).
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool has_last = false;
     int64_t workspace_bytes = 0;
     // kernels whose dynamic-LDS limit has been raised on this plan's device (the attribute is per device)
     mutable std::vector<const void*> lds_configured;
@@ -182,6 +203,29 @@ int ensure_lds(const ffs_plan* p, const void* fn, size_t bytes) {
         if (f == fn) return FFS_OK;
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     p->lds_configured.push_back(fn);
+    return FFS_OK;
+}
+
+// Calls on one plan from different streams: order them (see ffs_plan::last_done).
+int enter_stream(ffs_plan* p, hipStream_t st) {
+    if (p->has_last && p->last_stream != st) HIP_TRY(hipStreamWaitEvent(st, p->last_done, 0));
+    return FFS_OK;
+}
+int leave_stream(ffs_plan* p, hipStream_t st) {
+    HIP_TRY(hipEventRecord(p->last_done, st));
+    p->last_stream = st;
+    p->has_last = true;
+    return FFS_OK;
+}
+
+// Entry points without a plan work on whatever device owns the caller's buffer.
+int use_device_of(const void* dev_ptr) {
+    hipPointerAttribute_t attr;
+    if (dev_ptr && hipPointerGetAttributes(&attr, dev_ptr) == hipSuccess) {
+        HIP_TRY(hipSetDevice(attr.device));
+    } else {
+        (void)hipGetLastError();  // not a tracked allocation: stay on the caller's current device
+    }
     return FFS_OK;
 }
 
@@ -301,6 +345,8 @@ struct PoolArgs {
     const NomList* noms;
     PoolHeader* header;
     PoolEntry* entries;
+    PoolBest* best;
+    int shares;  // sub-batches of the call that share the pool (each flagged candidate's quota is divided by it)
 };
 
 int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t st) {
@@ -327,7 +373,7 @@ int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand,
     dim3 grid(p->N2 / C, MODE == 2 ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
                        cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->twn1, p->xlist);
+                       p->twn1, p->xlist, pa.best, pa.shares);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -372,7 +418,7 @@ int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int firs
     dim3 grid(p->N2 / C, EXH ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
                        p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->xlist, seg, seg_shift);
+                       p->xlist, seg, seg_shift, pa.best, pa.shares);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -405,7 +451,7 @@ int launch_pass_c_pruned(const ffs_plan* p, const CandDesc* cands, int first_can
 // Output bins m2 = m / N2 of the last pass that the lag window [d_lo, d_hi] of a candidate touches
 // (m = d for d >= 0, m = d + N for d < 0), as signed offsets in (-N1/2, N1/2].
 void add_bins(const ffs_plan* p, const CandDesc& cd, std::vector<int>* bins, bool* overflow) {
-    if (cd.flags & FFS_FLAG_EMPTY_WINDOW) return;
+    if (cd.flags & CAND_NO_LAGS) return;
     auto add_range = [&](int64_t m_lo, int64_t m_hi) {
         for (int64_t m2 = m_lo / p->N2; m2 <= m_hi / p->N2; ++m2) {
             int b = (int)m2;
@@ -440,6 +486,7 @@ struct VecView {
     int64_t len;
     double lo, hi;
     int64_t lead = 0;  // positions [0, lead) of the transform input are zero padding (see XformDesc)
+    int64_t off = 0;   // bit-packed vectors: bit index of sample 0 relative to ptr (see XformDesc)
 };
 
 // The reference's lag window for (R, S): allowed k in [kA, kB) of its length-n_ref convolve array
@@ -453,6 +500,29 @@ bool lag_window(int64_t R, int64_t S, int64_t n_ref, int64_t max_off, int64_t* d
     if (kA >= kB) return false;
     *d_hi = n_ref - 1 - S - kA;
     *d_lo = n_ref - S - kB;
+    return true;
+}
+
+// What the transform pipeline has to evaluate of that window: only lags with a non-empty overlap,
+// d in (-S, R).  Every other lag of the window has c(d) = 0 exactly and is represented by the single
+// virtual nominee (0, d_zero) -- d_zero = the largest such lag, i.e. the first such k (see CAND_HAS_ZERO
+// in ffs_kernels.h).  Returns false when the reference's window is empty (everything -inf);
+// *d_lo > *d_hi when the window holds only zero-overlap lags.
+bool overlap_window(int64_t R, int64_t S, int64_t n_ref, int64_t max_off, int64_t* d_lo, int64_t* d_hi, bool* has_zero,
+                    int64_t* d_zero) {
+    int64_t wl = 0, wh = -1;
+    *has_zero = false;
+    *d_zero = 0;
+    if (!lag_window(R, S, n_ref, max_off, &wl, &wh)) return false;
+    if (wh >= R) {
+        *has_zero = true;
+        *d_zero = wh;
+    } else if (wl <= -S) {
+        *has_zero = true;
+        *d_zero = -S;
+    }
+    *d_lo = wl > -S + 1 ? wl : -S + 1;
+    *d_hi = wh < R - 1 ? wh : R - 1;
     return true;
 }
 
@@ -489,14 +559,19 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
     cd->S = (int32_t)S;
     cd->R = (int32_t)R;
     cd->n_ref = (int32_t)n_ref;
-    int64_t d_lo = 0, d_hi = -1;
-    if (!lag_window(R, S, n_ref, max_off, &d_lo, &d_hi)) {
-        cd->flags = FFS_FLAG_EMPTY_WINDOW;
+    int64_t d_lo = 0, d_hi = -1, d_zero = 0;
+    bool has_zero = false;
+    if (!overlap_window(R, S, n_ref, max_off, &d_lo, &d_hi, &has_zero, &d_zero) || d_lo > d_hi) {
+        cd->flags = CAND_NO_LAGS;
         cd->d_lo = 0;
         cd->d_hi = -1;
     } else {
         cd->d_lo = (int32_t)d_lo;
         cd->d_hi = (int32_t)d_hi;
+    }
+    if (has_zero) {
+        cd->flags |= CAND_HAS_ZERO;
+        cd->d_zero = (int32_t)d_zero;
     }
     cd->s0 = mapped(sub.lo);
     cd->s1 = mapped(sub.hi);
@@ -516,6 +591,7 @@ void fill_xform(XformDesc* x, const VecView* a, const VecView* b, const void* sa
     x->a = a->ptr;
     x->len_a = (int32_t)a->len;
     x->lead_a = (int32_t)a->lead;
+    x->off_a = (int32_t)a->off;
     x->a0 = (float)mapped(a->lo);
     x->a1 = (float)mapped(a->hi);
     x->b = safe ? safe : a->ptr;  // absent second candidate: any valid address with length 0 (reads are clamped)
@@ -523,6 +599,7 @@ void fill_xform(XformDesc* x, const VecView* a, const VecView* b, const void* sa
         x->b = b->ptr;
         x->len_b = (int32_t)b->len;
         x->lead_b = (int32_t)b->lead;
+        x->off_b = (int32_t)b->off;
         x->b0 = (float)mapped(b->lo);
         x->b1 = (float)mapped(b->hi);
     }
@@ -533,7 +610,7 @@ void fill_xform(XformDesc* x, const VecView* a, const VecView* b, const void* sa
 extern "C" {
 
 const char* ffs_last_error(void) { return g_err.c_str(); }
-int ffs_version(void) { return 100; }
+int ffs_version(void) { return 200; }
 
 int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len) {
     if (ref_len <= 0 || sub_len <= 0) return 0;
@@ -545,9 +622,11 @@ int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len) {
 
 int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_samples) {
     const int64_t n_ref = ffs_fft_length(ref_len, sub_len);
-    if (n_ref == 0 || max_offset_samples < 0) return n_ref;
-    int64_t d_lo, d_hi;
-    if (!lag_window(ref_len, sub_len, n_ref, max_offset_samples, &d_lo, &d_hi)) return 2;  // nothing to evaluate
+    if (n_ref == 0) return n_ref;
+    int64_t d_lo, d_hi, d_zero;
+    bool has_zero;
+    if (!overlap_window(ref_len, sub_len, n_ref, max_offset_samples, &d_lo, &d_hi, &has_zero, &d_zero) || d_lo > d_hi)
+        return 2;  // nothing to evaluate
     // lags d in [d_lo, d_hi] of a length-n circular correlation equal the linear ones iff no product
     // wraps: S' + d_hi <= n and R' - d_lo <= n for the prefixes (S', R') that reach the window at all
     int64_t s_eff, r_eff;
@@ -586,6 +665,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->max_cand = max_cand;
     p->max_slots = 1 + (max_cand + 1) / 2;
     HIP_TRY(hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     {
         const char* e = getenv("FFS_DISABLE_PRUNED_PASS_C");
         p->allow_pruned = !(e && e[0] == '1');
@@ -691,6 +771,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
+    if (p->last_done) (void)hipEventDestroy(p->last_done);
     for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
     delete p;
     return FFS_OK;
@@ -705,7 +786,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     if (!p) return fail(FFS_E_INVALID, "plan is null");
     if (n_pairs < 0 || n_cand < 1 || n_cand > p->max_cand)
         return fail(FFS_E_INVALID, "n_cand=%d outside [1, plan max_cand=%d]", n_cand, p->max_cand);
-    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32) return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1)
+        return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
     if (n_pairs == 0) return FFS_OK;
@@ -713,6 +795,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     static_assert(sizeof(PairResult) == sizeof(ffs_pair_result), "ABI struct mismatch");
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(p->device));
+    int rc;
+    if ((rc = enter_stream(p, st))) return rc;
 
     const int n_packed = (n_cand + 1) / 2;
     const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
@@ -735,7 +819,6 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
     const size_t o_pbest = o_acc + n_cands * KNOM * sizeof(RescoreAcc);  // zeroed together with acc
     const size_t total = o_pbest + n_cands * sizeof(PoolBest);
-    int rc;
     if ((rc = ensure_desc(p, total))) return rc;
     HIP_TRY(hipEventSynchronize(p->upload_done));  // previous call's upload has left the pinned buffer
     char* hb = (char*)p->host_desc;
@@ -758,13 +841,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (!ref.ptr || !subs[j].ptr) {
                 if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
             }
+            if (dtype != FFS_DTYPE_U8 && (((uintptr_t)ref.ptr | (uintptr_t)subs[j].ptr) & 3))
+                return fail(FFS_E_INVALID, "float / bit-packed vectors must be 4-byte aligned (pair %d)", pi);
             const CandDesc& cd = hc[(size_t)pi * n_cand + j];
             if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
             // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
             // keeps working on the whole vectors through the candidate descriptor)
             int64_t s_eff, r_eff;
             effective_lengths(ref.len, subs[j].len, cd.d_lo, cd.d_hi, &s_eff, &r_eff);
-            if (!(cd.flags & FFS_FLAG_EMPTY_WINDOW)) {
+            if (!(cd.flags & CAND_NO_LAGS)) {
                 subs[j].len = s_eff;
                 if (r_eff > ref_used) ref_used = r_eff;
             }
@@ -802,7 +887,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
         const ffs_plan* sp = p->seg;
         int64_t d_lo = INT64_MAX, d_hi = INT64_MIN, s_max = 1;
         for (size_t i = 0; i < n_cands; ++i) {
-            if (hc[i].flags & FFS_FLAG_EMPTY_WINDOW) continue;
+            if (hc[i].flags & CAND_NO_LAGS) continue;
             if (hc[i].d_lo < d_lo) d_lo = hc[i].d_lo;
             if (hc[i].d_hi > d_hi) d_hi = hc[i].d_hi;
             const int64_t sl = views[(i / n_cand) * stride + 1 + i % n_cand].len;
@@ -815,7 +900,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 seg = true;
                 seg_blocks = (int)((s_max + B - 1) / B);
                 seg_lo = d_lo;
-                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : 4;
+                // byte / float vectors move the pointer to the block's first sample, bit-packed ones the bit offset
+                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : (dtype == FFS_DTYPE_F32 ? 4 : 0);
                 n_xf = (size_t)n_pairs * seg_blocks * n_slots;
                 for (int pi = 0; pi < n_pairs; ++pi) {
                     const VecView& ref = views[(size_t)pi * stride];
@@ -829,6 +915,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                             rb.len = rb.lead = 0;  // nothing of the reference in this stretch
                         } else {
                             rb.ptr = (const char*)ref.ptr + start * (int64_t)esz;  // may point in front of the vector (lead)
+                            if (!esz) rb.off = ref.off + start;
                         }
                         fill_xform(x, &rb, nullptr, ref.ptr);
                         std::vector<VecView> sb(n_cand);
@@ -836,7 +923,10 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                             sb[j] = views[(size_t)pi * stride + 1 + j];
                             const int64_t left = sb[j].len - (int64_t)k * B;
                             sb[j].len = left <= 0 ? 0 : (left < B ? left : B);
-                            if (sb[j].len > 0) sb[j].ptr = (const char*)sb[j].ptr + (int64_t)k * B * (int64_t)esz;
+                            if (sb[j].len > 0) {
+                                sb[j].ptr = (const char*)sb[j].ptr + (int64_t)k * B * (int64_t)esz;
+                                if (!esz) sb[j].off += (int64_t)k * B;
+                            }
                         }
                         for (int kk = 0; kk < n_packed; ++kk)
                             fill_xform(x + 1 + kk, &sb[2 * kk], (2 * kk + 1 < n_cand) ? &sb[2 * kk + 1] : nullptr, ref.ptr);
@@ -858,15 +948,13 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     NomList* dn = (NomList*)(db + o_nom);
     RescoreAcc* da = (RescoreAcc*)(db + o_acc);
     PoolBest* dpb = (PoolBest*)(db + o_pbest);
-    const PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries};
+    const PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries, dpb,
+                      (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight};
     CandResult* cres = (CandResult*)cand_out_dev;
     PairResult* pres = (PairResult*)pair_out_dev;
 
     if (p->direct_only) {
-        if (dtype == FFS_DTYPE_U8)
-            hipLaunchKernelGGL((k_direct<0>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres);
-        else
-            hipLaunchKernelGGL((k_direct<1>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres);
+        FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
@@ -881,10 +969,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             const XformDesc* dxs = dx + (size_t)p0 * seg_blocks * n_slots;
             {
                 ProfSpan span(p, st, FFS_K_PASS_A);
-                if (dtype == FFS_DTYPE_U8)
-                    rc = launch_pass_a<0>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st);
-                else
-                    rc = launch_pass_a<1>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st);
+                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st));
             }
             if (rc) return rc;
             {
@@ -910,10 +995,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 return rc;
             {
                 ProfSpan span(p, st, FFS_K_RESCORE);
-                if (dtype == FFS_DTYPE_U8)
-                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
-                else
-                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                                                       first_cand));
             }
             HIP_TRY(hipGetLastError());
         }
@@ -922,10 +1005,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             const int first_cand = p0 * n_cand;
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
-                if (dtype == FFS_DTYPE_U8)
-                    rc = launch_pass_a<0>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, ref_half, st);
-                else
-                    rc = launch_pass_a<1>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair, n_slots, ref_half, st);
+                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
+                                                           n_slots, ref_half, st));
             }
             if (rc) return rc;
             {
@@ -953,17 +1034,12 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
-                if (dtype == FFS_DTYPE_U8)
-                    hipLaunchKernelGGL((k_rescore<0>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
-                else
-                    hipLaunchKernelGGL((k_rescore<1>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da, first_cand);
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                                                       first_cand));
             }
             HIP_TRY(hipGetLastError());
         }
-        if (dtype == FFS_DTYPE_U8)
-            hipLaunchKernelGGL((k_pool_rescore<0>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb);
-        else
-            hipLaunchKernelGGL((k_pool_rescore<1>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb);
+        FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
         hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
         hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
                            (int)n_cands, dtype, pa.header, dpb);
@@ -972,19 +1048,21 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
                        (long long)filter_max_offset);
     HIP_TRY(hipGetLastError());
-    return FFS_OK;
+    return leave_stream(p, st);
 }
 
 int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_len, double ref_lo, double ref_hi,
                        const void* a_dev, int64_t a_len, double a_lo, double a_hi, const void* b_dev, int64_t b_len,
                        double b_lo, double b_hi, float* out_a_dev, float* out_b_dev, void* hip_stream) {
     if (!p || p->direct_only) return fail(FFS_E_INVALID, "plan has no FFT path (n_fft < %lld)", (long long)kMinFftN);
-    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32) return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1)
+        return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
     if (!ref_dev || !a_dev || ref_len <= 0 || a_len <= 0) return fail(FFS_E_EMPTY, "empty reference or candidate");
     if (ref_len > p->N || a_len > p->N || (b_dev && b_len > p->N)) return fail(FFS_E_TOO_LONG, "vector longer than n_fft");
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(p->device));
     int rc;
+    if ((rc = enter_stream(p, st))) return rc;
     if ((rc = ensure_desc(p, 4096))) return rc;
     HIP_TRY(hipEventSynchronize(p->upload_done));
     XformDesc* hx = (XformDesc*)p->host_desc;
@@ -994,14 +1072,12 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     HIP_TRY(hipMemcpyAsync(p->dev_desc, hx, 2 * sizeof(XformDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(p->upload_done, st));
     const XformDesc* dx = (const XformDesc*)p->dev_desc;
-    if (dtype == FFS_DTYPE_U8)
-        rc = launch_pass_a<0>(p, dx, 2, 2, 2, ref_half_ok(p), st);
-    else
-        rc = launch_pass_a<1>(p, dx, 2, 2, 2, ref_half_ok(p), st);
+    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx, 2, 2, 2, ref_half_ok(p), st));
     if (rc) return rc;
     if ((rc = launch_mid(p, 1, 2, ref_half_ok(p), st))) return rc;
-    const PoolArgs none{nullptr, nullptr, nullptr};
-    return launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st);
+    const PoolArgs none{nullptr, nullptr, nullptr, nullptr, 1};
+    if ((rc = launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st))) return rc;
+    return leave_stream(p, st);
 }
 
 // datetime.timedelta(seconds=x).total_seconds() for a float x >= 0, i.e. x rounded to whole
@@ -1058,14 +1134,17 @@ int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, con
     return n;
 }
 
-int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
-                            double ratio, double sample_rate, double start_seconds, uint8_t* out_dev, int64_t out_len,
-                            void* hip_stream) {
+static int rasterize_impl(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
+                          double ratio, double sample_rate, double start_seconds, void* out_dev, int64_t out_len,
+                          bool bits, void* hip_stream) {
     if (n_subs < 0 || out_len < 0 || (n_subs > 0 && (!start_us || !end_us))) return fail(FFS_E_INVALID, "bad argument");
     if (out_len > 0 && !out_dev) return fail(FFS_E_INVALID, "null output");
     if (out_len >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
+    if (bits && ((uintptr_t)out_dev & 3)) return fail(FFS_E_INVALID, "bit-packed output must be 4-byte aligned");
     hipStream_t st = (hipStream_t)hip_stream;
-    if (out_len > 0) HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_len, st));
+    int rc_dev;
+    if ((rc_dev = use_device_of(out_dev))) return rc_dev;
+    if (out_len > 0) HIP_TRY(hipMemsetAsync(out_dev, 0, bits ? (size_t)((out_len + 31) / 32) * 4 : (size_t)out_len, st));
     // The interval list is a host temporary that an asynchronous copy reads later: park it in a
     // per-thread keep-alive list that is only emptied after a stream synchronisation, so that a run
     // of calls (seven ratios per file) costs one sync per 64 calls instead of one each.
@@ -1088,9 +1167,174 @@ int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, cons
     HIP_TRY(hipMallocAsync((void**)&d_iv, (size_t)n_iv * sizeof(int2), st));
     HIP_TRY(hipMemcpyAsync(d_iv, iv.data(), (size_t)n_iv * sizeof(int2), hipMemcpyHostToDevice, st));
     const int blocks = (int)((n_iv + 3) / 4);
-    hipLaunchKernelGGL(k_fill_intervals, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, d_iv, (int)n_iv, out_dev);
+    if (bits)
+        hipLaunchKernelGGL(k_fill_intervals_bits, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, d_iv, (int)n_iv,
+                           (unsigned*)out_dev);
+    else
+        hipLaunchKernelGGL(k_fill_intervals, dim3(blocks < 4096 ? blocks : 4096), dim3(256), 0, st, d_iv, (int)n_iv,
+                           (unsigned char*)out_dev);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipFreeAsync(d_iv, st));
+    return FFS_OK;
+}
+
+int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
+                            double ratio, double sample_rate, double start_seconds, uint8_t* out_dev, int64_t out_len,
+                            void* hip_stream) {
+    return rasterize_impl(start_us, end_us, is_metadata, n_subs, ratio, sample_rate, start_seconds, out_dev, out_len, false,
+                          hip_stream);
+}
+
+int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
+                                 double ratio, double sample_rate, double start_seconds, uint32_t* out_dev,
+                                 int64_t out_len, void* hip_stream) {
+    return rasterize_impl(start_us, end_us, is_metadata, n_subs, ratio, sample_rate, start_seconds, out_dev, out_len, true,
+                          hip_stream);
+}
+
+int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshold, uint32_t* dst_dev, void* hip_stream) {
+    if (n < 0 || (src_dtype != FFS_DTYPE_U8 && src_dtype != FFS_DTYPE_F32)) return fail(FFS_E_INVALID, "bad argument");
+    if (n == 0) return FFS_OK;
+    if (!src_dev || !dst_dev || ((uintptr_t)dst_dev & 3)) return fail(FFS_E_INVALID, "null or misaligned buffer");
+    int rc;
+    if ((rc = use_device_of(dst_dev))) return rc;
+    const long long n_words = (n + 31) / 32;
+    long long blocks = (n_words + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (src_dtype == FFS_DTYPE_U8)
+        hipLaunchKernelGGL((k_pack_bits<0>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src_dev, (long long)n,
+                           (float)threshold, dst_dev, n_words);
+    else
+        hipLaunchKernelGGL((k_pack_bits<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, src_dev, (long long)n,
+                           (float)threshold, dst_dev, n_words);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int ffs_scatter_segments(const float* seg_labels_dev, const int64_t* seg_src_off, const int64_t* seg_dst_start,
+                         const int64_t* seg_len, int n_segments, float* out_dev, int64_t out_len, void* hip_stream) {
+    if (n_segments < 0 || out_len < 0 || (n_segments > 0 && (!seg_src_off || !seg_dst_start || !seg_len)))
+        return fail(FFS_E_INVALID, "bad argument");
+    if (out_len == 0) return FFS_OK;
+    if (!out_dev || (n_segments > 0 && !seg_labels_dev)) return fail(FFS_E_INVALID, "null device pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc;
+    if ((rc = use_device_of(out_dev))) return rc;
+    HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_len * sizeof(float), st));
+    for (int s0 = 0; s0 < n_segments; s0 += SCATTER_MAX) {
+        ScatterSegs segs;
+        memset(&segs, 0, sizeof segs);
+        long long longest = 0;
+        for (int i = s0; i < n_segments && i < s0 + SCATTER_MAX; ++i) {
+            if (seg_len[i] < 0 || seg_src_off[i] < 0) return fail(FFS_E_INVALID, "negative segment length / source offset");
+            // Python slice assignment sparse[lo:hi] = labels[:hi-lo] with lo = int(start*sample_rate) >= 0
+            if (seg_dst_start[i] < 0 || seg_dst_start[i] >= out_len || seg_len[i] == 0) continue;
+            segs.src_off[segs.n] = seg_src_off[i];
+            segs.dst_start[segs.n] = seg_dst_start[i];
+            segs.len[segs.n] = seg_len[i];
+            if (seg_len[i] > longest) longest = seg_len[i];
+            ++segs.n;
+        }
+        if (!segs.n) continue;
+        long long bx = (longest + 255) / 256;
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(k_scatter_segments, dim3((unsigned)bx, segs.n), dim3(256), 0, st, seg_labels_dev, segs, out_dev,
+                           (long long)out_len);
+    }
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+// ---- RCCL gather of the per-pair results (the only collective on the path) ---------------------
+// RCCL is resolved at run time (dlopen), so single-GPU users of libffsalign.so do not load it; in a
+// torch process the already-loaded librccl.so.1 is picked up, so both share one RCCL.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, ffs_comm_id, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi* rccl_api() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names)
+            if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // the copy this process already has
+        for (int i = 0; !api.handle && i < 3; ++i) api.handle = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) {
+            api.GetUniqueId = (int (*)(void*))dlsym(api.handle, "ncclGetUniqueId");
+            api.CommInitRank = (int (*)(void**, int, ffs_comm_id, int))dlsym(api.handle, "ncclCommInitRank");
+            api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
+            api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
+            api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
+        }
+    }
+    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) return nullptr;
+    return &api;
+}
+int rccl_fail(RcclApi* a, const char* what, int code) {
+    return fail(FFS_E_RCCL, "%s failed: %s", what, (a && a->GetErrorString) ? a->GetErrorString(code) : "?");
+}
+}  // namespace
+
+struct ffs_comm {
+    void* comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+};
+
+int ffs_comm_unique_id(ffs_comm_id* id_out) {
+    if (!id_out) return fail(FFS_E_INVALID, "id_out is null");
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FFS_E_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+    const int rc = a->GetUniqueId(id_out);
+    return rc ? rccl_fail(a, "ncclGetUniqueId", rc) : FFS_OK;
+}
+
+int ffs_comm_create(int device, int rank, int world_size, const ffs_comm_id* id, ffs_comm** out) {
+    if (!out || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(FFS_E_INVALID, "bad argument");
+    *out = nullptr;
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FFS_E_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+    HIP_TRY(hipSetDevice(device));
+    ffs_comm* c = new ffs_comm();
+    c->device = device;
+    c->rank = rank;
+    c->world = world_size;
+    const int rc = a->CommInitRank(&c->comm, world_size, *id, rank);
+    if (rc) {
+        delete c;
+        return rccl_fail(a, "ncclCommInitRank", rc);
+    }
+    *out = c;
+    return FFS_OK;
+}
+
+int ffs_gather_results(ffs_comm* c, const ffs_pair_result* send_dev, int64_t n_local, ffs_pair_result* recv_dev,
+                       void* hip_stream) {
+    if (!c || n_local < 0) return fail(FFS_E_INVALID, "bad argument");
+    if (n_local == 0) return FFS_OK;
+    if (!send_dev || !recv_dev) return fail(FFS_E_INVALID, "null device pointer");
+    RcclApi* a = rccl_api();
+    if (!a) return fail(FFS_E_RCCL, "librccl.so.1 could not be loaded");
+    HIP_TRY(hipSetDevice(c->device));
+    const int rc = a->AllGather(send_dev, recv_dev, (size_t)n_local * sizeof(ffs_pair_result), /*ncclUint8*/ 1, c->comm,
+                                (hipStream_t)hip_stream);
+    return rc ? rccl_fail(a, "ncclAllGather", rc) : FFS_OK;
+}
+
+int ffs_comm_destroy(ffs_comm* c) {
+    if (!c) return FFS_OK;
+    RcclApi* a = rccl_api();
+    if (a && c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)a->CommDestroy(c->comm);
+    }
+    delete c;
     return FFS_OK;
 }
 
@@ -1119,6 +1363,8 @@ int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len, dou
     if (n_samples < 0 || frame_len < 1) return fail(FFS_E_INVALID, "bad n_samples/frame_len");
     if (n_samples == 0) return FFS_OK;
     if (!pcm_dev || !labels_dev) return fail(FFS_E_INVALID, "null device pointer");
+    int rc_dev;
+    if ((rc_dev = use_device_of(labels_dev))) return rc_dev;
     const long long n_frames = (n_samples + frame_len - 1) / frame_len;
     const double thr_lin = pow(10.0, energy_threshold_db / 10.0);
     long long blocks = (n_frames + 3) / 4;
@@ -1134,6 +1380,8 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
     if (n_frames < 0 || chunk_frames < 1 || max_length < 1) return fail(FFS_E_INVALID, "bad argument");
     if (n_frames == 0) return FFS_OK;
     if (!valid_dev || !labels_dev || valid_dev == labels_dev) return fail(FFS_E_INVALID, "null or aliased buffers");
+    int rc_dev;
+    if ((rc_dev = use_device_of(labels_dev))) return rc_dev;
     const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     hipLaunchKernelGGL(k_vad_tokenize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, valid_dev,
                        (long long)n_frames, (long long)chunk_frames, min_length, max_length, max_continuous_silence,
@@ -1145,6 +1393,8 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
 int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev, void* hip_stream) {
     if (!bounds_dev || (n_frames > 0 && !frames_dev) || n_frames < 0) return fail(FFS_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)hip_stream;
+    int rc_dev;
+    if ((rc_dev = use_device_of(bounds_dev))) return rc_dev;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(1), 0, st, (long long*)bounds_dev);
     if (n_frames > 0) {
         long long blocks = (n_frames + 255) / 256;

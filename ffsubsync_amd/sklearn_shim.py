@@ -9,7 +9,7 @@ from the real shim and from this one are interchangeable by duck typing.
 from typing import Any, List, Tuple
 
 
-class TransformerMixin:
+class _TransformerMixin:
     """sklearn_shim.py:52-80: ``fit_transform(X, y=None, **fit_params)``."""
 
     def fit_transform(self, X: Any, y: Any = None, **fit_params: Any) -> Any:
@@ -18,7 +18,7 @@ class TransformerMixin:
         return self.fit(X, y, **fit_params).transform(X)  # type: ignore[attr-defined]
 
 
-class Pipeline:
+class _Pipeline:
     """Sequential ``(name, transformer)`` steps (sklearn_shim.py:89-335, reduced)."""
 
     def __init__(self, steps: List[Tuple[str, Any]], verbose: bool = False) -> None:
@@ -107,7 +107,7 @@ class Pipeline:
         return Xt
 
 
-def make_pipeline(*steps, **kwargs) -> Pipeline:
+def _make_pipeline(*steps, **kwargs) -> "_Pipeline":
     """sklearn_shim.py:362 -- name steps after their lower-cased class, numbering duplicates."""
     verbose = kwargs.pop("verbose", False)
     if kwargs:
@@ -122,4 +122,13 @@ def make_pipeline(*steps, **kwargs) -> Pipeline:
             out.append(("%s-%d" % (n, seen[n]), s))
         else:
             out.append((n, s))
-    return Pipeline(out, verbose=verbose)
+    return _Pipeline(out, verbose=verbose)
+
+
+# When the reference package is importable its own classes are used, so the drop-in aligners are
+# instances of ffsubsync.sklearn_shim.TransformerMixin and pipelines are the caller's Pipeline type;
+# otherwise (e.g. on a GPU box without ffsubsync) the stand-ins above provide the same contract.
+try:
+    from ffsubsync.sklearn_shim import Pipeline, TransformerMixin, make_pipeline  # type: ignore  # noqa: F401
+except Exception:  # ffsubsync (or one of its imports) is not available
+    TransformerMixin, Pipeline, make_pipeline = _TransformerMixin, _Pipeline, _make_pipeline

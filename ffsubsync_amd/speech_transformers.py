@@ -9,13 +9,16 @@ What is mirrored from the reference (ffsubsync/speech_transformers.py):
     :class:`PCMSpeechTransformer`, fed by any binary stream (the ffmpeg pipe in production);
   * ``ComputeSpeechFrameBoundariesMixin`` (:299-317).
 
-ffmpeg spawning, ffprobe, progress bars, webrtcvad/silero and the auditok token smoothing stay on
-the host in the reference and are out of scope.
+  * the sparse-reference scatter of ``MultiSegmentVideoSpeechTransformer.fit`` (:871-890) --
+    :func:`assemble_sparse_reference`; ``DeserializeSpeechTransformer`` (:987-1009) and its bulk
+    counterpart :func:`load_speech_batch` (``.npz`` files straight into bit-packed HBM vectors).
+
+ffmpeg / ffprobe spawning, the embedded-subtitle shortcut, progress bars and the thread pool of the
+multi-segment path are control plane and stay with the reference's own classes:
+:func:`install_detectors` puts the GPU detector behind them through the reference's factory seam.
+webrtcvad / silero arithmetic lives in absent third-party wheels (seams only).
 """
-import os
-import subprocess
-from datetime import timedelta
-from typing import Callable, List, NamedTuple, Optional, Union
+from typing import Callable, List, Optional, Sequence, Union
 
 import numpy as np
 
@@ -137,6 +140,44 @@ def detect_device(pcm_dev, sample_rate: int, frame_rate: int, non_speech_label: 
     """Same sweep for PCM already resident in HBM (int16 CUDA tensor) -> float32 CUDA labels."""
     return _native.vad_energy(pcm_dev, frames_per_window(sample_rate, frame_rate), energy_threshold_db,
                               non_speech_label)
+
+
+def detect_pinned_stream(pcm_host, sample_rate: int, frame_rate: int, non_speech_label: float,
+                         energy_threshold_db: float = DEFAULT_ENERGY_THRESHOLD_DB, staging=None):
+    """The chunk loop of ``_fit_using_audio`` (speech_transformers.py:683-753) for decoded s16le PCM that
+    sits in pinned host memory (int16 CPU tensor): every 100 s buffer (:683-685) is copied to one of two
+    HBM staging buffers on a copy stream while the frame-energy sweep of the previous buffer runs on the
+    caller's stream -- PCIe transfer and VAD overlap, the labels never leave the GPU.
+    Returns the float32 CUDA label vector.  ``staging`` = (buffers, copy_stream) to reuse across files."""
+    torch = _native.require_gpu()
+    frame_len = frames_per_window(sample_rate, frame_rate)
+    chunk = frame_len * WINDOWS_PER_BUFFER  # samples per buffer; a multiple of the frame length
+    n = int(pcm_host.numel())
+    n_frames = (n + frame_len - 1) // frame_len
+    labels = torch.empty(n_frames, dtype=torch.float32, device="cuda")
+    if n == 0:
+        return labels
+    if staging is None:
+        staging = ([torch.empty(chunk, dtype=torch.int16, device="cuda") for _ in range(2)], torch.cuda.Stream())
+    bufs, copy_stream = staging
+    main = torch.cuda.current_stream()
+    filled = [torch.cuda.Event() for _ in range(2)]
+    drained = [None, None]
+    for i, o in enumerate(range(0, n, chunk)):
+        k = i % 2
+        m = min(chunk, n - o)
+        with torch.cuda.stream(copy_stream):
+            if drained[k] is not None:
+                copy_stream.wait_event(drained[k])  # the sweep that last read this staging buffer is done
+            bufs[k][:m].copy_(pcm_host[o:o + m], non_blocking=True)
+            filled[k].record(copy_stream)
+        main.wait_event(filled[k])
+        f0 = o // frame_len
+        _native.check(_native.load().ffs_vad_energy(bufs[k].data_ptr(), m, frame_len, float(energy_threshold_db),
+                                                    float(non_speech_label), labels[f0:].data_ptr(), main.cuda_stream))
+        drained[k] = torch.cuda.Event()
+        drained[k].record(main)
+    return labels
 
 
 class ComputeSpeechFrameBoundariesMixin:
@@ -272,160 +313,61 @@ class PCMSpeechTransformer(TransformerMixin):
         return self.video_speech_results_
 
 
-class ProgressInfo(NamedTuple):
-    """ffsubsync/speech_transformers.py:40-53: what ``progress_handler`` receives per PCM chunk."""
-
-    processed_seconds: float
-    total_seconds: Optional[float]
-
-    @property
-    def fraction(self) -> Optional[float]:
-        if not self.total_seconds:
-            return None
-        return min(1.0, self.processed_seconds / self.total_seconds)
-
-
-class VideoSpeechTransformer(PCMSpeechTransformer):
-    """Same constructor and fitted attribute as the reference's ``VideoSpeechTransformer``
-    (speech_transformers.py:320-351): ``fit(fname)`` decodes the reference's audio with an ffmpeg
-    subprocess to s16le mono PCM on a pipe (:681-682) and runs the chunked VAD loop on the GPU.
-    Only the decode command needed for that is built here; the reference's embedded-subtitle
-    shortcut, ffprobe duration probing, remote-URL temp extraction and GUI/VLC progress plumbing are
-    control plane and stay with the reference (a ``subs_then_*`` vad falls straight through to audio)."""
-
-    def __init__(self, vad: str, sample_rate: int, frame_rate: int, non_speech_label: float,
-                 start_seconds: int = 0, ffmpeg_path: Optional[str] = None, ref_stream: Optional[str] = None,
-                 vlc_mode: bool = False, gui_mode: bool = False, max_duration_seconds: Optional[float] = None,
-                 extract_audio_first: bool = False, progress_handler=None) -> None:
-        super(VideoSpeechTransformer, self).__init__(vad, sample_rate, frame_rate, non_speech_label, None)
-        self.start_seconds = start_seconds
-        self.ffmpeg_path = ffmpeg_path
-        self.ref_stream = ref_stream
-        self.vlc_mode = vlc_mode
-        self.gui_mode = gui_mode
-        self.max_duration_seconds = max_duration_seconds
-        self.extract_audio_first = extract_audio_first
-        self._video_progress_handler = progress_handler
-
-    def _decode_command(self, fname: str) -> List[str]:
-        exe = "ffmpeg" if self.ffmpeg_path is None else os.path.join(self.ffmpeg_path, "ffmpeg")
-        cmd = [exe]
-        if self.start_seconds > 0:
-            cmd += ["-ss", str(timedelta(seconds=self.start_seconds))]
-        if self.max_duration_seconds is not None:
-            cmd += ["-t", str(timedelta(seconds=self.max_duration_seconds))]
-        cmd += ["-loglevel", "fatal", "-nostdin", "-i", fname]
-        if self.ref_stream is not None and self.ref_stream.startswith("0:a:"):
-            cmd += ["-map", self.ref_stream]
-        cmd += ["-f", "s16le", "-ac", "1", "-acodec", "pcm_s16le", "-af", "aresample=async=1",
-                "-ar", str(self.frame_rate), "-"]
-        return cmd
-
-    def fit(self, fname: str, *_) -> "VideoSpeechTransformer":
-        total = self.max_duration_seconds
-        if self._video_progress_handler is not None:
-            handler = self._video_progress_handler
-            self.progress_handler = lambda processed: handler(ProgressInfo(processed, total))
-        process = subprocess.Popen(self._decode_command(fname), stdin=subprocess.DEVNULL, stdout=subprocess.PIPE)
-        try:
-            super(VideoSpeechTransformer, self).fit(process.stdout)
-        finally:
-            process.wait()
-        return self
+def install_detectors(ref_speech_transformers=None) -> None:
+    """The VAD seam of the reference: ``VideoSpeechTransformer._fit_using_audio`` looks the
+    detector factory up as a module attribute by substring of ``--vad`` (speech_transformers.py:655-679),
+    so replacing ``ffsubsync.speech_transformers._make_auditok_detector`` puts the GPU frame-energy sweep +
+    token smoothing behind the reference's own class -- its ffmpeg pipe, chunk loop, embedded-subtitle
+    shortcut (``subs_then_*``, :609-633), progress reporting and ``MultiSegmentVideoSpeechTransformer``
+    thread pool stay exactly as they are.  (webrtc / silero keep the reference's CPU implementations.)"""
+    if ref_speech_transformers is None:
+        import ffsubsync.speech_transformers as ref_speech_transformers  # type: ignore
+    ref_speech_transformers._make_auditok_detector = _make_auditok_detector
 
 
-def _probe_duration(fname: str, ffmpeg_path: Optional[str] = None) -> float:
-    """Container duration in seconds via an ffprobe subprocess (the reference uses ffmpeg-python's
-    probe for the same number, speech_transformers.py:849-858)."""
-    exe = "ffprobe" if ffmpeg_path is None else os.path.join(ffmpeg_path, "ffprobe")
-    out = subprocess.check_output([exe, "-v", "error", "-show_entries", "format=duration", "-of",
-                                   "default=noprint_wrappers=1:nokey=1", fname], stdin=subprocess.DEVNULL)
-    return float(out.decode().strip())
-
-
-class MultiSegmentVideoSpeechTransformer(TransformerMixin):
-    """Sparse reference signal from a few sampled windows (speech_transformers.py:760-903): VAD runs on
-    ``segment_count`` windows of ``segment_duration`` seconds spread evenly over the reference (each
-    through its own :class:`VideoSpeechTransformer`, up to ``parallel_workers`` at a time -- every worker
-    thread drives the GPU through its own handles) and the labels are scattered into an otherwise
-    zero full-length vector, which the aligner consumes unchanged."""
-
-    START_MARGIN_SECONDS: int = 30
-    END_MARGIN_SECONDS: int = 60
-
-    def __init__(self, vad: str, sample_rate: int, frame_rate: int, non_speech_label: float,
-                 segment_count: int = 8, segment_duration: int = 60, skip_intro_outro: bool = False,
-                 parallel_workers: int = 4, ffmpeg_path: Optional[str] = None, ref_stream: Optional[str] = None,
-                 vlc_mode: bool = False, gui_mode: bool = False) -> None:
-        self.vad = vad.split("subs_then_")[-1]  # sampling is audio-only (:795-797)
-        self.sample_rate = sample_rate
-        self.frame_rate = frame_rate
-        self._non_speech_label = non_speech_label
-        self.segment_count = segment_count
-        self.segment_duration = segment_duration
-        self.skip_intro_outro = skip_intro_outro
-        self.parallel_workers = parallel_workers
-        self.ffmpeg_path = ffmpeg_path
-        self.ref_stream = ref_stream
-        self.vlc_mode = vlc_mode
-        self.gui_mode = gui_mode
-        self.video_speech_results_: Optional[np.ndarray] = None
-
-    def _segment_starts(self, total_duration: float) -> List[int]:
-        """Start seconds of the sampled windows (:813-834): evenly spaced over the usable span, margins
-        honoured when they leave room, clamped into range and de-duplicated."""
-        window = self.segment_duration
-        if total_duration <= window:
-            return [0]
-        first = float(self.START_MARGIN_SECONDS if self.skip_intro_outro else 0)
-        last = total_duration - (self.END_MARGIN_SECONDS if self.skip_intro_outro else 0)
-        if last - first < window:
-            first, last = 0.0, total_duration
-        span = last - first - window
-        count = max(1, self.segment_count)
-        if span <= 0 or count == 1:
-            return [int(max(0.0, min(first, total_duration - window)))]
-        picks = [int(round(first + i * span / (count - 1))) for i in range(count)]
-        top = int(total_duration) - window
-        return sorted({max(0, min(p, top)) for p in picks})
-
-    def _extract_segment_speech(self, fname: str, start: int):
-        seg = VideoSpeechTransformer(self.vad, self.sample_rate, self.frame_rate, self._non_speech_label,
-                                     start_seconds=start, ffmpeg_path=self.ffmpeg_path, ref_stream=self.ref_stream,
-                                     vlc_mode=self.vlc_mode, gui_mode=self.gui_mode,
-                                     max_duration_seconds=self.segment_duration)
-        seg.fit(fname)
-        return start, seg.transform()
-
-    def fit(self, fname: str, *_) -> "MultiSegmentVideoSpeechTransformer":
-        from concurrent.futures import ThreadPoolExecutor, as_completed
-
-        try:
-            total_duration = float(_probe_duration(fname, self.ffmpeg_path))
-        except Exception as e:
-            raise ValueError("multi-segment sync needs the reference duration, but probing "
-                             "'%s' failed: %s" % (fname, e))
-        starts = self._segment_starts(total_duration)
-        sparse = np.zeros(int(total_duration * self.sample_rate) + 2, dtype=float)
-        with ThreadPoolExecutor(max_workers=max(1, min(self.parallel_workers, len(starts)))) as pool:
-            pending = {pool.submit(self._extract_segment_speech, fname, s): s for s in starts}
-            for fut in as_completed(pending):
-                try:
-                    start, labels = fut.result()
-                except Exception:  # one bad window must not sink the sync (:878-886)
-                    continue
-                lo = int(start * self.sample_rate)
-                hi = min(lo + len(labels), len(sparse))
-                if hi > lo:
-                    sparse[lo:hi] = labels[: hi - lo]
-        if not np.any(sparse > 0):
-            raise ValueError("Unable to detect speech in any sampled segment. "
-                             "Perhaps try specifying a different stream / track, or a different vad.")
-        self.video_speech_results_ = sparse
-        return self
-
-    def transform(self, *_) -> np.ndarray:
-        return self.video_speech_results_
+def assemble_sparse_reference(segment_labels, starts_seconds, total_duration: float, sample_rate: int):
+    """Device-side scatter of ``MultiSegmentVideoSpeechTransformer.fit`` (speech_transformers.py:871-890):
+    ``sparse = zeros(int(total_duration*sample_rate) + 2)`` and, for every sampled window,
+    ``sparse[begin:end] = labels[:end-begin]`` with ``begin = int(start*sample_rate)`` clipped at the end.
+    ``segment_labels`` are float32 CUDA label vectors (e.g. from :func:`detect_device`); windows are
+    applied in the order given (later ones win where windows overlap, as in the reference's loop).
+    Returns the float32 CUDA vector; raises the reference's error when no frame is speech."""
+    torch = _native.require_gpu()
+    out_len = int(total_duration * sample_rate) + 2
+    lens = np.array([int(t.numel()) for t in segment_labels], dtype=np.int64)
+    src_off = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64) if lens.size else lens
+    dst = np.array([int(s * sample_rate) for s in starts_seconds], dtype=np.int64)
+    if lens.size:
+        labels = torch.cat([t.to(torch.float32).reshape(-1) for t in segment_labels])
+    else:
+        labels = torch.empty(0, dtype=torch.float32, device="cuda")
+    # overlapping windows must be applied in order: one launch per run of non-overlapping windows
+    sparse = None
+    order = list(range(lens.size))
+    while order:
+        run, rest, covered = [], [], []
+        for i in order:
+            lo_, hi_ = int(dst[i]), int(dst[i] + lens[i])
+            if rest or any(lo_ < b and a < hi_ for a, b in covered):
+                rest.append(i)
+            else:
+                run.append(i)
+                covered.append((lo_, hi_))
+        part = _native.scatter_segments(labels, src_off[run], dst[run], lens[run], out_len)
+        if sparse is None:
+            sparse = part
+        else:  # later windows overwrite earlier ones where they overlap
+            for i in run:
+                a, b = int(dst[i]), min(int(dst[i] + lens[i]), out_len)
+                if b > a:
+                    sparse[a:b] = part[a:b]
+        order = rest
+    if sparse is None:
+        sparse = torch.zeros(out_len, dtype=torch.float32, device="cuda")
+    if not bool((sparse > 0).any()):
+        raise ValueError("Unable to detect speech in any sampled segment. "
+                         "Perhaps try specifying a different stream / track, or a different vad.")
+    return sparse
 
 
 def serialize_speech(fname: str, speech) -> None:
@@ -461,3 +403,40 @@ class DeserializeSpeechTransformer(TransformerMixin):
     def transform(self, *_) -> np.ndarray:
         assert self.deserialized_speech_results_ is not None
         return self.deserialized_speech_results_
+
+
+def load_speech_batch(fnames: Sequence[str], non_speech_label: float = 0.0):
+    """Bulk ``.npz`` / ``.npy`` -> HBM feeder: every file is read and thresholded exactly as
+    ``DeserializeSpeechTransformer.fit`` does (``speech[speech < 1.0] = non_speech_label``,
+    speech_transformers.py:993-1005 -- so every vector is two-level: {non_speech_label, >= 1.0 values}),
+    bit-packed on the host and uploaded in ONE transfer; returns one bit-packed
+    ``subtitle_raster.DeviceRaster`` per file, which the aligners and ``batch.pack_pairs`` take as is.
+    A file whose speech values are not all equal (anything above 1.0) is returned as a float64 array instead."""
+    from .subtitle_raster import DeviceRaster
+
+    torch = _native.require_gpu()
+    loaded, chunks, total = [], [], 0
+    for fname in fnames:
+        speech = DeserializeSpeechTransformer(non_speech_label).fit(fname).transform()
+        speech = np.asarray(speech, dtype=float).ravel()
+        hi = float(speech.max()) if speech.size else 1.0
+        is_hi = speech >= 1.0
+        if speech.size and not np.all(speech[is_hi] == hi):
+            loaded.append((speech, None, 0))
+            continue
+        packed = np.packbits(is_hi, bitorder="little")
+        loaded.append((None, (float(non_speech_label), hi if is_hi.any() else 1.0, speech.size), total))
+        chunks.append((total, packed))
+        total += (packed.size + 63) // 64 * 64
+    host = np.zeros(max(total, 64), dtype=np.uint8)
+    for o, c in chunks:
+        host[o:o + c.size] = c
+    dev = torch.from_numpy(host).cuda().view(torch.int32)
+    out = []
+    for arr, meta, o in loaded:
+        if meta is None:
+            out.append(arr)
+        else:
+            lo, hi, n = meta
+            out.append(DeviceRaster(dev[o // 4: o // 4 + (n + 31) // 32], lo, hi, n))
+    return out

@@ -18,22 +18,36 @@ from .speech_transformers import ComputeSpeechFrameBoundariesMixin
 
 
 class DeviceRaster:
-    """A two-level activity vector in HBM: byte 0 -> ``lo``, byte != 0 -> ``hi``."""
+    """A two-level activity vector in HBM: 0 -> ``lo``, 1 -> ``hi``.
 
-    def __init__(self, bits, lo: float = 0.0, hi: float = 1.0) -> None:
-        self.bits = bits  # torch.uint8 CUDA tensor
+    ``bits`` is either a uint8 CUDA tensor of 0/1 bytes (``n`` omitted) or, with ``n`` given, the
+    bit-packed form the kernels prefer (int32 words, sample i = bit i & 31 of word i >> 5,
+    ``_native.FFS_DTYPE_U1``): an eighth of the HBM bytes."""
+
+    def __init__(self, bits, lo: float = 0.0, hi: float = 1.0, n: Optional[int] = None) -> None:
+        self.bits = bits
         self.lo = float(lo)
         self.hi = float(hi)
+        self.packed = n is not None
+        self.n = int(bits.numel()) if n is None else int(n)
 
     def __len__(self) -> int:
-        return int(self.bits.numel())
+        return self.n
 
     @property
     def size(self) -> int:
-        return len(self)
+        return self.n
+
+    def bytes01(self):
+        """0/1 uint8 CUDA tensor of the samples."""
+        return _native.unpack_bits(self.bits, self.n) if self.packed else self.bits
+
+    def packed_words(self):
+        """int32 CUDA tensor of the bit-packed samples (converted on the device when held as bytes)."""
+        return self.bits if self.packed else _native.pack_bits(self.bits)
 
     def __array__(self, dtype=None, copy=None):
-        host = self.bits.cpu().numpy()
+        host = self.bytes01().cpu().numpy()
         out = np.where(host != 0, self.hi, self.lo).astype(float)
         return out if dtype is None else out.astype(dtype)
 
@@ -41,8 +55,9 @@ class DeviceRaster:
         """float32 CUDA tensor of the sample values (for the boundary scan)."""
         import torch
 
-        return torch.where(self.bits != 0, torch.tensor(self.hi, device=self.bits.device),
-                           torch.tensor(self.lo, device=self.bits.device)).to(torch.float32)
+        b = self.bytes01()
+        return torch.where(b != 0, torch.tensor(self.hi, device=b.device),
+                           torch.tensor(self.lo, device=b.device)).to(torch.float32)
 
 
 def _microseconds(td: timedelta) -> int:
@@ -75,8 +90,11 @@ def rasterize_candidates(start_us, end_us, meta, ratios: Sequence[float], sample
                          start_seconds: float = 0) -> List[DeviceRaster]:
     """One DeviceRaster per framerate ratio: times scaled by the ratio (SubtitleScaler), amplitude
     min(1/ratio, 1) (speech_transformers.py:977)."""
-    return [DeviceRaster(_native.rasterize_subtitles(start_us, end_us, meta, r, sample_rate, start_seconds),
-                         0.0, min(1.0 / r, 1.0)) for r in ratios]
+    out = []
+    for r in ratios:
+        words, n = _native.rasterize_subtitles(start_us, end_us, meta, r, sample_rate, start_seconds, packed=True)
+        out.append(DeviceRaster(words, 0.0, min(1.0 / r, 1.0), n))
+    return out
 
 
 class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBoundariesMixin):
@@ -99,8 +117,9 @@ class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBounda
         start_us, end_us, meta = subtitle_records(subs, self._is_metadata)
         max_time = max([0] + [e / 10 ** 6 for e in end_us.tolist()])
         self.max_time_ = max_time - self.start_seconds
-        bits = _native.rasterize_subtitles(start_us, end_us, meta, 1.0, self.sample_rate, self.start_seconds)
-        self.subtitle_speech_results_ = DeviceRaster(bits, 0.0, min(1.0 / self.framerate_ratio, 1.0))
+        words, n = _native.rasterize_subtitles(start_us, end_us, meta, 1.0, self.sample_rate, self.start_seconds,
+                                               packed=True)
+        self.subtitle_speech_results_ = DeviceRaster(words, 0.0, min(1.0 / self.framerate_ratio, 1.0), n)
         self.fit_boundaries(self.subtitle_speech_results_.frames_float())
         return self
 

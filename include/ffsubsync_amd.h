@@ -15,7 +15,9 @@
  *     (0 = the null stream).  Calls are asynchronous with respect to the host unless stated;
  *     results land in caller-owned device buffers in stream order.
  *   - a plan owns its twiddle tables and workspace in HBM and may be used by one host thread
- *     at a time.
+ *     at a time; successive calls on different streams are ordered by the library (a call waits
+ *     for the plan's previous call before it touches the workspace).
+ *   - entry points without a plan run on the device that owns their output buffer.
  */
 #ifndef FFSUBSYNC_AMD_H
 #define FFSUBSYNC_AMD_H
@@ -32,10 +34,15 @@ extern "C" {
 #define FFS_E_NOMEM (-3)
 #define FFS_E_TOO_LONG (-4) /* R+S exceeds the plan's transform length */
 #define FFS_E_EMPTY (-5)    /* empty reference or candidate (aligners.py:58-66) */
+#define FFS_E_RCCL (-6)     /* librccl could not be loaded or an RCCL call failed */
 
 /* element types of the activity vectors */
 #define FFS_DTYPE_U8 0  /* two-level signal: byte==0 -> lo, byte!=0 -> hi  */
 #define FFS_DTYPE_F32 1 /* arbitrary float samples (lo/hi = bounds, used for the tie margin) */
+#define FFS_DTYPE_U1 2  /* two-level signal, one bit per sample: sample i = bit (i & 31) of the 32-bit
+                           little-endian word i >> 5 (numpy.packbits(..., bitorder="little")); 0 -> lo, 1 -> hi.
+                           The native format of the 0/1 activity vectors: an eighth of the HBM and PCIe bytes of
+                           FFS_DTYPE_U8.  Pointers 4-byte aligned; the buffer must cover whole 32-bit words. */
 
 /* result flags */
 #define FFS_FLAG_EMPTY_WINDOW 1 /* every lag masked: score=-inf, offset=N-1-S (aligners.py:45-48) */
@@ -68,7 +75,10 @@ int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len);
 
 /* Smallest supported transform length (2^k, or 3*2^k in [12288, 3145728]) a plan needs for one
  * (reference, candidate) solve.
- * Without a lag window this is ffs_fft_length (the full linear correlation).  With
+ * Only lags with a non-empty overlap, d in (-S, R), ever need a transform: every other lag the reference
+ * looks at has c(d) = 0 exactly and is handled as one virtual nominee (score 0, the largest such lag).
+ * Without a lag window the R+S-1 overlap lags need a circular correlation of length >= R+S (3*2^19 =
+ * 1 572 864 instead of the reference's 2^21 for 2 h @ 100 Hz inputs).  With
  * max_offset_samples >= 0 only lags inside the reference's window [d_lo, d_hi] are ever looked at:
  * only the prefixes S' = min(S, R - d_lo) and R' = min(R, S + d_hi) of the two vectors can meet at
  * such a lag (the rest is multiplied by zero padding), and a circular correlation of any length
@@ -93,8 +103,9 @@ int64_t ffs_plan_workspace_bytes(const ffs_plan* plan);
  * each one reference vector and n_cand candidate vectors (aligners.py:50-80, 131-167).
  *
  * Vectors are listed pair-major: index p*(1+n_cand) is pair p's reference, the next n_cand
- * entries its candidates.  vec_ptr[i] is a DEVICE pointer to vec_len[i] elements of `dtype`;
- * vec_lo/vec_hi give the two sample values of a FFS_DTYPE_U8 vector *before* the reference's
+ * entries its candidates.  vec_ptr[i] is a DEVICE pointer to vec_len[i] elements of `dtype`
+ * (vec_len counts samples for every dtype);
+ * vec_lo/vec_hi give the two sample values of a FFS_DTYPE_U8 / FFS_DTYPE_U1 vector *before* the reference's
  * 2*x-1 map (aligners.py:55-57), e.g. (0, 1) for a 0/1 vector or (0, 1/ratio) for a subtitle
  * track rasterised at a framerate ratio > 1 (speech_transformers.py:977).
  *
@@ -170,6 +181,44 @@ int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, con
 int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
                             int64_t n_subs, double ratio, double sample_rate, double start_seconds,
                             uint8_t* out_dev, int64_t out_len, void* hip_stream);
+
+/* Bit-packed (FFS_DTYPE_U1) variant: out_dev holds ceil(out_len/32) 32-bit words (zeroed, then filled). */
+int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
+                                 int64_t n_subs, double ratio, double sample_rate, double start_seconds,
+                                 uint32_t* out_dev, int64_t out_len, void* hip_stream);
+
+/* Two-level vector -> FFS_DTYPE_U1 on the device.  src_dtype FFS_DTYPE_U8: bit = (byte != 0);
+ * FFS_DTYPE_F32: bit = (x > threshold), e.g. VAD labels against 0.5 or (lo+hi)/2.  Writes
+ * ceil(n/32) words; unused high bits of the last word are 0. */
+int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshold, uint32_t* dst_dev,
+                  void* hip_stream);
+
+/* Sparse reference assembly of MultiSegmentVideoSpeechTransformer.fit (speech_transformers.py:871-890):
+ * out = zeros(out_len); out[dst_start[i] : dst_start[i]+len[i]] = labels[src_off[i] : src_off[i]+len[i]]
+ * for every sampled window i (clipped at out_len, Python slice semantics), in one device pass.
+ * seg_* are HOST arrays of n_segments entries; seg_labels_dev holds the windows' VAD labels. */
+int ffs_scatter_segments(const float* seg_labels_dev, const int64_t* seg_src_off, const int64_t* seg_dst_start,
+                         const int64_t* seg_len, int n_segments, float* out_dev, int64_t out_len,
+                         void* hip_stream);
+
+/* ---- multi-GPU: RCCL all-gather of the per-pair results over xGMI --------------------
+ * Problems are sharded by pair, one process per GPU; nothing is exchanged during the solves.  The
+ * single collective of the path gathers every rank's n_local 24-byte ffs_pair_result records:
+ *   recv_dev[r * n_local + i] = rank r's send_dev[i]      (ncclAllGather, latency-bound)
+ * Bootstrap as with NCCL: rank 0 calls ffs_comm_unique_id and publishes the 128 bytes out of band
+ * (torch.distributed's store, MPI, a file); every rank then calls ffs_comm_create.  librccl is
+ * resolved with dlopen at the first call (the copy already loaded in the process, e.g. torch's).
+ * Replaces: nothing in the reference (single process); the per-file call being sharded is
+ * ffsubsync.py:230-235. */
+typedef struct ffs_comm ffs_comm;
+typedef struct ffs_comm_id {
+    char internal[128];
+} ffs_comm_id;
+int ffs_comm_unique_id(ffs_comm_id* id_out);
+int ffs_comm_create(int device, int rank, int world_size, const ffs_comm_id* id, ffs_comm** out);
+int ffs_gather_results(ffs_comm* comm, const ffs_pair_result* send_dev, int64_t n_local,
+                       ffs_pair_result* recv_dev, void* hip_stream);
+int ffs_comm_destroy(ffs_comm* comm);
 
 /* Per-kernel timing with HIP events recorded on the caller's stream around every launch of the
  * hot kernels (used by bench.py for the roofline figures).  Kernel ids: */

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def _work(args):
     seed0, n, duration = args
-    from ffsubsync_amd import synth
+    from workloads import synth
     from oracle import aligners_oracle as orc
 
     problems = []

@@ -1,10 +1,11 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
-from ffsubsync_amd import batch, synth, _native
+from ffsubsync_amd import batch, _native
+from workloads import synth
 P = 1024
 specs = [synth.make_pair_spec(i) for i in range(P)]
-db = batch.build_device_batch(specs)
+db = synth.build_device_batch(specs)
 n = db.required_fft_length(6000)
 def run(nstreams, pif, steps=4):
     als = [batch.BatchAligner(n, 7, 6000, pairs_in_flight=pif) for _ in range(nstreams)]

@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
-from ffsubsync_amd import synth
+from workloads import synth
 from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
 from ffsubsync_amd.subtitle_raster import DeviceRaster
 spec = synth.make_pair_spec(0)

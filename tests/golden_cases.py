@@ -5,7 +5,7 @@ import hashlib
 
 import numpy as np
 
-from ffsubsync_amd import synth
+from workloads import synth
 from ffsubsync_amd.constants import FRAMERATE_RATIOS, candidate_ratios
 
 SR = 100

@@ -32,7 +32,7 @@ def test_exports_every_declared_symbol():
 
 def test_host_only_entry_points():
     lib = _native.load()
-    assert lib.ffs_version() >= 100
+    assert lib.ffs_version() >= 200
     assert _native.fft_length(0, 5) == 0
     for x in list(range(2, 3000)) + [2 ** k + d for k in range(4, 25) for d in (-1, 0, 1)]:
         # aligners.py:67-68
@@ -50,7 +50,8 @@ def test_plan_length_never_exceeds_reference_length():
         m = n // 3 if n % 3 == 0 else n  # a power of two, or three times one (column passes take a factor 3)
         assert n <= n_ref and (m & (m - 1)) == 0
         if mo is None:
-            assert n == n_ref
+            # every lag with a non-empty overlap, d in (-S, R): a circular correlation of length >= R+S-1
+            assert n >= r + s - 1 and (n == n_ref or n == n_ref // 4 * 3)
         elif n > 2:
             # the prefixes that can reach the lag window fit without wrapping onto themselves
             assert n >= max(min(s, r + mo), min(r, s + mo))
@@ -58,7 +59,9 @@ def test_plan_length_never_exceeds_reference_length():
     assert _native.plan_length(720000, 790000, 6000) == 3 << 18   # only 726 000 candidate samples reach the window
     assert _native.plan_length(790000, 720000, 6000) == 3 << 18   # ... and 726 000 reference samples
     assert _native.plan_length(790000, 790000, 6000) == 1 << 20   # needs 796 001
-    assert _native.plan_length(720000, 750751, 10 ** 7) == 1 << 21  # window as wide as the reference's
+    assert _native.plan_length(720000, 750751, 10 ** 7) == 3 << 19  # window as wide as the reference's: R+S-1 lags
+    assert _native.plan_length(720000, 750751, None) == 3 << 19 and _native.fft_length(720000, 750751) == 1 << 21
+    assert _native.plan_length(1 << 20, 1 << 20, None) == 1 << 21   # R+S = 2^21 exactly
     assert _native.plan_length(3000, 3000, 100) == 4096            # below the 3*2^k range
 
 

@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ffsubsync_amd import _native, synth
+from ffsubsync_amd import _native
+from workloads import synth
 from ffsubsync_amd.batch import gather_pair_results, shard_bounds
 from oracle import aligners_oracle as orc
 

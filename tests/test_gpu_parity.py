@@ -56,6 +56,11 @@ def test_raw_correlation_u8_matches_fp64(torch, log2n):
     err_b = np.abs(out_b.cpu().numpy() - eb).max()
     print("N=2^%d max abs err a=%.4g b=%.4g (margin %.4g)" % (log2n, err_a, err_b, tol))
     assert err_a < tol / 8 and err_b < tol / 8  # fp32 error must stay well inside the margin
+    # the same vectors bit-packed (FFS_DTYPE_U1): identical transform inputs, hence identical outputs
+    pk = lambda x: _native.pack_bits(d(x))
+    bit_a, bit_b = plan.correlate_full(_native.FFS_DTYPE_U1, pk(ref), (0, 1), pk(a), (0, 1), pk(b), (0.0, 0.96),
+                                       lens=(R, Sa, Sb))
+    assert torch.equal(bit_a, out_a) and torch.equal(bit_b, out_b)
     plan.close()
 
 
@@ -81,6 +86,10 @@ def test_raw_correlation_three_times_power_of_two(torch, n):
     err_b = np.abs(out_b.cpu().numpy() - eb).max()
     print("N=%d max abs err a=%.4g b=%.4g (margin %.4g)" % (n, err_a, err_b, tol))
     assert err_a < tol / 8 and err_b < tol / 8
+    pk = lambda x: _native.pack_bits(d(x))
+    bit_a, bit_b = plan.correlate_full(_native.FFS_DTYPE_U1, pk(ref), (0, 1), pk(a), (0, 1), pk(b), (0.0, 0.96),
+                                       lens=(R, Sa, Sb))
+    assert torch.equal(bit_a, out_a) and torch.equal(bit_b, out_b)
     if n <= 3 << 16:
         fa = rng.rand(Sa).astype(np.float32)
         out_f, _ = plan.correlate_full(_native.FFS_DTYPE_F32, d(ref.astype(np.float32)), (0, 1), d(fa), (0, 1))
@@ -92,16 +101,17 @@ def test_raw_correlation_three_times_power_of_two(torch, n):
 def test_three_times_power_of_two_plans_give_identical_records(torch, monkeypatch):
     """ffs_plan_length may pick 3*2^k; results must equal those of the power-of-two plan and of the
     reference-length plan, with the pruned and the full last pass."""
-    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
 
     assert _native.plan_length(720000, 750751, 6000) == 3 << 18
     specs = [synth.make_pair_spec(500 + i, duration_s=d) for i, d in enumerate((7200.0, 6900.0, 3500.0, 1700.0))]
     for group in (specs[:2], specs[2:3], specs[3:]):
-        db = batch.build_device_batch(group)
+        db = synth.build_device_batch(group)
         n3 = db.required_fft_length(6000)
         assert n3 % 3 == 0, n3
         n2 = 1 << int(np.ceil(np.log2(n3)))
-        n_full = db.required_fft_length(None)
+        n_full = db.required_fft_length(6000, reference_length=True)
         a = batch.BatchAligner(n3, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
         b = batch.BatchAligner(n2, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
         c = batch.BatchAligner(n_full, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
@@ -245,16 +255,21 @@ def test_float_inputs_with_window_and_three_times_power_of_two_length(torch):
 def test_batch_api_against_oracle(torch):
     """Throughput path: several 15-minute problems in one ffs_align_batch call, generated on the
     GPU, checked pair by pair against the CPU oracle on the same vectors."""
-    from ffsubsync_amd import batch, synth
+    from ffsubsync_amd import batch
+    from workloads import synth
 
     specs = [synth.make_pair_spec(100 + i, duration_s=900.0) for i in range(5)]
-    db = batch.build_device_batch(specs)
-    host = db.data.cpu().numpy()
-    for p, sp in enumerate(specs):  # GPU rasteriser == numpy rasteriser
+    db8 = synth.build_device_batch(specs, packed=False)
+    db = db8.to_bits()
+    host = db8.data.cpu().numpy()
+    bits = np.unpackbits(db.data.cpu().numpy(), bitorder="little")
+    for p, sp in enumerate(specs):  # GPU rasteriser == numpy rasteriser, bytes and bit-packed
         ref, cands = synth.pair_arrays(sp)
-        assert np.array_equal(host[db.offs[p, 0]: db.offs[p, 0] + db.lens[p, 0]], ref)
-        assert np.array_equal(host[db.offs[p, 3]: db.offs[p, 3] + db.lens[p, 3]], cands[2])
-    assert db.required_fft_length(6000) <= db.required_fft_length(None)
+        assert np.array_equal(host[db8.offs[p, 0]: db8.offs[p, 0] + db8.lens[p, 0]], ref)
+        assert np.array_equal(host[db8.offs[p, 3]: db8.offs[p, 3] + db8.lens[p, 3]], cands[2])
+        assert np.array_equal(bits[8 * db.offs[p, 0]: 8 * db.offs[p, 0] + db.lens[p, 0]], ref)
+        assert np.array_equal(bits[8 * db.offs[p, 3]: 8 * db.offs[p, 3] + db.lens[p, 3]], cands[2])
+    assert db.required_fft_length(6000) <= db.required_fft_length(None) <= db.required_fft_length(None, reference_length=True)
     al = batch.BatchAligner(db.required_fft_length(6000), 7, max_offset_samples=6000, pairs_in_flight=2)
     cres, pres = al.solve(db)
     for p, sp in enumerate(specs):
@@ -320,7 +335,7 @@ def test_exact_tie_rule_is_first_maximum_in_k(torch):
     """Where the exact integer correlation has tied maxima the reference's answer depends on fp64
     rounding noise; the device path is deterministic: np.argmax's rule (first k = largest offset)
     applied to the exact values.  Checked on both the direct and the FFT path."""
-    from ffsubsync_amd import synth
+    from workloads import synth
     from ffsubsync_amd.aligners import FFTAligner
 
     for n_ref, n_sub, seed in [(700, 300, 4), (700, 300, 8), (700, 300, 11), (3000, 2500, 4), (5000, 4000, 21)]:
@@ -336,10 +351,11 @@ def test_exact_tie_rule_is_first_maximum_in_k(torch):
 def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
     """With a lag window the last pass only evaluates the output bins the window can reach; the
     result records must be identical to those of the full column transform."""
-    from ffsubsync_amd import batch, synth
+    from ffsubsync_amd import batch
+    from workloads import synth
 
     specs = [synth.make_pair_spec(200 + i, duration_s=1200.0) for i in range(3)]
-    db = batch.build_device_batch(specs)
+    db = synth.build_device_batch(specs)
     n_fft = db.required_fft_length(6000)
     pruned = batch.BatchAligner(n_fft, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
     monkeypatch.setenv("FFS_DISABLE_PRUNED_PASS_C", "1")
@@ -354,10 +370,11 @@ def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
 def test_reference_half_rows_equal_all_rows(torch, monkeypatch):
     """The reference transform's rows k1 > N1/2 are rebuilt from the Hermitian mirror rows in the mid
     pass instead of being stored; storing all rows must give the same records."""
-    from ffsubsync_amd import batch, synth
+    from ffsubsync_amd import batch
+    from workloads import synth
 
     specs = [synth.make_pair_spec(700 + i, duration_s=d) for i, d in enumerate((7200.0, 5400.0, 2500.0))]
-    db = batch.build_device_batch(specs)
+    db = synth.build_device_batch(specs)
     for mo in (6000, None):
         n_fft = db.required_fft_length(mo)
         half = batch.BatchAligner(n_fft, 7, max_offset_samples=mo, pairs_in_flight=2).solve(db)
@@ -374,11 +391,12 @@ def test_block_segmented_mode_equals_single_transform(torch, monkeypatch):
     """With a narrow lag window a 3*2^k plan cuts every candidate into three blocks, correlates each
     with its stretch of the reference by a transform of a third of the length and adds the spectrum
     products before the way back; the records must equal those of the one-transform pipeline."""
-    from ffsubsync_amd import batch, synth
+    from ffsubsync_amd import batch
+    from workloads import synth
 
     specs = [synth.make_pair_spec(900 + i, duration_s=d) for i, d in enumerate((7200.0, 7100.0, 6500.0, 3500.0, 1700.0))]
     for group, n_cand_used in ((specs[:3], 7), (specs[3:4], 7), (specs[4:], 7)):
-        db = batch.build_device_batch(group)
+        db = synth.build_device_batch(group)
         n_fft = db.required_fft_length(6000)
         assert n_fft % 3 == 0 and n_fft // 3 >= 65536, n_fft
         a = batch.BatchAligner(n_fft, n_cand_used, max_offset_samples=6000, pairs_in_flight=2).solve(db)
@@ -407,7 +425,8 @@ def test_block_segmented_mode_equals_single_transform(torch, monkeypatch):
 def test_window_shortened_transform_equals_full_length(torch):
     """With a lag window the plan may use a transform shorter than the reference's N (no aliasing
     reaches the windowed lags, ffs_plan_length): every result record must equal the full-length one."""
-    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
     from ffsubsync_amd.aligners import _Vec, solve_pairs
 
     assert _native.plan_length(720000, 750751, 6000) == 3 << 18 and _native.fft_length(720000, 750751) == 1 << 21
@@ -419,8 +438,8 @@ def test_window_shortened_transform_equals_full_length(torch):
         assert np.array_equal(short[0]["offset"], full[0]["offset"]) and np.array_equal(short[0]["score"], full[0]["score"])
         assert np.array_equal(short[1], full[1])
     specs = [synth.make_pair_spec(300 + i, duration_s=2400.0) for i in range(3)]
-    db = batch.build_device_batch(specs)
-    n_short, n_full = db.required_fft_length(6000), db.required_fft_length(None)
+    db = synth.build_device_batch(specs)
+    n_short, n_full = db.required_fft_length(6000), db.required_fft_length(6000, reference_length=True)
     assert n_short < n_full
     a = batch.BatchAligner(n_short, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
     b = batch.BatchAligner(n_full, 7, max_offset_samples=6000, pairs_in_flight=2).solve(db)
@@ -461,11 +480,12 @@ def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
     imaginary half of the last candidate transform (k_mid_packed, Hermitian split across row pairs);
     results must match the default separate-reference path on a 7-ratio batch, a 1-candidate problem
     and a window-less problem."""
-    from ffsubsync_amd import _native, batch, synth
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
     from ffsubsync_amd.aligners import _Vec, solve_pairs
 
     specs = [synth.make_pair_spec(400 + i, duration_s=3000.0) for i in range(3)]
-    db = batch.build_device_batch(specs)
+    db = synth.build_device_batch(specs)
     n = db.required_fft_length(6000)
     c = SMALL["config1_none"]
     one = [(_Vec(c["ref"]), [_Vec(c["cands"][0])])]
@@ -490,7 +510,7 @@ def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
 def test_maximum_length_solve(torch):
     """Largest supported transform (N = 2^24, 46 h of 100 Hz frames): a windowed and a window-less
     solve through the batch entry point, checked against an exact evaluation of the winning lag."""
-    from ffsubsync_amd import synth
+    from workloads import synth
     from ffsubsync_amd.aligners import FFTAligner
 
     ref, sub = synth.simple_pair(9_000_000, 7_500_000, -4321, seed=9)
@@ -535,7 +555,7 @@ def test_aligner_is_usable_from_a_thread_pool(torch):
     every thread gets its own plan, so concurrent solves must not disturb each other."""
     from concurrent.futures import ThreadPoolExecutor
 
-    from ffsubsync_amd import synth
+    from workloads import synth
     from ffsubsync_amd.aligners import FFTAligner
 
     jobs = []

@@ -138,88 +138,3 @@ def test_end_to_end_pcm_to_offset():
     cands = rasterize_candidates(s, e, m, ratios)
     (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(labels, cands)
     assert winner is cands[true_idx] and offset == shift
-
-
-def test_video_speech_transformer_over_a_fake_ffmpeg_pipe(monkeypatch):
-    """The reference's own technique (tests/test_progress.py:47-80): Popen is replaced by a process
-    whose stdout yields PCM; the drop-in VideoSpeechTransformer must read it in 100 s buffers, fire the
-    progress callback monotonically and produce the oracle's labels."""
-    import ffsubsync_amd.speech_transformers as st
-
-    pcm, _ = vo.synth_pcm(480 * 23000 + 11, seed=12)
-    raw = pcm.tobytes()
-
-    class FakeStdout:
-        def __init__(self):
-            self.pos = 0
-
-        def read(self, n):
-            blob = raw[self.pos:self.pos + n]
-            self.pos += len(blob)
-            return blob
-
-    class FakeProcess:
-        def __init__(self, cmd, **kw):
-            FakeProcess.cmd = cmd
-            self.stdout = FakeStdout()
-
-        def wait(self):
-            return 0
-
-    monkeypatch.setattr(st.subprocess, "Popen", FakeProcess)
-    seen = []
-    t = st.VideoSpeechTransformer("subs_then_auditok", 100, 48000, 0.0, start_seconds=3, ref_stream="0:a:1",
-                                  max_duration_seconds=600.0, progress_handler=seen.append)
-    assert t.fit("movie.mkv") is t
-    cmd = FakeProcess.cmd
-    assert cmd[0] == "ffmpeg" and cmd[cmd.index("-ss") + 1] == "0:00:03" and cmd[cmd.index("-map") + 1] == "0:a:1"
-    assert cmd[cmd.index("-i") + 1] == "movie.mkv" and cmd[-1] == "-" and cmd[cmd.index("-ar") + 1] == "48000"
-    want = np.concatenate([vo.tokenize_chunk(vo.detect_fast(pcm[o:o + 4800000]) > 0.5, 0.0)
-                           for o in range(0, pcm.size, 4800000)])
-    assert np.array_equal(t.transform(), want) and t.video_speech_results_.dtype == np.float64
-    secs = [p.processed_seconds for p in seen]
-    assert len(secs) == 3 and secs == sorted(secs) and seen[-1].total_seconds == 600.0 and 0 < seen[0].fraction <= 1
-    with pytest.raises(ValueError, match="unknown vad"):
-        st.VideoSpeechTransformer("nonsense", 100, 48000, 0.0).fit("x.mkv")
-
-
-def test_multi_segment_reference_on_four_threads(monkeypatch):
-    """MultiSegmentVideoSpeechTransformer with the real GPU detector behind a fake ffmpeg that honours
-    -ss / -t: four worker threads run the VAD concurrently; the sparse vector must equal the oracle's
-    labels inside the sampled windows and be zero elsewhere."""
-    import ffsubsync_amd.speech_transformers as st
-
-    total_s = 600
-    pcm, _ = vo.synth_pcm(480 * 100 * total_s, seed=21)
-    full = vo.detect_fast(pcm)
-
-    def seconds(txt):
-        h, m, s = txt.split(":")
-        return int(h) * 3600 + int(m) * 60 + int(float(s))
-
-    class FakeProcess:
-        def __init__(self, cmd, **kw):
-            start = seconds(cmd[cmd.index("-ss") + 1]) if "-ss" in cmd else 0
-            dur = seconds(cmd[cmd.index("-t") + 1])
-            self.raw = pcm[start * 48000: (start + dur) * 48000].tobytes()
-            self.pos = 0
-            self.stdout = self
-
-        def read(self, n):
-            blob = self.raw[self.pos:self.pos + n]
-            self.pos += len(blob)
-            return blob
-
-        def wait(self):
-            return 0
-
-    monkeypatch.setattr(st.subprocess, "Popen", FakeProcess)
-    monkeypatch.setattr(st, "_probe_duration", lambda *a, **k: float(total_s))
-    t = st.MultiSegmentVideoSpeechTransformer("energy", 100, 48000, 0.0, segment_count=6, segment_duration=30,
-                                              parallel_workers=4).fit("ref.mkv")
-    sparse = t.transform()
-    assert sparse.size == total_s * 100 + 2
-    want = np.zeros_like(sparse)
-    for s in t._segment_starts(float(total_s)):
-        want[s * 100: (s + 30) * 100] = full[s * 100: (s + 30) * 100]
-    assert np.array_equal(sparse, want) and sparse.sum() > 0

@@ -1,0 +1,268 @@
+"""GPU tests of the pieces added around the aligner core: bit-packed vectors, the zero-overlap rule,
+per-candidate pool quotas, the device scatter of the multi-segment reference, the bulk .npz feeder,
+stream ordering on one plan and the one-rank RCCL gather."""
+import io
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import aligners_oracle as orc
+from oracle import vad_oracle as vo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def test_pack_bits_matches_numpy_packbits(torch):
+    from ffsubsync_amd import _native
+
+    rng = np.random.RandomState(1)
+    for n in (1, 31, 32, 33, 63, 4096, 100003, 720000):
+        x = (rng.rand(n) < 0.4).astype(np.uint8) * rng.randint(1, 255, n).astype(np.uint8)  # any non-zero byte is a 1
+        want = np.packbits(x != 0, bitorder="little")
+        want = np.concatenate([want, np.zeros(-want.size % 4, np.uint8)])
+        got = _native.pack_bits(torch.from_numpy(x).cuda()).view(torch.uint8).cpu().numpy()
+        assert np.array_equal(got, want), n
+        # unaligned source, float source with a threshold
+        buf = torch.from_numpy(np.concatenate([[7], x]).astype(np.uint8)).cuda()
+        assert np.array_equal(_native.pack_bits(buf[1:]).view(torch.uint8).cpu().numpy(), want)
+        f = np.where(x != 0, 1.0, rng.choice([0.0, -0.5, 0.25], n)).astype(np.float32)
+        assert np.array_equal(_native.pack_bits(torch.from_numpy(f).cuda(), 0.5).view(torch.uint8).cpu().numpy(), want)
+        assert np.array_equal(_native.unpack_bits(_native.pack_bits(torch.from_numpy(x).cuda()), n).cpu().numpy(), x != 0)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "late_start"])
+def test_bit_packed_rasters_match_reference(torch, name):
+    from ffsubsync_amd import _native
+
+    gold = np.load(os.path.join(HERE, "golden", "raster_golden.npz"))
+    s, e, m = gold[name + "_start_us"], gold[name + "_end_us"], gold[name + "_meta"]
+    ss = int(gold[name + "_start_seconds"])
+    for j, r in enumerate(float(x) for x in gold["ratios"]):
+        words, n = _native.rasterize_subtitles(s, e, m, r, 100, ss, packed=True)
+        want = gold["%s_r%d" % (name, j)]
+        assert n == want.size
+        assert np.array_equal(np.unpackbits(words.view(torch.uint8).cpu().numpy(), bitorder="little")[:n], want)
+
+
+def test_lags_without_overlap_follow_the_zero_rule(torch):
+    """Lags with an empty overlap are exactly 0 in the reference's `convolve` (fp64 noise ~1e-10 around 0).
+    When every real lag scores below 0 the maximum is one of them; the device reports score 0.0 at the
+    largest such lag (np.argmax's first k).  The reference's own pick among those noise-level ties is not
+    defined, so only the score is compared with the oracle."""
+    from ffsubsync_amd.aligners import FFTAligner
+
+    rng = np.random.RandomState(3)
+    for R, S in ((5000, 3000), (3000, 5000), (700, 300)):  # FFT path twice, direct kernel once
+        ref = np.ones(R)
+        sub = np.zeros(S)  # +1 against -1 everywhere: every overlapping lag is negative
+        score, offset = FFTAligner(None).fit_transform(ref, sub, get_score=True)
+        o_score, _ = orc.fft_align(ref, sub, None)
+        n_ref = orc.fft_length(R, S)
+        assert float(score) == 0.0 and abs(float(o_score)) < 1e-6
+        assert offset == n_ref - 1 - S and offset >= R  # k = 0: the first maximum
+        # a window that keeps real lags only changes nothing about them
+        sub2 = (rng.rand(S) < 0.5).astype(float)
+        ref2 = (rng.rand(R) < 0.5).astype(float)
+        got = FFTAligner(None).fit_transform(ref2, sub2, get_score=True)
+        exp = orc.fft_align(ref2, sub2, None)
+        assert got[1] == exp[1] and float(got[0]) == pytest.approx(float(exp[0]), rel=1e-9)
+    # Python negative-slice window of short inputs (R = S = 3000, max 6000 -> lags [-3000, -2192]): the
+    # lag -3000 has no overlap; it only wins when everything else is negative
+    ref, sub = np.ones(3000), np.zeros(3000)
+    score, offset = FFTAligner(6000).fit_transform(ref, sub, get_score=True)
+    assert float(score) == 0.0 and offset == -3000
+
+
+def test_one_degenerate_pair_does_not_change_its_neighbours(torch):
+    """Per-candidate pool quotas: a silent reference (thousands of exactly tied lags in every candidate)
+    shares a batch with ordinary pairs; the ordinary pairs' records are those of a batch without it, and the
+    degenerate pair still gets the exact answer."""
+    from ffsubsync_amd.aligners import _Vec, solve_pairs
+    from workloads import synth
+
+    rng = np.random.RandomState(11)
+    normal = []
+    for i in range(3):
+        spec = synth.make_pair_spec(40 + i, duration_s=300.0)
+        ref, cands = synth.pair_float_arrays(spec)
+        normal.append((_Vec(ref), [_Vec(c) for c in cands]))
+    silent_ref = np.zeros(30000)
+    subs = [0.4 * (rng.rand(20000 + 100 * j) < 0.3) for j in range(7)]
+    silent = (_Vec(silent_ref), [_Vec(s) for s in subs])
+    alone_c, alone_p = solve_pairs(normal, 6000, 6000)
+    mixed_c, mixed_p = solve_pairs(normal[:1] + [silent] + normal[1:], 6000, 6000)
+    keep = [0, 2, 3]
+    assert np.array_equal(mixed_p[keep], alone_p)
+    for f in ("score", "offset", "flags"):
+        assert np.array_equal(mixed_c[keep][f], alone_c[f])
+    assert not (mixed_c["flags"] & 2).any()
+    for j, s in enumerate(subs):
+        exp = orc.fft_align(silent_ref, s, 6000)
+        conv, S = orc.convolve_full(silent_ref, s)
+        m = orc.mask_extreme_offsets(conv, S, 6000)
+        k = int(np.argmax(m >= m.max() - 1e-6))
+        assert int(mixed_c[1, j]["offset"]) == len(m) - 1 - k - S
+        assert float(mixed_c[1, j]["score"]) == pytest.approx(float(exp[0]), rel=1e-9)
+
+
+def test_device_scatter_of_the_multi_segment_reference(torch):
+    """assemble_sparse_reference == the reference's host loop (speech_transformers.py:871-890), with the
+    window labels produced by the GPU detector from four threads at once."""
+    from ffsubsync_amd.speech_transformers import assemble_sparse_reference, detect_device
+
+    total_s, win = 600, 30
+    pcm, _ = vo.synth_pcm(480 * 100 * total_s, seed=21)
+    full = vo.detect_fast(pcm)
+    starts = [0, 114, 228, 342, 456, 570, 585]  # the last window is clipped at the end, the last two overlap
+    dev_pcm = torch.from_numpy(pcm).cuda()
+    labels = [None] * len(starts)
+
+    def work(i):
+        torch.cuda.set_device(0)
+        a, b = starts[i] * 48000, min((starts[i] + win) * 48000, pcm.size)
+        labels[i] = detect_device(dev_pcm[a:b], 100, 48000, 0.0)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(starts))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    for s, lab in zip(starts, labels):
+        assert np.array_equal(lab.cpu().numpy(), full[s * 100: s * 100 + lab.numel()])
+    labels[-1] = 1.0 - labels[-1]  # make the order of the two overlapping windows matter: the later one wins
+    duration = float(total_s) - 2.0  # ... and let the vector end inside the last two windows (clipping)
+    sparse = assemble_sparse_reference(labels, starts, duration, 100).cpu().numpy()
+    want = np.zeros(int(duration * 100) + 2)
+    for s, lab in zip(starts, labels):  # the reference's loop, speech_transformers.py:886-890
+        seg = lab.cpu().numpy()
+        begin = int(s * 100)
+        end = min(begin + len(seg), len(want))
+        if end > begin:
+            want[begin:end] = seg[: end - begin]
+    assert sparse.dtype == np.float32 and np.array_equal(sparse, want.astype(np.float32)) and sparse.sum() > 0
+    with pytest.raises(ValueError, match="Unable to detect speech in any sampled segment"):
+        assemble_sparse_reference([torch.zeros(100, device="cuda")], [3], 60.0, 100)
+
+
+def test_bulk_npz_feeder_and_aligner(torch, tmp_path):
+    """load_speech_batch: .npz/.npy -> bit-packed HBM vectors (DeserializeSpeechTransformer semantics), usable
+    as the reference of a solve."""
+    from ffsubsync_amd.aligners import FFTAligner
+    from ffsubsync_amd.speech_transformers import DeserializeSpeechTransformer, load_speech_batch, serialize_speech
+    from workloads import synth
+
+    files, hosts = [], []
+    for i in range(3):
+        ref, sub = synth.simple_pair(50000 + 37 * i, 42000, 250 + i, seed=60 + i)
+        speech = np.where(ref > 0, 1.0, [0.0, 0.3, 0.7][i])  # serialized labels below 1 become non_speech_label
+        path = str(tmp_path / ("ref%d.npz" % i))
+        serialize_speech(path, speech)
+        files.append(path)
+        hosts.append((sub, DeserializeSpeechTransformer(-0.25).fit(path).transform()))
+    np.save(str(tmp_path / "w.npy"), np.array([0.0, 1.0, 1.5, 1.0]))
+    rasters = load_speech_batch(files + [str(tmp_path / "w.npy")], non_speech_label=-0.25)
+    assert isinstance(rasters[3], np.ndarray) and rasters[3].tolist() == [-0.25, 1.0, 1.5, 1.0]  # not two-level
+    for r, (sub, host) in zip(rasters[:3], hosts):
+        assert r.packed and len(r) == host.size and (r.lo, r.hi) == (-0.25, 1.0)
+        assert np.array_equal(np.asarray(r), host)
+        got = FFTAligner(6000).fit_transform(r, sub, get_score=True)
+        exp = orc.fft_align(host, sub, 6000)
+        assert got[1] == exp[1] and float(got[0]) == pytest.approx(float(exp[0]), rel=1e-9)
+
+
+def test_chunked_detector_loop_over_a_pipe(torch):
+    """PCMSpeechTransformer with the auditok-style GPU detector fed by a pipe-like object: 100 s buffers
+    (speech_transformers.py:683-685), one tokenizer pass per buffer, monotonic progress, float64 labels."""
+    from ffsubsync_amd.speech_transformers import PCMSpeechTransformer
+
+    pcm, _ = vo.synth_pcm(480 * 23000 + 11, seed=12)
+
+    class Pipe:
+        def __init__(self, raw):
+            self.raw, self.pos, self.reads = raw, 0, []
+
+        def read(self, n):
+            self.reads.append(n)
+            blob = self.raw[self.pos:self.pos + n]
+            self.pos += len(blob)
+            return blob
+
+    seen = []
+    pipe = Pipe(pcm.tobytes())
+    t = PCMSpeechTransformer("subs_then_auditok", 100, 48000, 0.0, progress_handler=seen.append)
+    assert t.fit(pipe) is t
+    assert set(pipe.reads) == {960 * 10000}
+    want = np.concatenate([vo.tokenize_chunk(vo.detect_fast(pcm[o:o + 4800000]) > 0.5, 0.0)
+                           for o in range(0, pcm.size, 4800000)])
+    assert np.array_equal(t.transform(), want) and t.video_speech_results_.dtype == np.float64
+    assert len(seen) == 3 and seen == sorted(seen)
+    with pytest.raises(ValueError, match="unknown vad"):
+        PCMSpeechTransformer("nonsense", 100, 48000, 0.0).fit(io.BytesIO(b"\0" * 9600))
+    with pytest.raises(ValueError, match="Unable to detect speech"):
+        PCMSpeechTransformer("energy", 100, 48000, 0.0).fit(io.BytesIO(b""))
+
+
+def test_calls_on_two_streams_share_one_plan(torch):
+    """A plan's workspace is reused by every call; calls issued on different streams are ordered by the
+    library, so alternating streams gives the same records as one stream."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(800 + i, duration_s=1800.0) for i in range(6)]
+    db = synth.build_device_batch(specs)
+    al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=2)
+    _, want = al.solve(db)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for rep in range(6):
+        with torch.cuda.stream(s1 if rep % 2 == 0 else s2):
+            outs.append(al.solve_async(db, rep % 3 * 2, rep % 3 * 2 + 2))
+    torch.cuda.synchronize()
+    for rep, (_, pair_out) in enumerate(outs):
+        got = pair_out.cpu().numpy().view(want.dtype)[:2]
+        assert np.array_equal(got, want[rep % 3 * 2: rep % 3 * 2 + 2])
+    al.plan.close()
+
+
+def test_one_rank_rccl_gather_and_sharded_solve(torch):
+    """The N > 1 path of bench.py with one rank, end to end on the GPU: torch.distributed 'nccl' (= RCCL)
+    process group, ffs_comm_create bootstrapped through its store, the shard solved with the HIP path,
+    ffs_gather_results (RCCL C API) == torch's all_gather_into_tensor == the local records."""
+    import torch.distributed as dist
+
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        comm = batch.make_comm(0, 1)
+        specs = [synth.make_pair_spec(900 + i, duration_s=900.0) for i in range(5)]
+        db = synth.build_device_batch(specs)
+        lo, hi = batch.shard_bounds(len(specs), 0, 1)
+        al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=4)
+        _, pair_out = al.solve_async(db, lo, hi)
+        mine = batch.gather_pair_results(pair_out, len(specs), 1, comm=comm)
+        theirs = batch.gather_pair_results(pair_out, len(specs), 1)
+        torch.cuda.synchronize()
+        assert torch.equal(mine, pair_out) and torch.equal(theirs, pair_out)
+        pres = mine.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
+        for p, sp in enumerate(specs):
+            assert int(pres[p]["best_cand"]) == sp.true_ratio_index
+        comm.close()
+        al.plan.close()
+    finally:
+        dist.destroy_process_group()

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-from .constants import SAMPLE_RATE, candidate_ratios
+from ffsubsync_amd.constants import SAMPLE_RATE, candidate_ratios
 
 
 @dataclass
@@ -130,3 +130,56 @@ def make_subtitle_records(seed: int, duration_s: float = 5400.0, mean_gap_s: flo
     start_us = np.rint((ends - durs) * 1e3).astype(np.int64) * 1000
     end_us = np.rint(ends * 1e3).astype(np.int64) * 1000
     return start_us, end_us, np.zeros(start_us.size, dtype=np.uint8)
+
+
+def build_device_batch(specs: Sequence[PairSpec], device=None, chunk_pairs: int = 32, packed: bool = True):
+    """The specs' vectors rasterised straight into HBM with torch ops (index_add + cumsum) as one
+    ``ffsubsync_amd.batch.DeviceBatch``: bit-packed (FFS_DTYPE_U1, the library's native format; the bytes
+    of each chunk of pairs are packed as soon as they are rasterised) unless ``packed`` is False (0/1 bytes)."""
+    import torch
+
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.batch import DeviceBatch
+
+    _native.require_gpu()
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    n_pairs = len(specs)
+    n_vec = 1 + len(specs[0].cand_len)
+    lens = np.zeros((n_pairs, n_vec), dtype=np.int64)
+    lo = np.zeros((n_pairs, n_vec), dtype=np.float64)
+    hi = np.ones((n_pairs, n_vec), dtype=np.float64)
+    for p, sp in enumerate(specs):
+        lens[p, 0] = sp.ref_len
+        lens[p, 1:] = sp.cand_len
+        hi[p, 1:] = sp.cand_amp
+    padded = (lens + 63) // 64 * 64
+    offs = np.concatenate([[0], np.cumsum(padded.ravel())[:-1]]).reshape(n_pairs, n_vec).astype(np.int64)
+    total = int(padded.sum())
+    data = torch.zeros(total // 8 if packed else total, dtype=torch.uint8, device=device)
+    for p0 in range(0, n_pairs, chunk_pairs):
+        p1 = min(p0 + chunk_pairs, n_pairs)
+        base = int(offs[p0, 0])
+        end = int(offs[p1 - 1, -1] + padded[p1 - 1, -1])
+        starts, ends = [], []
+        for p in range(p0, p1):
+            sp = specs[p]
+            for v, (s, e) in enumerate([(sp.ref_starts, sp.ref_ends)] + list(zip(sp.cand_starts, sp.cand_ends))):
+                n = int(lens[p, v])
+                o = int(offs[p, v]) - base
+                starts.append(np.clip(s, 0, n) + o)
+                ends.append(np.clip(e, 0, n) + o)
+        starts = torch.from_numpy(np.concatenate(starts)).to(device)
+        ends = torch.from_numpy(np.concatenate(ends)).to(device)
+        delta = torch.zeros(end - base + 1, dtype=torch.int32, device=device)
+        delta.index_add_(0, starts, torch.ones_like(starts, dtype=torch.int32))
+        delta.index_add_(0, ends, -torch.ones_like(ends, dtype=torch.int32))
+        chunk = (torch.cumsum(delta[:-1], 0) > 0).to(torch.uint8)
+        del delta
+        if packed:  # vector offsets are multiples of 64 bytes = 512 samples = 16 words
+            _native.pack_bits(chunk, out=data[base // 8: end // 8].view(torch.int32))
+        else:
+            data[base:end] = chunk
+        del chunk
+    if packed:
+        return DeviceBatch(data, offs // 8, lens, lo, hi, _native.FFS_DTYPE_U1)
+    return DeviceBatch(data, offs, lens, lo, hi, _native.FFS_DTYPE_U8)
