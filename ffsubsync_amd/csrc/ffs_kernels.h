@@ -29,6 +29,9 @@ constexpr int KBLK = 6;   // nominees kept per pass-C block
 constexpr int KNOM = 16;  // nominees kept per candidate
 constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
+constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
+constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
+
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
     const void* a;
     const void* b;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
                                                          const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
                                                          int slots_per_pair, int nt, int pf_ahead,
-                                                         unsigned* __restrict__ pf_sink, int ref_half) {
+                                                         unsigned* __restrict__ pf_sink, int half_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     typedef ColShape<L> CS;
@@ -316,29 +319,38 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
     } else if constexpr (DT == 2) {
-        // Bit-packed inputs: the tile's L rows x C columns are L windows of C (+ up to 31 alignment) bits
-        // per vector.  The block copies each window's NW dwords to LDS first (a few coalesced dword loads
-        // per thread, an eighth of the byte path's input lines), then every thread picks its 2 x 16 bits.
-        constexpr int NW = (C + 62) / 32;
-        unsigned* stage = reinterpret_cast<unsigned*>(smem);  // [2][L][NW]; the FFT's first LDS write is behind a barrier
+        // Bit-packed inputs: the tile's L rows x C columns are L windows of C bits per vector, at arbitrary
+        // bit offsets.  The block first builds the ALIGNED windows in LDS -- one thread per 32 window bits:
+        // two dword loads and a funnel shift (v_alignbit) -- so that bit c of a row's window is column c;
+        // afterwards a thread's 2 x 16 samples cost one LDS read (compile-time offset), one bit-field
+        // extract and one select each.  An eighth of the byte path's input lines, no prefetch blocks.
+        constexpr int CW = (C + 31) / 32;  // dwords per window
+        unsigned* stage = reinterpret_cast<unsigned*>(smem);  // [2][L][CW]; the FFT's first LDS write is behind a barrier
         const int col0 = tile * C;
-        for (int i = threadIdx.x; i < 2 * L * NW; i += LT * C) {
-            const int h = i / (L * NW), row = (i / NW) % L, j = i % NW;
+        for (int i = threadIdx.x; i < 2 * L * CW; i += LT * C) {
+            const int h = i / (L * CW), row = (i / CW) % L, j = i % CW;
             const unsigned* src = reinterpret_cast<const unsigned*>(h ? d.b : d.a);
             const int off = h ? d.off_b : d.off_a, len = h ? d.len_b : d.len_a, lead = h ? d.lead_b : d.lead_a;
-            const int w = ((off + row * N2 + col0) >> 5) + j;  // arithmetic shift: floor
-            unsigned val = 0;  // only dwords that hold a valid sample (bits off+lead .. off+len-1) are touched
-            if (len > lead && w >= ((off + lead) >> 5) && w <= ((off + len - 1) >> 5)) val = src[w];
-            stage[i] = val;
+            const int bit0 = off + row * N2 + col0 + 32 * j;  // first bit of this dword of the window
+            const int w = bit0 >> 5;                          // arithmetic shift: floor
+            // only dwords that hold a valid sample (bits off+lead .. off+len-1) are touched
+            const int w_lo = (off + lead) >> 5, w_hi = (off + len - 1) >> 5;
+            unsigned d0 = 0, d1 = 0;
+            if (len > lead) {
+                if (w >= w_lo && w <= w_hi) d0 = src[w];
+                if (w + 1 >= w_lo && w + 1 <= w_hi) d1 = src[w + 1];
+            }
+            stage[i] = __builtin_amdgcn_alignbit(d1, d0, (unsigned)bit0 & 31u);
         }
         __syncthreads();
+        const unsigned* wa = stage + u * CW + (c >> 5);
+        const unsigned* wb = wa + L * CW;
+        const unsigned sh = c & 31;
         unsigned ba[16], bb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = u + LT * q;
-            const int pa = ((d.off_a + row * N2 + col0) & 31) + c, pb = ((d.off_b + row * N2 + col0) & 31) + c;
-            ba[q] = (stage[row * NW + (pa >> 5)] >> (pa & 31)) & 1u;
-            bb[q] = (stage[(L + row) * NW + (pb >> 5)] >> (pb & 31)) & 1u;
+            ba[q] = __builtin_amdgcn_ubfe(wa[LT * q * CW], sh, 1u);
+            bb[q] = __builtin_amdgcn_ubfe(wb[LT * q * CW], sh, 1u);
         }
         float xa[16], xb[16];
         map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
@@ -356,9 +368,14 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
-    // ref_half: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
-    // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all
-    const int k1_end = (ref_half && blockIdx.y % xf_per_pair == 0) ? L / 2 + 1 : L;
+    // HALF_REF: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
+    // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all.
+    // HALF_LAST: with an odd candidate count the last packed transform carries ONE real candidate; its
+    // product with the reference spectrum stays Hermitian, so neither its rows k1 > L/2 nor their
+    // results are ever needed (the last pass rebuilds them by conjugation, see k_pass_c*).
+    const int xi = blockIdx.y % xf_per_pair;
+    const int k1_end = (((half_flags & HALF_REF) && xi == 0) || ((half_flags & HALF_LAST) && xi == xf_per_pair - 1))
+                           ? L / 2 + 1 : L;
     if constexpr (CS::R3) {
         // Radix-3 columns: the last step (the combine) reads its inputs from LDS anyway, so the outputs
         // are re-dealt for the store: thread (cp, rg) produces the rows k1 = kg + 2*LTI*j + LI*r (j < 8;
@@ -467,11 +484,12 @@ FFS_DEV void mirror_load(cf (&v)[16], const cf* lds, const RowAddr<L>& addr, std
 template <int L, bool SEP>
 __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                 float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
-                                                const cf* __restrict__ ts, int ref_half) {
+                                                const cf* __restrict__ ts, int half_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
     constexpr int ROWS = 256 / LT;
+    const int ref_half = half_flags & HALF_REF;
     constexpr int ROW_STRIDE = RowAddr<L>::ROW_ELEMS;
     const int row = threadIdx.x / LT;
     const int u = threadIdx.x % LT;
@@ -492,6 +510,9 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
         }
     };
 
+    // HALF_LAST (one row per block): rows above N1/2 of the single-candidate slot are never needed
+    const int s_end = (L == 4096 && SEP && (half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
+    if (s_end <= 1) return;  // block-uniform: nothing to do for this row (single-candidate solves)
     TwRegs<L> twr;
     twr.load(tw, u);
     cf rr[16];
@@ -521,7 +542,7 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R)/N
 
     const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
-    for (int s = 1; s < n_slots; ++s) {
+    for (int s = 1; s < s_end; ++s) {
         cf* buf = base + (size_t)s * N;
         cf v[16];
 #pragma unroll
@@ -551,8 +572,9 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 template <int L>
 __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                     int n_blocks, float inv_n, const cf* __restrict__ tw,
-                                                    const cf* __restrict__ tb, const cf* __restrict__ ts, int ref_half) {
+                                                    const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
     static_assert(L == 4096, "one row per 256-thread block");
+    const int ref_half = half_flags & HALF_REF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -561,6 +583,9 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
     RowAddr<L> addr(0, u);
     const int C = 1 << log2C;
     cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
+    // HALF_LAST: rows above N1/2 of the single-candidate slot (the last one) are never needed
+    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
+    if (s_end <= 1) return;
     const bool mirrored = ref_half && k1 > N1 / 2;
     const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
     const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
@@ -573,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
     // for two slots instead of one (half the re-reads, 22 instead of 28 row transforms per row for seven
     // candidates) at the price of a second accumulator row -- two blocks per CU instead of three, which
     // costs this kind of kernel about 9 %.
-    for (int s = 1; s < n_slots; s += 2) {
-        const bool two = s + 1 < n_slots;
+    for (int s = 1; s < s_end; s += 2) {
+        const bool two = s + 1 < s_end;
         cf acc_a[16], acc_b[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc_a[q] = acc_b[q] = mk(0.f, 0.f);
@@ -619,6 +644,84 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
                 (base + (size_t)(s + 1) * N + q * qstride)[off0] = cmul(acc_b[q], w);
             }
         }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Block-segmented mid pass, three candidate slots per sweep over the blocks.  The transformed reference row
+// conj(R_k)/N of the current block is needed once per slot; parking it in LDS (every thread re-reads only
+// the sixteen values it wrote itself: no barrier, no conflicts) frees its 32 registers for a third
+// accumulator row.  With HALF_LAST a seven-ratio solve is three full slots plus one half slot, so the rows
+// above N1/2 are done in ONE sweep (every reference row read and transformed once) and the others in two.
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_mid_seg3(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                                     int n_blocks, float inv_n, const cf* __restrict__ tw,
+                                                     const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
+    static_assert(L == 4096, "one row per 256-thread block");
+    const int ref_half = half_flags & HALF_REF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]
+    const int u = threadIdx.x;
+    const int k1 = blockIdx.x;
+    RowAddr<L> addr(0, u);
+    const int C = 1 << log2C;
+    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
+    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
+    if (s_end <= 1) return;
+    const bool mirrored = ref_half && k1 > N1 / 2;
+    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
+    const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
+    const size_t qstride = (size_t)LT * N1;
+    const float sgn = mirrored ? inv_n : -inv_n;
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    for (int s0 = 1; s0 < s_end; s0 += 3) {
+        const int ns = (s_end - s0) < 3 ? (s_end - s0) : 3;
+        cf acc0[16], acc1[16], acc2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc0[q] = acc1[q] = acc2[q] = mk(0.f, 0.f);
+        for (int k = 0; k < n_blocks; ++k) {
+            cf* grp = base + (size_t)k * n_slots * N;
+            {
+                cf rr[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
+                fft_regs<L>(rr, lds, u, addr, twr);
+                if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+                    __syncthreads();
+                    mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+                    __syncthreads();
+                    mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+                }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R_k)/N
+            }
+            auto slot = [&](cf(&acc)[16], int j) {
+                cf v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)(s0 + j) * N + q * qstride)[off0];
+                fft_regs<L>(v, lds, u, addr, twr);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], s_rr[q * LT + u]);
+            };
+            slot(acc0, 0);
+            if (ns > 1) slot(acc1, 1);
+            if (ns > 2) slot(acc2, 2);
+        }
+        auto finish = [&](cf(&acc)[16], int j) {
+            fft_regs<L>(acc, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+                (base + (size_t)(s0 + j) * N + q * qstride)[off0] = cmul(acc[q], w);
+            }
+        };
+        finish(acc0, 0);
+        if (ns > 1) finish(acc1, 1);
+        if (ns > 2) finish(acc2, 2);
     }
 }
 
@@ -917,7 +1020,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
                                                          PoolHeader* __restrict__ pool, PoolEntry* __restrict__ entries,
                                                          int log2CL, const cf* __restrict__ tw3,
                                                          const int* __restrict__ xlist, PoolBest* __restrict__ pbest,
-                                                         int pool_shares) {
+                                                         int pool_shares, int half_last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
@@ -949,8 +1052,20 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
     TwRegs<CS::LI> twr;
     twr.load(tw, CS::R3 ? u / 3 : u);
     cf v[16];
+    if (half_last && kp == n_packed - 1) {
+        // HALF_LAST: the single-candidate slot holds rows 0..L/2 only; its spectrum product is Hermitian, and
+        // after the row pass that symmetry reads  Y[L-k1][m1] = conj(Y[k1][m1])  (same column!), so the
+        // missing rows are the conjugates of stored ones
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
+        for (int q = 0; q < 16; ++q) {
+            const int row = u + LT * q;
+            const cf y = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(row <= L / 2 ? row : L - row) << log2CL)];
+            v[q] = row <= L / 2 ? y : mk(y.x, -y.y);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
+    }
     cf* s_tw3 = lds + L * C;
     if constexpr (CS::R3) {
         for (int i = tid; i < L; i += NT) s_tw3[i] = tw3[i];
@@ -1012,7 +1127,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
                                                                 PoolHeader* __restrict__ pool,
                                                                 PoolEntry* __restrict__ entries, int log2CL,
                                                                 const int* __restrict__ xlist, int seg, int seg_shift,
-                                                                PoolBest* __restrict__ pbest, int pool_shares) {
+                                                                PoolBest* __restrict__ pbest, int pool_shares,
+                                                                int half_last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int LT = L / 16;
     constexpr int NT = LT * C;
@@ -1042,8 +1158,24 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     }
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     cf v[16];
+    if (half_last && kp == n_packed - 1) {
+        // HALF_LAST: rows 0..L/2 only (see k_pass_c): sum_k1 Y[k1] W^(k1 m2) over all rows equals
+        // Y[0] + (-1)^m2 Y[L/2] + 2 Re sum_{0<k1<L/2} Y[k1] W^(k1 m2) -- only the real part is used
+        // (the slot's imaginary candidate does not exist), so weighting the stored rows is all it takes
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
+        for (int q = 0; q < 16; ++q) {
+            const int row = u + LT * q;
+            const float wgt = (row == 0 || row == L / 2) ? 1.0f : 2.0f;
+            v[q] = mk(0.f, 0.f);
+            if (row <= L / 2) {
+                const cf y = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)row << log2CL)];
+                v[q] = mk(wgt * y.x, wgt * y.y);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
+    }
     for (int i = tid; i < L; i += NT) s_tw[i] = twn1[i];
     __syncthreads();
     // W_L^(b*(u + LT*q)) = W_L^(b*u) * W_16^(b*q)  (L = 16*LT): the second factor is the same for the

@@ -138,6 +138,8 @@ struct ffs_plan {
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
     bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
+    bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
+    bool mid_seg_three = false;     // FFS_MID_SEG_SLOTS=3: k_mid_seg3 (three slots per sweep) instead of k_mid_seg
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
@@ -261,7 +263,7 @@ struct ProfSpan {
 // ---- kernel dispatch -------------------------------------------------------------------------
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
-                       bool ref_half, hipStream_t st) {
+                       int ref_half, hipStream_t st) {
     const size_t lds = col_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
@@ -272,13 +274,13 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
                        p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, p->pass_a_prefetch,
-                       (unsigned*)p->bnom, ref_half ? 1 : 0);
+                       (unsigned*)p->bnom, ref_half);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 template <int DT>
-int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, bool ref_half,
+int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, int ref_half,
                   hipStream_t st) {
     switch (p->N1) {
         case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
@@ -300,14 +302,14 @@ int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_pe
 }
 
 template <int L, bool SEP>
-int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipStream_t st) {
+int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStream_t st) {
     const size_t lds = row_lds_bytes(L);
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_mid<L, SEP>, lds))) return rc_lds;
     constexpr int ROWS = 256 / (L / 16);
     dim3 grid(p->N1 / ROWS, n_pairs);
     hipLaunchKernelGGL((k_mid<L, SEP>), grid, dim3(256), lds, st, p->work, p->N1, p->log2CL, (long long)p->N, n_slots,
-                       (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM, ref_half ? 1 : 0);
+                       (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM, ref_half);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -315,7 +317,7 @@ int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, 
 // the reference slot may hold only its rows 0..N1/2 (see k_mid) when one block handles one row
 bool ref_half_ok(const ffs_plan* p) { return p->allow_ref_half && p->N2 == 4096 && (p->N2 / 16) >= (1 << p->log2CL) && p->N1 % 2 == 0; }
 
-int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipStream_t st) {
+int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStream_t st) {
     const bool sep = (p->N2 / 16) >= (1 << p->log2CL);
 #define FFS_MID(L) \
     case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, ref_half, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, ref_half, st)
@@ -330,13 +332,22 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, bool ref_half, hipSt
     return fail(FFS_E_INVALID, "unsupported row length %d", p->N2);
 }
 
-int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, bool ref_half, hipStream_t st) {
-    const size_t lds = row_lds_bytes(4096);
+int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, int ref_half, hipStream_t st) {
     int rc_lds;
+    if (sp->mid_seg_three) {  // three slots per sweep, reference row parked in LDS
+        const size_t lds3 = row_lds_bytes(4096) + 4096 * sizeof(cf);
+        if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg3<4096>, lds3))) return rc_lds;
+        hipLaunchKernelGGL((k_mid_seg3<4096>), dim3(sp->N1, n_pairs), dim3(256), lds3, st, sp->work, sp->N1, sp->log2CL,
+                           (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
+                           ref_half);
+        HIP_TRY(hipGetLastError());
+        return FFS_OK;
+    }
+    const size_t lds = row_lds_bytes(4096);
     if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096>, lds))) return rc_lds;
     hipLaunchKernelGGL((k_mid_seg<4096>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1, sp->log2CL,
                        (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                       ref_half ? 1 : 0);
+                       ref_half);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -347,6 +358,7 @@ struct PoolArgs {
     PoolEntry* entries;
     PoolBest* best;
     int shares;  // sub-batches of the call that share the pool (each flagged candidate's quota is divided by it)
+    int half_last = 0;  // HALF_LAST layout of the last candidate slot (see ffs_kernels.h)
 };
 
 int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t st) {
@@ -373,7 +385,7 @@ int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand,
     dim3 grid(p->N2 / C, MODE == 2 ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c<L, C, MODE>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N, p->tw1,
                        cands, first_cand, n_cand, n_packed, n_slots, p->bnom, out_a, out_b, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->twn1, p->xlist, pa.best, pa.shares);
+                       p->twn1, p->xlist, pa.best, pa.shares, pa.half_last);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -418,7 +430,7 @@ int launch_pass_c_pruned_inst(const ffs_plan* p, const CandDesc* cands, int firs
     dim3 grid(p->N2 / C, EXH ? kCollectRows : n_pairs * n_packed);
     hipLaunchKernelGGL((k_pass_c_pruned<L, C, EXH>), grid, dim3((L / 16) * C), lds, st, p->work, p->N2, (long long)p->N,
                        p->twn1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, bins, pa.noms, pa.header, pa.entries, p->log2CL,
-                       p->xlist, seg, seg_shift, pa.best, pa.shares);
+                       p->xlist, seg, seg_shift, pa.best, pa.shares, pa.half_last);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -675,6 +687,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_seg = !(e6 && e6[0] == '1');
         const char* e4 = getenv("FFS_DISABLE_REF_HALF");
         p->allow_ref_half = !(e4 && e4[0] == '1');
+        const char* e8 = getenv("FFS_MID_SEG_SLOTS");
+        p->mid_seg_three = (e8 && e8[0] == '3');
+        const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
+        p->allow_half_last = !(e7 && e7[0] == '1');
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = atoi(e3);
         const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
@@ -806,6 +822,13 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                             (p->N2 / 16) >= (1 << p->log2CL) && p->N1 >= 2;
     const int xf_per_pair = packed_ref ? n_packed : n_slots;
     const bool ref_half = !packed_ref && !p->direct_only && ref_half_ok(p);
+    // odd candidate count: the last packed transform carries one real candidate -> half of its rows suffice
+    // (needs the one-row-per-block mid kernels, like ref_half; the plan that runs the kernels decides)
+    auto half_flags_of = [&](const ffs_plan* q, bool rh) {
+        const bool hl = !packed_ref && (n_cand % 2 == 1) && q->allow_half_last && ref_half_ok(q) && q->N1 >= 4;
+        return (rh ? HALF_REF : 0) | (hl ? HALF_LAST : 0);
+    };
+    const int hflags = p->direct_only ? 0 : half_flags_of(p, ref_half);
     const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
     const size_t n_cands = (size_t)n_pairs * n_cand;
     size_t n_xf = (size_t)n_pairs * xf_per_pair;
@@ -948,8 +971,9 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     NomList* dn = (NomList*)(db + o_nom);
     RescoreAcc* da = (RescoreAcc*)(db + o_acc);
     PoolBest* dpb = (PoolBest*)(db + o_pbest);
-    const PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries, dpb,
-                      (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight};
+    PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries, dpb,
+                (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight};
+    pa.half_last = (hflags & HALF_LAST) ? 1 : 0;
     CandResult* cres = (CandResult*)cand_out_dev;
     PairResult* pres = (PairResult*)pair_out_dev;
 
@@ -963,23 +987,26 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             // block-segmented pipeline on the length-M sub-plan: 3x shorter transforms, the blocks'
             // spectrum products are added in the mid pass, last pass over one third of the data
             ffs_plan* sp = p->seg;
+            const int sflags = half_flags_of(sp, true);
+            PoolArgs spa = pa;
+            spa.half_last = (sflags & HALF_LAST) ? 1 : 0;
             const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
             const int first_cand = p0 * n_cand;
             const int tiles_s = sp->N2 / sp->C;
             const XformDesc* dxs = dx + (size_t)p0 * seg_blocks * n_slots;
             {
                 ProfSpan span(p, st, FFS_K_PASS_A);
-                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, true, st));
+                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st));
             }
             if (rc) return rc;
             {
                 ProfSpan span(p, st, FFS_K_MID);
-                rc = launch_mid_seg(sp, np, n_slots, seg_blocks, true, st);
+                rc = launch_mid_seg(sp, np, n_slots, seg_blocks, sflags, st);
             }
             if (rc) return rc;
             {
                 ProfSpan span(p, st, FFS_K_PASS_C);
-                rc = launch_pass_c_pruned<false>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, pa, st, 1,
+                rc = launch_pass_c_pruned<false>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, spa, st, 1,
                                                  (int)seg_lo);
             }
             if (rc) return rc;
@@ -990,7 +1017,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                                    first_cand, sp->xlist);
             }
             HIP_TRY(hipGetLastError());
-            if ((rc = launch_pass_c_pruned<true>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, pa, st, 1,
+            if ((rc = launch_pass_c_pruned<true>(sp, dc, first_cand, n_cand, n_packed, seg_blocks * n_slots, np, bins, spa, st, 1,
                                                  (int)seg_lo)))
                 return rc;
             {
@@ -1006,12 +1033,12 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
                 FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
-                                                           n_slots, ref_half, st));
+                                                           n_slots, hflags, st));
             }
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_MID);
-                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, ref_half, st);
+                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, hflags, st);
             }
             if (rc) return rc;
             {
@@ -1072,9 +1099,9 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     HIP_TRY(hipMemcpyAsync(p->dev_desc, hx, 2 * sizeof(XformDesc), hipMemcpyHostToDevice, st));
     HIP_TRY(hipEventRecord(p->upload_done, st));
     const XformDesc* dx = (const XformDesc*)p->dev_desc;
-    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx, 2, 2, 2, ref_half_ok(p), st));
+    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx, 2, 2, 2, ref_half_ok(p) ? HALF_REF : 0, st));
     if (rc) return rc;
-    if ((rc = launch_mid(p, 1, 2, ref_half_ok(p), st))) return rc;
+    if ((rc = launch_mid(p, 1, 2, ref_half_ok(p) ? HALF_REF : 0, st))) return rc;
     const PoolArgs none{nullptr, nullptr, nullptr, nullptr, 1};
     if ((rc = launch_pass_c<1>(p, nullptr, 0, 2, 1, 2, 1, out_a_dev, out_b_dev, none, st))) return rc;
     return leave_stream(p, st);

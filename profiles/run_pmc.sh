@@ -6,7 +6,7 @@ OUT=${1:-$GRAFT_REPO_ROOT/gpurun_out/pmc}
 EXTRA=${2:-}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --pairs 64 --steps 1 --warmup 1 --cpu-pairs 0 --no-profile --e2e-files 0 --skip-full-length-record --pairs-in-flight 32 $EXTRA"
+CMD="python $GRAFT_REPO_ROOT/bench.py --pairs 64 --steps 1 --warmup 1 --cpu-pairs 0 --no-profile --skip-secondary --pairs-in-flight 32 $EXTRA"
 run() { name=$1; shift; timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -o "$name" -- $CMD > "$OUT/$name.log" 2>&1; }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
 run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 kernel trace + stats of the default bench command (run on the GPU box via gpurun).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 EXTRA=${2:-}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o "$TAG" -- \
-    python $GRAFT_REPO_ROOT/bench.py --cpu-pairs 0 --e2e-files 0 --skip-full-length-record --no-vad $EXTRA > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.log"
+    python $GRAFT_REPO_ROOT/bench.py --cpu-pairs 0 --skip-secondary $EXTRA > "$OUT/bench_under_rocprof.json" 2> "$OUT/rocprof.log"
 ls "$OUT"

@@ -9,6 +9,8 @@ import json
 import logging
 import os
 import sys
+
+sys.dont_write_bytecode = True  # importing the reference must not write __pycache__ into /root/reference
 import types
 
 import numpy as np

@@ -9,6 +9,8 @@ few class names they touch are registered first (the rasterisation itself never 
 import logging
 import os
 import sys
+
+sys.dont_write_bytecode = True  # importing the reference must not write __pycache__ into /root/reference
 import types
 from datetime import timedelta
 

@@ -266,3 +266,77 @@ def test_one_rank_rccl_gather_and_sharded_solve(torch):
         al.plan.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_cand", [7, 5, 3, 1])
+def test_half_rows_of_a_single_candidate_slot_equal_all_rows(torch, monkeypatch, n_cand):
+    """HALF_LAST: with an odd candidate count the last packed transform holds one real candidate and only rows
+    0..N1/2 of it are stored / transformed / read (the last pass rebuilds the rest by conjugation).  Records
+    must be identical to FFS_DISABLE_HALF_LAST=1 on every pipeline: block-segmented, single transform with
+    the pruned and with the full last pass, and a windowless solve (full last pass)."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(1200 + i, duration_s=d) for i, d in enumerate((7200.0, 7000.0, 5400.0))]
+    db7 = synth.build_device_batch(specs)
+    cols = list(range(n_cand))
+    pick = lambda a: np.ascontiguousarray(a[:, [0] + [1 + j for j in cols]])
+    db = batch.DeviceBatch(db7.data, pick(db7.offs), pick(db7.lens), pick(db7.lo), pick(db7.hi), db7.dtype)
+
+    def solve(max_offset, env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        al = batch.BatchAligner(db.required_fft_length(max_offset), n_cand, max_offset, pairs_in_flight=2)
+        out = al.solve(db)
+        al.plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    for max_offset, extra in ((6000, {}), (6000, {"FFS_DISABLE_SEGMENTED": "1"}),
+                              (6000, {"FFS_DISABLE_SEGMENTED": "1", "FFS_DISABLE_PRUNED_PASS_C": "1"}), (None, {})):
+        half = solve(max_offset, dict(extra))
+        full = solve(max_offset, dict(extra, FFS_DISABLE_HALF_LAST="1"))
+        for f in ("score", "offset", "flags"):
+            assert np.array_equal(half[0][f], full[0][f]), (n_cand, max_offset, extra, f)
+        assert np.array_equal(half[1], full[1])
+        assert np.abs(half[0]["score_f32"].astype(np.float64) - half[0]["score"]).max() < 0.5
+        if n_cand == 7:
+            for p, sp in enumerate(specs):
+                assert int(half[1][p]["best_cand"]) == sp.true_ratio_index
+
+
+@pytest.mark.parametrize("n_cand", [7, 8, 4, 2])
+def test_three_slots_per_sweep_mid_pass_gives_identical_records(torch, monkeypatch, n_cand):
+    """k_mid_seg3 (FFS_MID_SEG_SLOTS=3: three accumulator rows, reference row parked in LDS) against the
+    default two-slot k_mid_seg, with and without the half last slot."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    ratios = None
+    if n_cand == 8:  # the inferred-length eighth candidate of subtitle references (ffsubsync.py:205-222)
+        from ffsubsync_amd.constants import candidate_ratios
+
+        ratios = candidate_ratios() + [1.0213]
+    specs = [synth.make_pair_spec(1300 + i, duration_s=d, ratios=ratios) for i, d in enumerate((7200.0, 6800.0, 4000.0))]
+    db8 = synth.build_device_batch(specs)
+    pick = lambda a: np.ascontiguousarray(a[:, : 1 + n_cand])
+    db = batch.DeviceBatch(db8.data, pick(db8.offs), pick(db8.lens), pick(db8.lo), pick(db8.hi), db8.dtype)
+
+    def solve(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        al = batch.BatchAligner(db.required_fft_length(6000), n_cand, 6000, pairs_in_flight=2)
+        out = al.solve(db)
+        al.plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    base = solve({})
+    for env in ({"FFS_MID_SEG_SLOTS": "3"}, {"FFS_MID_SEG_SLOTS": "3", "FFS_DISABLE_HALF_LAST": "1"}):
+        got = solve(env)
+        for f in ("score", "offset", "flags"):
+            assert np.array_equal(base[0][f], got[0][f]), (env, f)
+        assert np.array_equal(base[1], got[1])
+        assert np.abs(got[0]["score_f32"].astype(np.float64) - got[0]["score"]).max() < 0.5
