@@ -198,7 +198,7 @@ def e2e_figures(torch, _native, n_files, minutes=90.0, cpu_files=1):
         for i in range(min(cpu_files, n_files)):
             host, (s_us, e_us, meta) = files[i]
             lab = vo.chunked_detect(host.numpy())
-            cands = [ro.rasterize(s_us, e_us, meta, r, 100, 0) * min(1.0 / r, 1.0) for r in ratios]
+            cands = [ro.rasterize(s_us, e_us, meta, r, 100, 0) for r in ratios]  # amplitude min(1/r, 1) included
             (sc, off), idx = orc.max_score_align(lab, cands, 6000)
             agree &= (idx == int(pres[i]["best_cand"]) and off == int(pres[i]["offset"])
                       and abs(sc - pres[i]["score"]) <= 1e-5 * abs(sc))
@@ -329,7 +329,10 @@ def main():
     # slot U = 8*n bytes (n = device transform length): a pair is 1 reference + ceil(cands/2) packed candidate
     # transforms; the reference's spectrum is real-input Hermitian, so only half of its rows are stored.
     def must_move(n_fft, seg, cands):
-        slots = (cands + 1) // 2
+        # an odd candidate count leaves one real candidate in the last packed transform: only half of its rows
+        # are stored, transformed and read (HALF_LAST, ffs_kernels.h)
+        half_last = cands % 2 == 1 and os.environ.get("FFS_DISABLE_HALF_LAST") != "1"
+        slots = (cands + 1) // 2 - (0.5 if half_last else 0.0)
         unit = 8.0 * n_fft
         in_bytes = float(np.mean(db.lens.sum(axis=1))) / (8.0 if db.dtype == _native.FFS_DTYPE_U1 else 1.0)
         if cands != n_cand:

@@ -491,9 +491,9 @@ def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
     one = [(_Vec(c["ref"]), [_Vec(c["cands"][0])])]
 
     def run():
-        _native._plans.clear()  # the layout switch is read when a plan is created
+        _native.clear_plan_cache()  # the layout switch is read when a plan is created
         out = (batch.BatchAligner(n, 7, 6000, pairs_in_flight=2).solve(db), solve_pairs(one, None), solve_pairs(one, 6000))
-        _native._plans.clear()
+        _native.clear_plan_cache()
         return out
 
     separate = run()

@@ -252,3 +252,42 @@ def test_select_candidates_view():
     assert one.n_pairs == 3 and one.n_cand == 1
     assert one.offs.tolist() == [[0, 192], [256, 320], [512, 640]]
     assert one.hi[:, 1].tolist() == [0.3, 0.5, 1.0] and one.lens[:, 0].tolist() == [5, 261, 517]
+
+
+def test_bench_starts_itself_under_the_launcher(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must re-run itself under torch.distributed.run with one
+    process per GPU on 127.0.0.1 (a driver can produce the scaling record with a plain command)."""
+    import importlib
+    import sys
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--scaling", "strong"])
+    monkeypatch.delenv("RANK", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--scaling", "strong"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+
+
+def test_strong_and_weak_scaling_shards():
+    """bench.py --scaling strong splits the same pairs over the ranks (BASELINE configs[3]); the shards tile
+    the batch exactly, in order, for every world size."""
+    for n in (1024, 8192, 1000, 7):
+        for world in (1, 2, 4, 8):
+            bounds = [shard_bounds(n, r, world) for r in range(world)]
+            assert bounds[0][0] == 0 and bounds[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
+            per = (n + world - 1) // world
+            assert all(hi - lo <= per for lo, hi in bounds)
