@@ -31,6 +31,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
+constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (FFS_PASS_A_STORE8=1, experiment)
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
     const void* a;
@@ -163,33 +164,40 @@ FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1, int
 // is sample n_base + LT*N2*q.  The zero-padding test is skipped for the leading QF values of q when the
 // whole block (columns < col_end, all LT row phases) is inside the vector there -- a block-uniform
 // condition, so the three variants are selected by scalar branches.
-template <int LT, int QF>
+// MASK: b[q] is an all-ones / all-zeros word (from a signed bit-field extract) and the value is picked with
+// one v_bfi_b32; otherwise b[q] is any byte value and the pick is a compare + select.
+template <bool MASK>
+FFS_DEV float pick_level(unsigned b, float v0, float v1) {
+    if (MASK) return __uint_as_float((b & __float_as_uint(v1)) | (~b & __float_as_uint(v0)));
+    return b ? v1 : v0;
+}
+template <int LT, int QF, bool MASK>
 FFS_DEV void map_bytes_from(const unsigned (&b)[16], float v0, float v1, int len, int n_base, int N2, float (&out)[16]) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const float x = b[q] ? v1 : v0;
+        const float x = pick_level<MASK>(b[q], v0, v1);
         out[q] = (q < QF || n_base + LT * N2 * q < len) ? x : 0.0f;
     }
 }
-template <int LT>
+template <int LT, bool MASK = false>
 FFS_DEV void map_bytes(const unsigned (&b)[16], float v0, float v1, int len, int n_base, int N2, int col_end,
                        int lead, float (&out)[16]) {
     if (lead > 0) {  // rare (one reference block per pair in block-segmented mode): test both ends
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int n = n_base + LT * N2 * q;
-            out[q] = (n >= lead && n < len) ? (b[q] ? v1 : v0) : 0.0f;
+            out[q] = (n >= lead && n < len) ? pick_level<MASK>(b[q], v0, v1) : 0.0f;
         }
         return;
     }
     const int rows_full = (len >= col_end) ? (len - col_end) / N2 + 1 : 0;  // rows r with r*N2 + col_end - 1 < len
     const int q_full = rows_full / LT;                                      // q with every row u + LT*q inside
     if (q_full >= 12)
-        map_bytes_from<LT, 12>(b, v0, v1, len, n_base, N2, out);
+        map_bytes_from<LT, 12, MASK>(b, v0, v1, len, n_base, N2, out);
     else if (q_full >= 6)
-        map_bytes_from<LT, 6>(b, v0, v1, len, n_base, N2, out);
+        map_bytes_from<LT, 6, MASK>(b, v0, v1, len, n_base, N2, out);
     else
-        map_bytes_from<LT, 0>(b, v0, v1, len, n_base, N2, out);
+        map_bytes_from<LT, 0, MASK>(b, v0, v1, len, n_base, N2, out);
 }
 
 // value of `x` in the neighbour lane (lane ^ 1): one DPP move, quad_perm [1,0,3,2]
@@ -349,12 +357,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         unsigned ba[16], bb[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            ba[q] = __builtin_amdgcn_ubfe(wa[LT * q * CW], sh, 1u);
-            bb[q] = __builtin_amdgcn_ubfe(wb[LT * q * CW], sh, 1u);
+            ba[q] = (unsigned)__builtin_amdgcn_sbfe((int)wa[LT * q * CW], sh, 1u);  // 0 or ~0
+            bb[q] = (unsigned)__builtin_amdgcn_sbfe((int)wb[LT * q * CW], sh, 1u);
         }
         float xa[16], xb[16];
-        map_bytes<LT>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
-        map_bytes<LT>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
+        map_bytes<LT, true>(ba, d.a0, d.a1, d.len_a, u * N2 + n2, N2, tile * C + C, d.lead_a, xa);
+        map_bytes<LT, true>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
     } else {
@@ -438,7 +446,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             v[q + 8] = cmul(v[q + 8], cmul(h[q], wq[8]));
         }
     }
-    if constexpr (C >= 2) {
+    if (C >= 64 && (half_flags & STORE_8B)) {
+        // 64-column tiles: an 8-byte store per lane already writes one whole 512-byte row chunk per wave
+        // instruction, so the lane-pair exchange below (64 VALU instructions) buys nothing here
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            if (ob + CS::OSTEP * q < k1_end) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];
+    } else if constexpr (C >= 2) {
         // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
         // the even-c lane writes rows q = 0,2,.. of columns (c, c+1), the odd-c lane rows q = 1,3,..
         // (a wave store then covers 8 full 128-byte rows).
@@ -834,6 +848,9 @@ struct WinParams {
     int lo[2], hi[2];
     float marg[2];
     int seg, shift;  // block-segmented mode: output index m is lag m + shift (no wrap-around)
+    // the window in output-index space: m passes iff (unsigned)(m - ra[h][i]) <= rw[h][i] for i = 0 or 1
+    int ra[2][2];
+    unsigned rw[2][2];
 };
 
 // lag of output index m: circular (lags 0..d_hi at m = d, negative ones at m = d + N) or, in
@@ -843,11 +860,17 @@ FFS_DEV int lag_of(const WinParams& wp, int h, int m, int nN) {
     return (m <= wp.hi[h]) ? m : m - nN;
 }
 
-FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand, int seg_shift = 0,
+// Is output index m (>= 0; -1 = "no value") inside half h's lag window?  Two unsigned range tests.
+FFS_DEV bool in_window(const WinParams& wp, int h, int m) {
+    return (unsigned)(m - wp.ra[h][0]) <= wp.rw[h][0] || (unsigned)(m - wp.ra[h][1]) <= wp.rw[h][1];
+}
+
+FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand, int nN, int seg_shift = 0,
                               int seg = 0) {
     WinParams w;
     w.seg = seg;
     w.shift = seg_shift;
+    constexpr int NEVER = 0x40000000;  // start of an empty range (width 0): no index ever equals it
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const bool present = (2 * kp + h) < n_cand;
@@ -855,47 +878,58 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
         w.lo[h] = cd.d_lo;
         w.hi[h] = (present && !(cd.flags & CAND_NO_LAGS)) ? cd.d_hi : cd.d_lo - 1;  // absent/empty: nothing passes
         w.marg[h] = cd.margin;
+        const int lo = w.lo[h], hi = w.hi[h];
+        w.ra[h][0] = w.ra[h][1] = NEVER;
+        w.rw[h][0] = w.rw[h][1] = 0u;
+        if (hi >= lo) {
+            if (seg) {  // m = d - shift
+                w.ra[h][0] = lo - seg_shift;
+                w.rw[h][0] = (unsigned)(hi - lo);
+            } else {
+                if (hi >= 0) {  // lags 0..hi sit at m = d
+                    const int a = lo > 0 ? lo : 0;
+                    w.ra[h][0] = a;
+                    w.rw[h][0] = (unsigned)(hi - a);
+                }
+                if (lo < 0) {  // negative lags at m = d + N
+                    const int b = hi < -1 ? hi : -1;
+                    w.ra[h][1] = nN + lo;
+                    w.rw[h][1] = (unsigned)(b - lo);
+                }
+            }
+        }
     }
     return w;
 }
 
-// Per-block argmax + near-tie nominees of the NV values each thread holds: v[q].x belongs to the
-// real-part candidate, v[q].y to the imaginary-part one, at circular lag m_of(q) (< 0: no value).
-// Ordering: larger value wins, ties go to the larger offset d (= np.argmax's first index in k).
+// Per-block maximum + near-tie nominees of the NV values each thread holds: v[q].x belongs to the
+// real-part candidate, v[q].y to the imaginary-part one, at output index m_of(q) (< 0: no value).
+// The window test of every value is done once (a bit per value); lags are only worked out for the few
+// values that reach the tie margin.
 template <int NV, int NW, class MOf>
 FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, unsigned char* smem, int tid,
                             BlockNom* __restrict__ out_a, BlockNom* __restrict__ out_b) {
+    static_assert(2 * NV <= 32, "one validity bit per value and half");
     float bv[2] = {-INFINITY, -INFINITY};
-    int bd[2] = {INT32_MIN, INT32_MIN};
+    unsigned okmask = 0;
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const int m = m_of(q);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int d = lag_of(wp, h, m, nN);
-            const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
+            const bool ok = in_window(wp, h, m);
+            okmask |= (ok ? 1u : 0u) << (2 * q + h);
             const float val = h ? v[q].y : v[q].x;
-            if (ok && better(val, d, bv[h], bd[h])) {
-                bv[h] = val;
-                bd[h] = d;
-            }
+            bv[h] = fmaxf(bv[h], ok ? val : -INFINITY);
         }
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            const float ov = __shfl_xor(bv[h], sft, 64);
-            const int od = __shfl_xor(bd[h], sft, 64);
-            if (better(ov, od, bv[h], bd[h])) {
-                bv[h] = ov;
-                bd[h] = od;
-            }
-        }
+        for (int sft = 32; sft >= 1; sft >>= 1) bv[h] = fmaxf(bv[h], __shfl_xor(bv[h], sft, 64));
     }
     __syncthreads();  // callers are done with their LDS data; reuse it as scratch
     float* s_val = reinterpret_cast<float*>(smem);         // [NW][2]
-    int* s_d = reinterpret_cast<int*>(smem + 256);         // [NW][2]
     float* s_bmax = reinterpret_cast<float*>(smem + 512);  // [2]
     int* s_cnt = reinterpret_cast<int*>(smem + 528);       // [2]
     float* s_lval = reinterpret_cast<float*>(smem + 544);  // [2][KBLK]
@@ -904,18 +938,11 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
     if (lane == 0) {
         s_val[wave * 2 + 0] = bv[0];
         s_val[wave * 2 + 1] = bv[1];
-        s_d[wave * 2 + 0] = bd[0];
-        s_d[wave * 2 + 1] = bd[1];
     }
     __syncthreads();
     if (tid < 2) {
         float fv = -INFINITY;
-        int fd = INT32_MIN;
-        for (int w = 0; w < NW; ++w)
-            if (better(s_val[w * 2 + tid], s_d[w * 2 + tid], fv, fd)) {
-                fv = s_val[w * 2 + tid];
-                fd = s_d[w * 2 + tid];
-            }
+        for (int w = 0; w < NW; ++w) fv = fmaxf(fv, s_val[w * 2 + tid]);
         s_bmax[tid] = fv;
         s_cnt[tid] = 0;
     }
@@ -925,15 +952,12 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
         const float thr = s_bmax[h] - eff_margin(wp.marg[h], s_bmax[h]);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
-            const int m = m_of(q);
-            const int d = lag_of(wp, h, m, nN);
-            const bool ok = (m >= 0) && (d >= wp.lo[h]) && (d <= wp.hi[h]);
             const float val = h ? v[q].y : v[q].x;
-            if (ok && val >= thr) {
+            if (((okmask >> (2 * q + h)) & 1u) && val >= thr) {
                 const int slot = atomicAdd(&s_cnt[h], 1);
                 if (slot < KBLK) {
                     s_lval[h * KBLK + slot] = val;
-                    s_ld[h * KBLK + slot] = d;
+                    s_ld[h * KBLK + slot] = lag_of(wp, h, m_of(q), nN);
                 }
             }
         }
@@ -1084,7 +1108,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
         }
         return;
     }
-    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand);
+    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, (int)N);
     if (MODE == 2) {
         block_collect_all<16>(
             v, [&](int q) { return m1 + N2 * (ob + CS::OSTEP * q); }, wp, (int)N, xci, xwant, xthr, pool, entries, pbest,
@@ -1212,7 +1236,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
             mm[j] = tile * C + cc + N2 * m2;
         }
     }
-    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, seg_shift, seg);
+    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, (int)N, seg_shift, seg);
     if (EXH) {
         block_collect_all<NVF>(
             val, [&](int j) { return mm[j]; }, wp, (int)N, xci, xwant, xthr, pool, entries, pbest,

@@ -140,6 +140,7 @@ struct ffs_plan {
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     bool mid_seg_three = false;     // FFS_MID_SEG_SLOTS=3: k_mid_seg3 (three slots per sweep) instead of k_mid_seg
+    bool pass_a_store8 = false;     // FFS_PASS_A_STORE8=1: 8-byte stores in pass A for 64-column tiles
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
@@ -274,7 +275,7 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
                        p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, p->pass_a_prefetch,
-                       (unsigned*)p->bnom, ref_half);
+                       (unsigned*)p->bnom, ref_half | (p->pass_a_store8 ? STORE_8B : 0));
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -687,6 +688,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_seg = !(e6 && e6[0] == '1');
         const char* e4 = getenv("FFS_DISABLE_REF_HALF");
         p->allow_ref_half = !(e4 && e4[0] == '1');
+        const char* e9 = getenv("FFS_PASS_A_STORE8");
+        p->pass_a_store8 = (e9 && e9[0] == '1');
         const char* e8 = getenv("FFS_MID_SEG_SLOTS");
         p->mid_seg_three = (e8 && e8[0] == '3');
         const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
