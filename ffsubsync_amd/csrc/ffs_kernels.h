@@ -31,7 +31,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
-constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (FFS_PASS_A_STORE8=1, experiment)
+constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (default; FFS_PASS_A_STORE8=0 turns it off)
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
     const void* a;
@@ -448,7 +448,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     }
     if (C >= 64 && (half_flags & STORE_8B)) {
         // 64-column tiles: an 8-byte store per lane already writes one whole 512-byte row chunk per wave
-        // instruction, so the lane-pair exchange below (64 VALU instructions) buys nothing here
+        // instruction, so the lane-pair exchange below (64 VALU instructions of ~330 per wave; the kernel is
+        // ~45 % VALU-busy) buys nothing here: measured 6.54 -> 6.28 us/pair
 #pragma unroll
         for (int q = 0; q < 16; ++q)
             if (ob + CS::OSTEP * q < k1_end) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];

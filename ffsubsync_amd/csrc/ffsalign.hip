@@ -140,7 +140,7 @@ struct ffs_plan {
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     bool mid_seg_three = false;     // FFS_MID_SEG_SLOTS=3: k_mid_seg3 (three slots per sweep) instead of k_mid_seg
-    bool pass_a_store8 = false;     // FFS_PASS_A_STORE8=1: 8-byte stores in pass A for 64-column tiles
+    bool pass_a_store8 = true;      // FFS_PASS_A_STORE8=0: 16-byte paired stores in pass A for 64-column tiles too
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
@@ -689,7 +689,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         const char* e4 = getenv("FFS_DISABLE_REF_HALF");
         p->allow_ref_half = !(e4 && e4[0] == '1');
         const char* e9 = getenv("FFS_PASS_A_STORE8");
-        p->pass_a_store8 = (e9 && e9[0] == '1');
+        p->pass_a_store8 = !(e9 && e9[0] == '0');
         const char* e8 = getenv("FFS_MID_SEG_SLOTS");
         p->mid_seg_three = (e8 && e8[0] == '3');
         const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
