@@ -72,7 +72,8 @@ class NativeError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
+    """In-tree libffsalign.so; FFS_LIBRARY_PATH selects another build of it (A/B runs of compile-time variants)."""
+    return os.environ.get("FFS_LIBRARY_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), _LIB_NAME)
 
 
 def load():

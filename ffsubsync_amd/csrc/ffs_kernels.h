@@ -450,9 +450,21 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         // 64-column tiles: an 8-byte store per lane already writes one whole 512-byte row chunk per wave
         // instruction, so the lane-pair exchange below (64 VALU instructions of ~330 per wave; the kernel is
         // ~45 % VALU-busy) buys nothing here: measured 6.54 -> 6.28 us/pair
+        // a slot is at most 2^24 elements: 32-bit element offsets from the (block-uniform) slot pointer,
+        // one add per store; the row guard only exists for the two half slots (block-uniform choice)
+        // (byte offsets in 32-bit arithmetic -- 2^27 at most -- so that the stores can use the scalar base +
+        // 32-bit lane offset addressing mode instead of 64-bit address pairs)
+        const unsigned o0 = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)ob << log2CL)) * (unsigned)sizeof(cf);
+        const unsigned ostep = ((unsigned)CS::OSTEP << log2CL) * (unsigned)sizeof(cf);
+        char* outb = reinterpret_cast<char*>(out);
+        if (k1_end == L) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q)
-            if (ob + CS::OSTEP * q < k1_end) out[tile_base<L, C>(tile, c, log2CL) + ((size_t)(ob + CS::OSTEP * q) << log2CL)] = v[q];
+            for (int q = 0; q < 16; ++q) *reinterpret_cast<cf*>(outb + (o0 + ostep * q)) = v[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                if (ob + CS::OSTEP * q < k1_end) *reinterpret_cast<cf*>(outb + (o0 + ostep * q)) = v[q];
+        }
     } else if constexpr (C >= 2) {
         // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
         // the even-c lane writes rows q = 0,2,.. of columns (c, c+1), the odd-c lane rows q = 1,3,..
