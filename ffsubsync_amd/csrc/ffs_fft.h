@@ -368,28 +368,64 @@ FFS_DEV void stage_gather(cf (&v)[16], const cf* lds, int, const Addr& addr) {
     stage_gather_impl(v, lds, addr, std::make_integer_sequence<int, 16>{});
 }
 
+// Workgroup barrier that only waits for this wave's LDS traffic.  __syncthreads() also drains the wave's
+// outstanding GLOBAL loads (s_waitcnt vmcnt(0) in front of s_barrier), which defeats software prefetching:
+// loads issued for the next row would be waited for at the first exchange of the current transform.  The
+// exchanges of a transform only communicate through LDS, so lgkmcnt(0) is all they need.
+FFS_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool LB>
+FFS_DEV void block_sync() {
+    if constexpr (LB)
+        lds_barrier();
+    else
+        __syncthreads();
+}
+
 // Forward DFT of length L over the LT threads that share `addr`'s LDS region.
 // In: v[q] = x[u + LT*q].  Out: v[q] = X[u + LT*q].  All threads of the block must call it
 // (it contains __syncthreads()).  tw = this thread's preloaded stage twiddles.
-template <int L, class Addr>
+// LB: barriers wait for LDS traffic only (lds_barrier), so global loads issued before the call stay in flight.
+template <int L, class Addr, bool LB = false>
 FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& tw) {
     typedef Shape<L> S;
+    auto barrier = [] { block_sync<LB>(); };
     addr.refresh();
     stage_first(v);
     if constexpr (S::R1 > 1) {
-        __syncthreads();  // previous readers of this LDS region are done
+        barrier();  // previous readers of this LDS region are done
         stage_scatter<L, 16, 1>(v, lds, u, addr);
-        __syncthreads();
+        barrier();
         stage_gather<L>(v, lds, u, addr);
         stage_compute<L, S::R1, 16>(v, tw.s1);
         if constexpr (S::R2 > 1) {
-            __syncthreads();
+            barrier();
             stage_scatter<L, S::R1, 16>(v, lds, u, addr);
-            __syncthreads();
+            barrier();
             stage_gather<L>(v, lds, u, addr);
             stage_compute<L, S::R2, 256>(v, tw.s2);
         }
     }
+}
+
+// Same transform with the two LDS exchanges in two different regions (L = 4096 only).  Alternating regions
+// removes the "previous readers are done" barrier in front of each scatter: a region is rewritten only after
+// the barrier of the exchange that used the OTHER region, which every thread reaches after its own reads of
+// the first one.  Two barriers per transform instead of four.  Entry condition: no thread still reads lds0
+// (true after any previous call of this function, or after a barrier).
+template <int L, class Addr>
+FFS_DEV void fft_regs_db(cf (&v)[16], cf* lds0, cf* lds1, int u, Addr& addr, const TwRegs<L>& tw) {
+    typedef Shape<L> S;
+    static_assert(S::R1 > 1 && S::R2 > 1, "three-stage transforms only");
+    addr.refresh();
+    stage_first(v);
+    stage_scatter<L, 16, 1>(v, lds0, u, addr);
+    __syncthreads();
+    stage_gather<L>(v, lds0, u, addr);
+    stage_compute<L, S::R1, 16>(v, tw.s1);
+    stage_scatter<L, S::R1, 16>(v, lds1, u, addr);
+    __syncthreads();
+    stage_gather<L>(v, lds1, u, addr);
+    stage_compute<L, S::R2, 256>(v, tw.s2);
 }
 
 // ---- column transforms of length 3 * 2^k ----------------------------------------------------
@@ -415,21 +451,21 @@ struct ColShape {
 
 // First half of a length-3*LI column transform: the three sub-transforms, twiddled, left in LDS as
 // F'[g][k'][c] = W_L^(g k') F_g[k'] at lds[(g*LI + k')*C + c] (followed by a barrier).
-template <int L, int C>
+template <int L, int C, bool LB = false>
 FFS_DEV void col_fft3_front(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
                             const cf* __restrict__ tw3) {
     constexpr int LI = ColShape<L>::LI, LTI = ColShape<L>::LTI;
     const int u = u12 / 3, g = u12 % 3;
     ColAddr<LI, C> addr(u, c);
-    fft_regs<LI>(v, lds + g * (LI * C), u, addr, twr);
+    fft_regs<LI, ColAddr<LI, C>, LB>(v, lds + g * (LI * C), u, addr, twr);
     // W_L^(g k') from the block's LDS copy of the table (a global load issued up front would pin
     // sixteen register pairs across the whole sub-transform)
 #pragma unroll
     for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], tw3[g * (u + LTI * q)]);
-    __syncthreads();
+    block_sync<LB>();
 #pragma unroll
     for (int q = 0; q < 16; ++q) lds[(g * LI + u + LTI * q) * C + c] = v[q];
-    __syncthreads();
+    block_sync<LB>();
 }
 
 // X_r = a + W_3^r b + W_3^(2r) cc  with W_3 = -1/2 - i*sqrt(3)/2:  a + alpha*(b + cc) + beta*(-i)*(b - cc),
@@ -442,17 +478,17 @@ FFS_DEV cf radix3_out(cf a, cf b, cf cc, float alpha, float beta) {
 // Forward DFT of one column of a C-column tile.  In: v[q] = x[u12 + LT*q].  Out: v[q] =
 // X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L) in LDS, outside the L*C elements at `lds`; used only
 // for L = 3*LI.
-template <int L, int C>
+template <int L, int C, bool LB = false>
 FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
                      const cf* __restrict__ tw3) {
     typedef ColShape<L> CS;
     if constexpr (!CS::R3) {
         ColAddr<L, C> addr(u12, c);
-        fft_regs<L>(v, lds, u12, addr, twr);
+        fft_regs<L, ColAddr<L, C>, LB>(v, lds, u12, addr, twr);
     } else {
         constexpr int LI = CS::LI, LTI = CS::LTI;
         const int u = u12 / 3, g = u12 % 3;
-        col_fft3_front<L, C>(v, lds, u12, c, twr, tw3);
+        col_fft3_front<L, C, LB>(v, lds, u12, c, twr, tw3);
         const float alpha = (g == 0) ? 1.0f : -0.5f;
         const float beta = (g == 0) ? 0.0f : (g == 1 ? FFS_SQRT3_HALF : -FFS_SQRT3_HALF);
 #pragma unroll

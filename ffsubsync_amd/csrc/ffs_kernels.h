@@ -31,6 +31,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
+constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD (default; FFS_MID_SEG_PAIRMAP=0 turns it off)
 constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (default; FFS_PASS_A_STORE8=0 turns it off)
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
@@ -494,6 +495,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     }
 }
 
+template <int L>
+FFS_DEV int u_of(const RowAddr<L>& a) { return 16 * a.u_hi + a.u_lo; }
 template <int L, int... Q>
 FFS_DEV void mirror_store(const cf (&v)[16], cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
     ((lds[addr.template gather<Q>()] = v[Q]), ...);
@@ -596,7 +599,8 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 // what the unsegmented pipeline moves.  The reference rows are transformed again for every slot
 // (keeping n_blocks spectra would not fit in registers); the row-transform count per pair is the same
 // as in k_mid at three times the transform length.
-template <int L>
+// DB: the two LDS exchanges of every row transform use two separate buffers (fft_regs_db: half the barriers).
+template <int L, bool DB>
 __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                     int n_blocks, float inv_n, const cf* __restrict__ tw,
                                                     const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
@@ -604,9 +608,24 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
     const int ref_half = half_flags & HALF_REF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
+    cf* lds1 = lds + RowAddr<L>::ROW_ELEMS;  // second exchange buffer (DB only)
     constexpr int LT = L / 16;
+    auto fft = [&](cf(&x)[16], RowAddr<L>& a, const TwRegs<L>& t) {
+        if constexpr (DB)
+            fft_regs_db<L>(x, lds, lds1, u_of(a), a, t);
+        else
+            fft_regs<L>(x, lds, u_of(a), a, t);
+    };
     const int u = threadIdx.x;
-    const int k1 = blockIdx.x;
+    // PAIR_ROWS: rows k1 and N1-k1 read the same stored reference rows (one of them mirrored).  Workgroup b
+    // runs on XCD b % 8, so give the two rows of a pair block indices 8 apart: same XCD (same L2), dispatched
+    // back to back -- the second read of every reference row can then be an L2 hit instead of HBM traffic.
+    // Pair j = (j, N1-j) for 0 < j < N1/2, pair 0 = the two self-mirrored rows (0, N1/2).
+    int k1 = blockIdx.x;
+    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {
+        const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
+        k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
+    }
     RowAddr<L> addr(0, u);
     const int C = 1 << log2C;
     cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
@@ -637,34 +656,141 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
             for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)s * N + q * qstride)[off0];
-            fft_regs<L>(rr, lds, u, addr, twr);
+            fft(rr, addr, twr);
             if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+                cf* mbuf = DB ? lds1 : lds;  // DB: the buffer the transform's last gather used (see fft_regs_db)
                 __syncthreads();
-                mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+                mirror_store(rr, mbuf, addr, std::make_integer_sequence<int, 16>{});
                 __syncthreads();
-                mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
+                mirror_load(rr, mbuf, addr, std::make_integer_sequence<int, 16>{});
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R_k)/N
-            fft_regs<L>(v, lds, u, addr, twr);
+            fft(v, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc_a[q] = cmac(acc_a[q], v[q], rr[q]);
             if (two) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)(s + 1) * N + q * qstride)[off0];
-                fft_regs<L>(v, lds, u, addr, twr);
+                fft(v, addr, twr);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc_b[q] = cmac(acc_b[q], v[q], rr[q]);
             }
         }
-        fft_regs<L>(acc_a, lds, u, addr, twr);
+        fft(acc_a, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
             (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
         }
         if (two) {
-            fft_regs<L>(acc_b, lds, u, addr, twr);
+            fft(acc_b, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
+                (base + (size_t)(s + 1) * N + q * qstride)[off0] = cmul(acc_b[q], w);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Block-segmented mid pass, software-pipelined: same arithmetic as k_mid_seg (two candidate slots per sweep),
+// but the sixteen loads of the NEXT row (reference row of the next block, or the next slot's row) are issued
+// before the transform of the current one, so the HBM latency of every row hides behind a row transform
+// instead of stalling the block (two blocks per CU = two waves per SIMD leave little else to switch to).
+// Rows alternate between two register buffers; the item order of a sweep is R_0 A_0 B_0 R_1 A_1 B_1 ...
+template <int L>
+__global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                                         int n_blocks, float inv_n, const cf* __restrict__ tw,
+                                                         const cf* __restrict__ tb, const cf* __restrict__ ts,
+                                                         int half_flags) {
+    static_assert(L == 4096, "one row per 256-thread block");
+    const int ref_half = half_flags & HALF_REF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]: conj(R_k)/N of the current block, thread-private columns
+    const int u = threadIdx.x;
+    int k1 = blockIdx.x;
+    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see k_mid_seg
+        const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
+        k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
+    }
+    RowAddr<L> addr(0, u);
+    const int C = 1 << log2C;
+    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
+    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
+    if (s_end <= 1) return;
+    const bool mirrored = ref_half && k1 > N1 / 2;
+    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
+    const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
+    const size_t qstride = (size_t)LT * N1;
+    const float sgn = mirrored ? inv_n : -inv_n;
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    for (int s = 1; s < s_end; s += 2) {
+        const bool two = s + 1 < s_end;
+        cf acc_a[16], acc_b[16], x0[16], x1[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc_a[q] = acc_b[q] = mk(0.f, 0.f);
+        auto issue = [&](cf(&x)[16], int k, int slot) {  // slot 0 = the reference row
+            const cf* src = base + ((size_t)k * n_slots + slot) * N;
+            const unsigned off = slot ? off0 : offr;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = (src + q * qstride)[off];
+            __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
+        };
+        auto consume_ref = [&](cf(&x)[16]) {
+            fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+            if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+                lds_barrier();
+                mirror_store(x, lds, addr, std::make_integer_sequence<int, 16>{});
+                lds_barrier();
+                mirror_load(x, lds, addr, std::make_integer_sequence<int, 16>{});
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = mk(x[q].x * inv_n, x[q].y * sgn);  // conj(R_k)/N
+        };
+        auto consume_acc = [&](cf(&x)[16], cf(&acc)[16]) {
+            fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], x[q], s_rr[q * LT + u]);
+        };
+        // one block: on entry `a` holds R_k (loads in flight).  two slots: R_k in a, A_k in b, B_k in a, and
+        // R_(k+1) goes to b -- the buffers swap roles for the next block; one slot: R_(k+1) returns to a.
+        auto block2 = [&](cf(&a)[16], cf(&b)[16], int k) {
+            issue(b, k, s);
+            consume_ref(a);
+            issue(a, k, s + 1);
+            consume_acc(b, acc_a);
+            if (k + 1 < n_blocks) issue(b, k + 1, 0);
+            consume_acc(a, acc_b);
+        };
+        auto block1 = [&](cf(&a)[16], cf(&b)[16], int k) {
+            issue(b, k, s);
+            consume_ref(a);
+            if (k + 1 < n_blocks) issue(a, k + 1, 0);
+            consume_acc(b, acc_a);
+        };
+        issue(x0, 0, 0);
+        if (two) {
+            for (int k = 0; k < n_blocks; k += 2) {
+                block2(x0, x1, k);
+                if (k + 1 < n_blocks) block2(x1, x0, k + 1);
+            }
+        } else {
+            for (int k = 0; k < n_blocks; ++k) block1(x0, x1, k);
+        }
+        fft_regs<L, RowAddr<L>, true>(acc_a, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+            (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
+        }
+        if (two) {
+            fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);

@@ -308,8 +308,9 @@ def test_half_rows_of_a_single_candidate_slot_equal_all_rows(torch, monkeypatch,
 
 @pytest.mark.parametrize("n_cand", [7, 8, 4, 2])
 def test_three_slots_per_sweep_mid_pass_gives_identical_records(torch, monkeypatch, n_cand):
-    """k_mid_seg3 (FFS_MID_SEG_SLOTS=3: three accumulator rows, reference row parked in LDS) against the
-    default two-slot k_mid_seg, with and without the half last slot."""
+    """The variants of the block-segmented mid pass -- k_mid_seg3 (FFS_MID_SEG_SLOTS=3: three accumulator
+    rows, reference row parked in LDS), k_mid_seg_pipe (FFS_MID_SEG_PIPE: row loads issued one item ahead) and
+    the plain two-slot k_mid_seg -- give identical records, with and without the half last slot."""
     from ffsubsync_amd import batch
     from workloads import synth
 
@@ -333,8 +334,11 @@ def test_three_slots_per_sweep_mid_pass_gives_identical_records(torch, monkeypat
             monkeypatch.delenv(k)
         return out
 
-    base = solve({})
-    for env in ({"FFS_MID_SEG_SLOTS": "3"}, {"FFS_MID_SEG_SLOTS": "3", "FFS_DISABLE_HALF_LAST": "1"}):
+    base = solve({"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0"})  # plain two-slot k_mid_seg, rows in order
+    for env in ({}, {"FFS_DISABLE_HALF_LAST": "1"},  # defaults: pipelined loads + mirror-row pairs per XCD
+                {"FFS_MID_SEG_PIPE": "0"}, {"FFS_MID_SEG_PAIRMAP": "0"},
+                {"FFS_MID_SEG_SLOTS": "3"}, {"FFS_MID_SEG_SLOTS": "3", "FFS_DISABLE_HALF_LAST": "1"},
+                {"FFS_MID_SEG_DB": "1"}, {"FFS_MID_SEG_DB": "1", "FFS_DISABLE_HALF_LAST": "1"}):
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
