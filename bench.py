@@ -451,7 +451,9 @@ def main():
         result["kernels"] = per_kernel
         mm_launch = per_kernel[dom]["must_move_bytes_per_launch"]
         result["roofline"] = {
-            "kernel": {"pass_a": "k_pass_a", "mid": "k_mid_seg" if seg_mode else "k_mid", "pass_c": "k_pass_c_pruned"}[dom],
+            "kernel": {"pass_a": "k_pass_a", "pass_c": "k_pass_c_pruned",
+                       "mid": ("k_mid_seg_pipe" if os.environ.get("FFS_MID_SEG_PIPE") != "0" else "k_mid_seg") if seg_mode
+                       else "k_mid"}[dom],
             "bound": "hbm",
             "achieved": per_kernel[dom]["must_move_GBps"],
             "peak": HBM_PEAK / 1e9,
