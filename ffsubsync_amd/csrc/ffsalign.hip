@@ -139,6 +139,7 @@ struct ffs_plan {
     bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
+    int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
     bool mid_seg_three = false;     // FFS_MID_SEG_SLOTS=3: k_mid_seg3 (three slots per sweep) instead of k_mid_seg
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
     bool mid_seg_db = false;        // FFS_MID_SEG_DB=1: k_mid_seg with two exchange buffers (half the barriers)
@@ -716,6 +717,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->mid_seg_db = (e11 && e11[0] == '1');
         const char* e10 = getenv("FFS_MID_SEG_PIPE");
         p->mid_seg_pipe = !(e10 && e10[0] == '0');
+        const char* e13 = getenv("FFS_RESCORE_SEG");
+        if (e13 && atoi(e13) >= 1 && atoi(e13) <= RSEG) p->rescore_seg_bits = atoi(e13);
         const char* e8 = getenv("FFS_MID_SEG_SLOTS");
         p->mid_seg_three = (e8 && e8[0] == '3');
         const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
@@ -1051,7 +1054,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 return rc;
             {
                 ProfSpan span(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? p->rescore_seg_bits : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
                                                        first_cand));
             }
             HIP_TRY(hipGetLastError());
@@ -1090,7 +1093,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? p->rescore_seg_bits : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
                                                        first_cand));
             }
             HIP_TRY(hipGetLastError());
