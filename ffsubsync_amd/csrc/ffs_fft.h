@@ -407,27 +407,6 @@ FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& 
     }
 }
 
-// Same transform with the two LDS exchanges in two different regions (L = 4096 only).  Alternating regions
-// removes the "previous readers are done" barrier in front of each scatter: a region is rewritten only after
-// the barrier of the exchange that used the OTHER region, which every thread reaches after its own reads of
-// the first one.  Two barriers per transform instead of four.  Entry condition: no thread still reads lds0
-// (true after any previous call of this function, or after a barrier).
-template <int L, class Addr>
-FFS_DEV void fft_regs_db(cf (&v)[16], cf* lds0, cf* lds1, int u, Addr& addr, const TwRegs<L>& tw) {
-    typedef Shape<L> S;
-    static_assert(S::R1 > 1 && S::R2 > 1, "three-stage transforms only");
-    addr.refresh();
-    stage_first(v);
-    stage_scatter<L, 16, 1>(v, lds0, u, addr);
-    __syncthreads();
-    stage_gather<L>(v, lds0, u, addr);
-    stage_compute<L, S::R1, 16>(v, tw.s1);
-    stage_scatter<L, S::R1, 16>(v, lds1, u, addr);
-    __syncthreads();
-    stage_gather<L>(v, lds1, u, addr);
-    stage_compute<L, S::R2, 256>(v, tw.s2);
-}
-
 // ---- column transforms of length 3 * 2^k ----------------------------------------------------
 // A column transform of length L = 3*LI (LI a power of two) is three interleaved length-LI transforms
 // (decimation in time) and one radix-3 combine:

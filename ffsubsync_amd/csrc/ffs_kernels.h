@@ -495,8 +495,6 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     }
 }
 
-template <int L>
-FFS_DEV int u_of(const RowAddr<L>& a) { return 16 * a.u_hi + a.u_lo; }
 template <int L, int... Q>
 FFS_DEV void mirror_store(const cf (&v)[16], cf* lds, const RowAddr<L>& addr, std::integer_sequence<int, Q...>) {
     ((lds[addr.template gather<Q>()] = v[Q]), ...);
@@ -599,8 +597,7 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 // what the unsegmented pipeline moves.  The reference rows are transformed again for every slot
 // (keeping n_blocks spectra would not fit in registers); the row-transform count per pair is the same
 // as in k_mid at three times the transform length.
-// DB: the two LDS exchanges of every row transform use two separate buffers (fft_regs_db: half the barriers).
-template <int L, bool DB>
+template <int L>
 __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                     int n_blocks, float inv_n, const cf* __restrict__ tw,
                                                     const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
@@ -608,14 +605,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
     const int ref_half = half_flags & HALF_REF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
-    cf* lds1 = lds + RowAddr<L>::ROW_ELEMS;  // second exchange buffer (DB only)
     constexpr int LT = L / 16;
-    auto fft = [&](cf(&x)[16], RowAddr<L>& a, const TwRegs<L>& t) {
-        if constexpr (DB)
-            fft_regs_db<L>(x, lds, lds1, u_of(a), a, t);
-        else
-            fft_regs<L>(x, lds, u_of(a), a, t);
-    };
     const int u = threadIdx.x;
     // PAIR_ROWS: rows k1 and N1-k1 read the same stored reference rows (one of them mirrored).  Workgroup b
     // runs on XCD b % 8, so give the two rows of a pair block indices 8 apart: same XCD (same L2), dispatched
@@ -656,35 +646,34 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N
             for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
 #pragma unroll
             for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)s * N + q * qstride)[off0];
-            fft(rr, addr, twr);
+            fft_regs<L>(rr, lds, u, addr, twr);
             if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
-                cf* mbuf = DB ? lds1 : lds;  // DB: the buffer the transform's last gather used (see fft_regs_db)
                 __syncthreads();
-                mirror_store(rr, mbuf, addr, std::make_integer_sequence<int, 16>{});
+                mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
                 __syncthreads();
-                mirror_load(rr, mbuf, addr, std::make_integer_sequence<int, 16>{});
+                mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
             }
 #pragma unroll
             for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R_k)/N
-            fft(v, addr, twr);
+            fft_regs<L>(v, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc_a[q] = cmac(acc_a[q], v[q], rr[q]);
             if (two) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)(s + 1) * N + q * qstride)[off0];
-                fft(v, addr, twr);
+                fft_regs<L>(v, lds, u, addr, twr);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc_b[q] = cmac(acc_b[q], v[q], rr[q]);
             }
         }
-        fft(acc_a, addr, twr);
+        fft_regs<L>(acc_a, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
             (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
         }
         if (two) {
-            fft(acc_b, addr, twr);
+            fft_regs<L>(acc_b, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
@@ -797,84 +786,6 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
                 (base + (size_t)(s + 1) * N + q * qstride)[off0] = cmul(acc_b[q], w);
             }
         }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// Block-segmented mid pass, three candidate slots per sweep over the blocks.  The transformed reference row
-// conj(R_k)/N of the current block is needed once per slot; parking it in LDS (every thread re-reads only
-// the sixteen values it wrote itself: no barrier, no conflicts) frees its 32 registers for a third
-// accumulator row.  With HALF_LAST a seven-ratio solve is three full slots plus one half slot, so the rows
-// above N1/2 are done in ONE sweep (every reference row read and transformed once) and the others in two.
-template <int L>
-__global__ __launch_bounds__(256, 2) void k_mid_seg3(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
-                                                     int n_blocks, float inv_n, const cf* __restrict__ tw,
-                                                     const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
-    static_assert(L == 4096, "one row per 256-thread block");
-    const int ref_half = half_flags & HALF_REF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int LT = L / 16;
-    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]
-    const int u = threadIdx.x;
-    const int k1 = blockIdx.x;
-    RowAddr<L> addr(0, u);
-    const int C = 1 << log2C;
-    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
-    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
-    if (s_end <= 1) return;
-    const bool mirrored = ref_half && k1 > N1 / 2;
-    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
-    const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
-    const size_t qstride = (size_t)LT * N1;
-    const float sgn = mirrored ? inv_n : -inv_n;
-    TwRegs<L> twr;
-    twr.load(tw, u);
-    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
-    for (int s0 = 1; s0 < s_end; s0 += 3) {
-        const int ns = (s_end - s0) < 3 ? (s_end - s0) : 3;
-        cf acc0[16], acc1[16], acc2[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc0[q] = acc1[q] = acc2[q] = mk(0.f, 0.f);
-        for (int k = 0; k < n_blocks; ++k) {
-            cf* grp = base + (size_t)k * n_slots * N;
-            {
-                cf rr[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
-                fft_regs<L>(rr, lds, u, addr, twr);
-                if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
-                    __syncthreads();
-                    mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
-                    __syncthreads();
-                    mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
-                }
-#pragma unroll
-                for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R_k)/N
-            }
-            auto slot = [&](cf(&acc)[16], int j) {
-                cf v[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)(s0 + j) * N + q * qstride)[off0];
-                fft_regs<L>(v, lds, u, addr, twr);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], s_rr[q * LT + u]);
-            };
-            slot(acc0, 0);
-            if (ns > 1) slot(acc1, 1);
-            if (ns > 2) slot(acc2, 2);
-        }
-        auto finish = [&](cf(&acc)[16], int j) {
-            fft_regs<L>(acc, lds, u, addr, twr);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-                (base + (size_t)(s0 + j) * N + q * qstride)[off0] = cmul(acc[q], w);
-            }
-        };
-        finish(acc0, 0);
-        if (ns > 1) finish(acc1, 1);
-        if (ns > 2) finish(acc2, 2);
     }
 }
 

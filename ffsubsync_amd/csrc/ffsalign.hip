@@ -140,9 +140,7 @@ struct ffs_plan {
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
-    bool mid_seg_three = false;     // FFS_MID_SEG_SLOTS=3: k_mid_seg3 (three slots per sweep) instead of k_mid_seg
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
-    bool mid_seg_db = false;        // FFS_MID_SEG_DB=1: k_mid_seg with two exchange buffers (half the barriers)
     bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
     bool pass_a_store8 = true;      // FFS_PASS_A_STORE8=0: 16-byte paired stores in pass A for 64-column tiles too
     // device tables
@@ -339,17 +337,8 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStr
 
 int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, int ref_half, hipStream_t st) {
     int rc_lds;
-    if (sp->mid_seg_three) {  // three slots per sweep, reference row parked in LDS
-        const size_t lds3 = row_lds_bytes(4096) + 4096 * sizeof(cf);
-        if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg3<4096>, lds3))) return rc_lds;
-        hipLaunchKernelGGL((k_mid_seg3<4096>), dim3(sp->N1, n_pairs), dim3(256), lds3, st, sp->work, sp->N1, sp->log2CL,
-                           (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                           ref_half);
-        HIP_TRY(hipGetLastError());
-        return FFS_OK;
-    }
     const size_t lds = row_lds_bytes(4096);
-    if (sp->mid_seg_pipe && !sp->mid_seg_db) {  // software-pipelined row loads (default)
+    if (sp->mid_seg_pipe) {  // software-pipelined row loads (default)
         const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
         if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_pipe<4096>, ldsp))) return rc_lds;
         hipLaunchKernelGGL((k_mid_seg_pipe<4096>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1, sp->log2CL,
@@ -358,16 +347,8 @@ int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, i
         HIP_TRY(hipGetLastError());
         return FFS_OK;
     }
-    if (sp->mid_seg_db) {  // two exchange buffers, half the barriers
-        if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096, true>, 2 * lds))) return rc_lds;
-        hipLaunchKernelGGL((k_mid_seg<4096, true>), dim3(sp->N1, n_pairs), dim3(256), 2 * lds, st, sp->work, sp->N1, sp->log2CL,
-                           (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                           ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0));
-        HIP_TRY(hipGetLastError());
-        return FFS_OK;
-    }
-    if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096, false>, lds))) return rc_lds;
-    hipLaunchKernelGGL((k_mid_seg<4096, false>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1, sp->log2CL,
+    if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096>, lds))) return rc_lds;
+    hipLaunchKernelGGL((k_mid_seg<4096>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1, sp->log2CL,
                        (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
                        ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0));
     HIP_TRY(hipGetLastError());
@@ -713,14 +694,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->pass_a_store8 = !(e9 && e9[0] == '0');
         const char* e12 = getenv("FFS_MID_SEG_PAIRMAP");
         p->mid_seg_pairmap = !(e12 && e12[0] == '0');
-        const char* e11 = getenv("FFS_MID_SEG_DB");
-        p->mid_seg_db = (e11 && e11[0] == '1');
         const char* e10 = getenv("FFS_MID_SEG_PIPE");
         p->mid_seg_pipe = !(e10 && e10[0] == '0');
         const char* e13 = getenv("FFS_RESCORE_SEG");
         if (e13 && atoi(e13) >= 1 && atoi(e13) <= RSEG) p->rescore_seg_bits = atoi(e13);
-        const char* e8 = getenv("FFS_MID_SEG_SLOTS");
-        p->mid_seg_three = (e8 && e8[0] == '3');
         const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
         p->allow_half_last = !(e7 && e7[0] == '1');
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");

@@ -307,10 +307,10 @@ def test_half_rows_of_a_single_candidate_slot_equal_all_rows(torch, monkeypatch,
 
 
 @pytest.mark.parametrize("n_cand", [7, 8, 4, 2])
-def test_three_slots_per_sweep_mid_pass_gives_identical_records(torch, monkeypatch, n_cand):
-    """The variants of the block-segmented mid pass -- k_mid_seg3 (FFS_MID_SEG_SLOTS=3: three accumulator
-    rows, reference row parked in LDS), k_mid_seg_pipe (FFS_MID_SEG_PIPE: row loads issued one item ahead) and
-    the plain two-slot k_mid_seg -- give identical records, with and without the half last slot."""
+def test_mid_pass_variants_give_identical_records(torch, monkeypatch, n_cand):
+    """The default block-segmented mid pass (k_mid_seg_pipe: row loads issued one item ahead, LDS-only
+    barriers, mirror-row pairs on one XCD) against the plain two-slot k_mid_seg with rows in index order,
+    with and without the half last slot, for even and odd candidate counts."""
     from ffsubsync_amd import batch
     from workloads import synth
 
@@ -337,8 +337,7 @@ def test_three_slots_per_sweep_mid_pass_gives_identical_records(torch, monkeypat
     base = solve({"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0"})  # plain two-slot k_mid_seg, rows in order
     for env in ({}, {"FFS_DISABLE_HALF_LAST": "1"},  # defaults: pipelined loads + mirror-row pairs per XCD
                 {"FFS_MID_SEG_PIPE": "0"}, {"FFS_MID_SEG_PAIRMAP": "0"},
-                {"FFS_MID_SEG_SLOTS": "3"}, {"FFS_MID_SEG_SLOTS": "3", "FFS_DISABLE_HALF_LAST": "1"},
-                {"FFS_MID_SEG_DB": "1"}, {"FFS_MID_SEG_DB": "1", "FFS_DISABLE_HALF_LAST": "1"}):
+                {"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0", "FFS_DISABLE_HALF_LAST": "1"}):
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
