@@ -614,7 +614,7 @@ def test_randomised_problems_against_oracle(torch):
         dens = rng.choice([0.05, 0.3, 0.5, 0.9])
         seg = np.maximum(1, rng.geometric(1.0 / rng.choice([2, 20, 200]), size=R))
         ref01 = np.repeat(rng.rand(seg.size) < dens, seg)[:R]
-        n_cand = int(rng.choice([1, 1, 2, 3, 7]))
+        n_cand = int(rng.choice([1, 1, 2, 3, 7] + ([5, 8] if big else [])))
         lo_hi_ref = [(0.0, 1.0), (-1.0, 1.0), (0.25, 1.0)][rng.randint(3)]
         ref = np.where(ref01, lo_hi_ref[1], lo_hi_ref[0])
         cands = []
