@@ -588,12 +588,21 @@ def main():
             allp = gathered.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
             result["gathered_records"] = int(allp.size)
             result["gathered_best_cand_valid"] = int((allp["best_cand"][: (args.pairs if strong else world * per)] >= 0).sum())
-    if rank == 0:
-        print(json.dumps(result))
     if use_dist:
         if comm is not None:
             comm.close()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout when a communicator is created; push it out first so
+        # that the JSON record is the LAST line of the output
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
