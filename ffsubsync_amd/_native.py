@@ -17,6 +17,7 @@ _lib_lock = threading.Lock()
 
 FFS_DTYPE_U8 = 0
 FFS_DTYPE_F32 = 1
+FFS_DTYPE_F64 = 3  # float64 samples (fp32 transforms nominate, fp64 re-evaluation of the caller's own samples)
 FFS_DTYPE_U1 = 2  # one bit per sample, numpy.packbits(..., bitorder="little") order, 32-bit words
 FLAG_EMPTY_WINDOW = 1
 FLAG_AMBIGUOUS = 2

@@ -110,11 +110,10 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
                 v.dev = v.raster.packed_words()
                 keep_alive.append(v.dev)
     else:
-        # float inputs (fused / weighted VAD levels): fp32 for the transforms; the winning lags are re-evaluated
-        # in fp64 from these fp32 samples, i.e. for inputs rounded to fp32 (relative 6e-8; the score tolerance
-        # of the contract is 1e-5)
-        dtype = _native.FFS_DTYPE_F32
-        chunks = [v.host_values().astype(np.float32).view(np.uint8) for v in vecs]
+        # float inputs (fused / weighted VAD levels) go over as float64: the transforms nominate in fp32, the
+        # winning lags are re-evaluated in fp64 from these very samples (no input rounding)
+        dtype = _native.FFS_DTYPE_F64
+        chunks = [np.ascontiguousarray(v.host_values(), dtype=np.float64).view(np.uint8) for v in vecs]
     # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
     offs = np.zeros(len(chunks), dtype=np.int64)
     total = 0

@@ -155,6 +155,8 @@ FFS_DEV float load_mapped(const void* p, int len, int n, float v0, float v1, int
     float val;
     if (DT == 0) {
         val = (reinterpret_cast<const unsigned char*>(p)[idx] != 0) ? v1 : v0;
+    } else if (DT == 3) {
+        val = (float)(2.0 * reinterpret_cast<const double*>(p)[idx] - 1.0);
     } else {
         val = 2.0f * reinterpret_cast<const float*>(p)[idx] - 1.0f;
     }
@@ -1407,6 +1409,14 @@ FFS_DEV void bit_counts(const void* sp, const void* rp, int R, int d, int a, int
     }
 }
 
+// Float inputs: the mapped sample x' = 2x - 1 in fp64 (DT 1: fp32 samples, DT 3: fp64 samples, exactly the
+// reference's arithmetic, aligners.py:55-57).
+template <int DT>
+FFS_DEV double mapped_sample(const void* p, int i) {
+    if (DT == 3) return 2.0 * reinterpret_cast<const double*>(p)[i] - 1.0;
+    return 2.0 * (double)reinterpret_cast<const float*>(p)[i] - 1.0;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
                                                  RescoreAcc* __restrict__ acc, int first_cand) {
@@ -1415,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
     const int count = nl.count;
     if (count <= 0) return;
     const CandDesc& cd = cands[ci];
-    constexpr int VEC = (DT == 0) ? 16 : (DT == 2 ? 128 : 4);  // elements per 16-byte load
+    constexpr int VEC = (DT == 0) ? 16 : (DT == 2 ? 128 : (DT == 3 ? 2 : 4));  // elements per 16-byte load
     for (int ni = 0; ni < count; ++ni) {
         const int d = nl.d[ni];
         const int i0 = d < 0 ? -d : 0;
@@ -1478,6 +1488,16 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
                 atomicAdd(&out.n1x, n1x);
                 atomicAdd(&out.nx1, nx1);
             }
+        } else if (DT == 3) {
+            double sum = 0.0;
+            for (int i = a + (int)threadIdx.x; i < b; i += 256) sum += mapped_sample<3>(cd.s, i) * mapped_sample<3>(cd.r, i + d);
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
+            __shared__ double s_part3[4];
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) s_part3[threadIdx.x >> 6] = sum;
+            __syncthreads();
+            if (threadIdx.x == 0) out.part[blockIdx.x] = ((s_part3[0] + s_part3[1]) + s_part3[2]) + s_part3[3];
         } else {
             const float* s = reinterpret_cast<const float*>(cd.s);
             const float* r = reinterpret_cast<const float*>(cd.r) + d;
@@ -1508,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
 }
 
 FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
-    if (dt == 1) {
+    if (dt == 1 || dt == 3) {
         double sum = 0.0;
         for (int i = 0; i < RSEG; ++i) sum += a.part[i];
         return sum;
@@ -1535,7 +1555,7 @@ __global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict
         const int i0 = d < 0 ? -d : 0;
         const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
         double score = 0.0;
-        if (DT != 1) {
+        if (DT != 1 && DT != 3) {
             const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
             const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + (DT == 0 ? d : 0);
             unsigned int n11 = 0, n1x = 0, nx1 = 0;
@@ -1581,11 +1601,9 @@ __global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict
             a.nx1 = s_cnt[2][0] + s_cnt[2][1] + s_cnt[2][2] + s_cnt[2][3];
             score = exact_score(cd, a, d, 0);
         } else {
-            const float* s = reinterpret_cast<const float*>(cd.s);
-            const float* r = reinterpret_cast<const float*>(cd.r) + d;
             double sum = 0.0;
             for (int i = i0 + (int)threadIdx.x; i < i1; i += 256)
-                sum += (2.0 * (double)s[i] - 1.0) * (2.0 * (double)r[i] - 1.0);
+                sum += mapped_sample<DT>(cd.s, i) * mapped_sample<DT>(cd.r, i + d);
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
             __syncthreads();
@@ -1708,7 +1726,7 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
             const int i0 = d < 0 ? -d : 0;
             const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
             double sc;
-            if (DT != 1) {
+            if (DT != 1 && DT != 3) {
                 const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
                 const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r);
                 RescoreAcc a;
@@ -1722,10 +1740,8 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
                 }
                 sc = exact_score(cd, a, d, 0);
             } else {
-                const float* s = reinterpret_cast<const float*>(cd.s);
-                const float* r = reinterpret_cast<const float*>(cd.r);
                 sc = 0.0;
-                for (int i = i0; i < i1; ++i) sc += (2.0 * (double)s[i] - 1.0) * (2.0 * (double)r[i + d] - 1.0);
+                for (int i = i0; i < i1; ++i) sc += mapped_sample<DT>(cd.s, i) * mapped_sample<DT>(cd.r, i + d);
             }
             if (sc > bs || (sc == bs && d > bd)) {
                 bs = sc;

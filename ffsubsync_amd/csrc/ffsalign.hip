@@ -38,7 +38,7 @@ int fail(int code, const char* fmt, ...) {
         if (_e != hipSuccess) return fail(FFS_E_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); \
     } while (0)
 
-// run `stmt` with a compile-time DT equal to the runtime element type (0 = bytes, 1 = float, 2 = bit-packed)
+// run `stmt` with a compile-time DT equal to the runtime element type (0 = bytes, 1 = float, 2 = bit-packed, 3 = double)
 #define FFS_BY_DTYPE(dtype, stmt)              \
     do {                                       \
         if ((dtype) == FFS_DTYPE_U8) {         \
@@ -46,6 +46,9 @@ int fail(int code, const char* fmt, ...) {
             stmt;                              \
         } else if ((dtype) == FFS_DTYPE_F32) { \
             constexpr int DT = 1;              \
+            stmt;                              \
+        } else if ((dtype) == FFS_DTYPE_F64) { \
+            constexpr int DT = 3;              \
             stmt;                              \
         } else {                               \
             constexpr int DT = 2;              \
@@ -811,7 +814,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     if (!p) return fail(FFS_E_INVALID, "plan is null");
     if (n_pairs < 0 || n_cand < 1 || n_cand > p->max_cand)
         return fail(FFS_E_INVALID, "n_cand=%d outside [1, plan max_cand=%d]", n_cand, p->max_cand);
-    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1)
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1 && dtype != FFS_DTYPE_F64)
         return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
@@ -873,8 +876,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (!ref.ptr || !subs[j].ptr) {
                 if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
             }
-            if (dtype != FFS_DTYPE_U8 && (((uintptr_t)ref.ptr | (uintptr_t)subs[j].ptr) & 3))
-                return fail(FFS_E_INVALID, "float / bit-packed vectors must be 4-byte aligned (pair %d)", pi);
+            if (dtype != FFS_DTYPE_U8 && (((uintptr_t)ref.ptr | (uintptr_t)subs[j].ptr) & (dtype == FFS_DTYPE_F64 ? 7 : 3)))
+                return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
             const CandDesc& cd = hc[(size_t)pi * n_cand + j];
             if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
             // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
@@ -933,7 +936,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 seg_blocks = (int)((s_max + B - 1) / B);
                 seg_lo = d_lo;
                 // byte / float vectors move the pointer to the block's first sample, bit-packed ones the bit offset
-                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : (dtype == FFS_DTYPE_F32 ? 4 : 0);
+                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : (dtype == FFS_DTYPE_F32 ? 4 : (dtype == FFS_DTYPE_F64 ? 8 : 0));
                 n_xf = (size_t)n_pairs * seg_blocks * n_slots;
                 for (int pi = 0; pi < n_pairs; ++pi) {
                     const VecView& ref = views[(size_t)pi * stride];
@@ -1091,7 +1094,7 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
                        const void* a_dev, int64_t a_len, double a_lo, double a_hi, const void* b_dev, int64_t b_len,
                        double b_lo, double b_hi, float* out_a_dev, float* out_b_dev, void* hip_stream) {
     if (!p || p->direct_only) return fail(FFS_E_INVALID, "plan has no FFT path (n_fft < %lld)", (long long)kMinFftN);
-    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1)
+    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1 && dtype != FFS_DTYPE_F64)
         return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
     if (!ref_dev || !a_dev || ref_len <= 0 || a_len <= 0) return fail(FFS_E_EMPTY, "empty reference or candidate");
     if (ref_len > p->N || a_len > p->N || (b_dev && b_len > p->N)) return fail(FFS_E_TOO_LONG, "vector longer than n_fft");

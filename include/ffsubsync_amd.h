@@ -39,6 +39,9 @@ extern "C" {
 /* element types of the activity vectors */
 #define FFS_DTYPE_U8 0  /* two-level signal: byte==0 -> lo, byte!=0 -> hi  */
 #define FFS_DTYPE_F32 1 /* arbitrary float samples (lo/hi = bounds, used for the tie margin) */
+#define FFS_DTYPE_F64 3 /* as FFS_DTYPE_F32 with double samples: the transforms still nominate in fp32, the winning
+                           lags are re-evaluated in fp64 from the caller's own samples (the reference's arithmetic,
+                           aligners.py:55-57, without any input rounding) */
 #define FFS_DTYPE_U1 2  /* two-level signal, one bit per sample: sample i = bit (i & 31) of the 32-bit
                            little-endian word i >> 5 (numpy.packbits(..., bitorder="little")); 0 -> lo, 1 -> hi.
                            The native format of the 0/1 activity vectors: an eighth of the HBM and PCIe bytes of

@@ -343,3 +343,40 @@ def test_mid_pass_variants_give_identical_records(torch, monkeypatch, n_cand):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
         assert np.array_equal(base[1], got[1])
         assert np.abs(got[0]["score_f32"].astype(np.float64) - got[0]["score"]).max() < 0.5
+
+
+def test_float64_inputs_are_rescored_from_the_callers_samples(torch):
+    """FFS_DTYPE_F64: sample values that fp32 cannot represent (0.1, 0.3, 0.7 ...) -- the transforms nominate
+    in fp32, but the reported score is the fp64 sum over the caller's own float64 samples: it agrees with the
+    reference arithmetic to fp64 rounding (1e-12 relative here), not merely to the 1e-5 contract."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.aligners import FFTAligner, _Vec, solve_pairs
+
+    rng = np.random.RandomState(17)
+    lv = np.array([0.0, 0.1, 0.3, 0.7, 1.0])
+    ref = np.repeat(lv[rng.randint(0, 5, 900)], 23)
+    sub = np.concatenate([np.zeros(211), ref[:15000]]) * 0.9
+    assert not _Vec(ref).two_level
+    for mo in (None, 6000, 300):
+        got = FFTAligner(mo).fit_transform(ref, sub, get_score=True)
+        exp = orc.fft_align(ref, sub, mo)
+        assert got[1] == exp[1] == -211
+        assert float(got[0]) == pytest.approx(float(exp[0]), rel=1e-12)
+    # the same through the raw ABI with fp32 copies: still inside the contract, but only to fp32 input rounding
+    d = lambda x, t: torch.from_numpy(np.ascontiguousarray(x, dtype=t)).cuda()
+    n_fft = _native.plan_length(ref.size, sub.size, None)
+    plan = _native.Plan(n_fft, 1, 1)
+    cand_out = torch.empty(24, dtype=torch.uint8, device="cuda")
+    pair_out = torch.empty(24, dtype=torch.uint8, device="cuda")
+    scores = {}
+    for name, dt, t in (("f32", _native.FFS_DTYPE_F32, np.float32), ("f64", _native.FFS_DTYPE_F64, np.float64)):
+        r_dev, s_dev = d(ref, t), d(sub, t)
+        plan.align_batch(1, 1, dt, np.array([r_dev.data_ptr(), s_dev.data_ptr()], np.uint64), np.array([ref.size, sub.size]),
+                         np.array([0.0, 0.0]), np.array([1.0, 0.9]), None, None, cand_out, pair_out)
+        res = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[0]
+        assert int(res["offset"]) == -211
+        scores[name] = float(res["score"])
+    exact = float(orc.fft_align(ref, sub, None)[0])
+    assert abs(scores["f64"] - exact) <= 1e-12 * abs(exact)
+    assert 1e-12 * abs(exact) < abs(scores["f32"] - exact) <= 1e-5 * abs(exact)
+    plan.close()
