@@ -32,6 +32,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
 constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD (default; FFS_MID_SEG_PAIRMAP=0 turns it off)
+constexpr int DBG_NO_FFT = 256, DBG_HOT_MEM = 512;  // section experiments of the mid pass (FFS_MID_DEBUG=1 / 2 / 3)
 constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (default; FFS_PASS_A_STORE8=0 turns it off)
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
@@ -710,7 +711,10 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
     }
     RowAddr<L> addr(0, u);
     const int C = 1 << log2C;
-    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
+    // section experiments (profiles/mid_sections.py): DBG_HOT_MEM makes every pair use pair 0's buffers (all
+    // traffic becomes L2 hits: compute + LDS + issue only), DBG_NO_FFT drops the row transforms (memory only)
+    const bool no_fft = half_flags & DBG_NO_FFT;
+    cf* base = work + (size_t)((half_flags & DBG_HOT_MEM) ? 0 : blockIdx.y) * n_blocks * n_slots * N;
     const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
     if (s_end <= 1) return;
     const bool mirrored = ref_half && k1 > N1 / 2;
@@ -734,8 +738,8 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
             __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
         };
         auto consume_ref = [&](cf(&x)[16]) {
-            fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
-            if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+            if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+            if (mirrored && !no_fft) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
                 lds_barrier();
                 mirror_store(x, lds, addr, std::make_integer_sequence<int, 16>{});
                 lds_barrier();
@@ -745,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
             for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = mk(x[q].x * inv_n, x[q].y * sgn);  // conj(R_k)/N
         };
         auto consume_acc = [&](cf(&x)[16], cf(&acc)[16]) {
-            fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+            if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], x[q], s_rr[q * LT + u]);
         };
@@ -774,14 +778,14 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
         } else {
             for (int k = 0; k < n_blocks; ++k) block1(x0, x1, k);
         }
-        fft_regs<L, RowAddr<L>, true>(acc_a, lds, u, addr, twr);
+        if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_a, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
             (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
         }
         if (two) {
-            fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
+            if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);

@@ -143,6 +143,7 @@ struct ffs_plan {
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
+    int mid_debug = 0;              // FFS_MID_DEBUG: 1 = no row transforms, 2 = L2-resident traffic, 3 = both (WRONG RESULTS: timing only)
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
     bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
     bool pass_a_store8 = true;      // FFS_PASS_A_STORE8=0: 16-byte paired stores in pass A for 64-column tiles too
@@ -346,7 +347,7 @@ int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, i
         if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_pipe<4096>, ldsp))) return rc_lds;
         hipLaunchKernelGGL((k_mid_seg_pipe<4096>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1, sp->log2CL,
                            (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                           ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0));
+                           ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0) | sp->mid_debug);
         HIP_TRY(hipGetLastError());
         return FFS_OK;
     }
@@ -697,6 +698,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->pass_a_store8 = !(e9 && e9[0] == '0');
         const char* e12 = getenv("FFS_MID_SEG_PAIRMAP");
         p->mid_seg_pairmap = !(e12 && e12[0] == '0');
+        const char* e15 = getenv("FFS_MID_DEBUG");
+        if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
         const char* e10 = getenv("FFS_MID_SEG_PIPE");
         p->mid_seg_pipe = !(e10 && e10[0] == '0');
         const char* e13 = getenv("FFS_RESCORE_SEG");
