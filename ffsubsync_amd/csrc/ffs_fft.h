@@ -32,34 +32,52 @@ FFS_HD cf mk(float x, float y) {
 FFS_DEV cf cadd(cf a, cf b) { return a + b; }
 FFS_DEV cf csub(cf a, cf b) { return a - b; }
 // (a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x)
+// one asm statement per complex multiply: the compiler's hazard recogniser treats every inline-asm VGPR result as a
+// possible dst_sel forwarding hazard and puts an s_nop between two dependent statements; packed-FP32 ops write whole
+// registers (no dst_sel), so inside one statement the pair can issue back to back
 FFS_DEV cf cmul(cf a, cf b) {
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "v"(b));
     return r;
 }
 // same with a wave-uniform second factor (compile-time twiddle constants live in an SGPR pair)
 FFS_DEV cf cmul_k(cf a, float kx, float ky) {
     const cf b = {kx, ky};
-    cf t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "s"(b));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
+    cf r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "=&v"(r)
+        : "v"(a), "s"(b));
     return r;
 }
 // acc + a*b: two packed FMAs
 FFS_DEV cf cmac(cf acc, cf a, cf b) {
-    cf t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(b), "v"(acc));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
-    return r;
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(acc)
+        : "v"(a), "v"(b));
+    return acc;
+}
+// the same as a side-effecting statement: cannot be speculated, so `if (uniform) acc = cmac_v(...)` stays a branch
+// instead of becoming compute-both-and-select (which doubles the live accumulators)
+FFS_DEV cf cmac_v(cf acc, cf a, cf b) {
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+                 "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+                 : "+v"(acc)
+                 : "v"(a), "v"(b));
+    return acc;
 }
 // acc + a*k with a wave-uniform k (SGPR pair): two packed FMAs
 FFS_DEV cf cmac_k(cf acc, cf a, float kx, float ky) {
     const cf b = {kx, ky};
-    cf t, r;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "s"(b), "v"(acc));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(a), "s"(b), "v"(t));
-    return r;
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"
+        : "+v"(acc)
+        : "v"(a), "s"(b));
+    return acc;
 }
 // a + (-i)*t = (a.x + t.y, a.y - t.x)   and   a - (-i)*t = (a.x - t.y, a.y + t.x)
 FFS_DEV cf add_negi(cf a, cf t) {

@@ -721,7 +721,8 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
     const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
     const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
     const size_t qstride = (size_t)LT * N1;
-    const float sgn = mirrored ? inv_n : -inv_n;
+    const unsigned off0b = off0 * (unsigned)sizeof(cf), offrb = offr * (unsigned)sizeof(cf);  // < 8*N: fits 32 bits
+    const cf scale = mk(inv_n, mirrored ? inv_n : -inv_n);
     TwRegs<L> twr;
     twr.load(tw, u);
     const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
@@ -731,10 +732,14 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc_a[q] = acc_b[q] = mk(0.f, 0.f);
         auto issue = [&](cf(&x)[16], int k, int slot) {  // slot 0 = the reference row
-            const cf* src = base + ((size_t)k * n_slots + slot) * N;
-            const unsigned off = slot ? off0 : offr;
+            // uniform 64-bit row pointer + 32-bit byte offset per lane: the load takes its base from an SGPR pair
+            const char* src = reinterpret_cast<const char*>(base + ((size_t)k * n_slots + slot) * N);
+            unsigned off = slot ? off0b : offrb;
+            // opaque: otherwise off + q*stride is hoisted as sixteen loop-invariant 64-bit VGPR offsets (32 registers
+            // and a 64-bit add per load); this way the row pointers are scalar adds and the lane offset one VGPR
+            asm volatile("" : "+v"(off));
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = (src + q * qstride)[off];
+            for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const cf*>(src + q * qstride * sizeof(cf) + off);
             __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
         };
         auto consume_ref = [&](cf(&x)[16]) {
@@ -746,7 +751,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
                 mirror_load(x, lds, addr, std::make_integer_sequence<int, 16>{});
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = mk(x[q].x * inv_n, x[q].y * sgn);  // conj(R_k)/N
+            for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = x[q] * scale;  // conj(R_k)/N
         };
         auto consume_acc = [&](cf(&x)[16], cf(&acc)[16]) {
             if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
@@ -782,15 +787,124 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
+            *reinterpret_cast<cf*>(reinterpret_cast<char*>(base + (size_t)s * N + q * qstride) + off0b) = cmul(acc_a[q], w);
         }
         if (two) {
             if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
-                (base + (size_t)(s + 1) * N + q * qstride)[off0] = cmul(acc_b[q], w);
+                *reinterpret_cast<cf*>(reinterpret_cast<char*>(base + (size_t)(s + 1) * N + q * qstride) + off0b) = cmul(acc_b[q], w);
             }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// Block-segmented mid pass, ONE sweep: up to four accumulator rows, so every reference row of a solve with up to
+// eight candidates (four packed slots) is loaded and transformed once -- 19 instead of 22 row transforms per row for
+// seven candidates, and the reference rows are read once instead of twice.  The accumulators alone are 128 VGPRs; it
+// fits in 256 (two blocks per CU) because nothing else stays live across items: conj(R_k)/N is parked in LDS, row
+// pointers are scalar, lane offsets opaque to the optimiser (no hoisted address tables).  PF: the loads of the next
+// item are issued into a staging buffer before the current item is transformed (copied to the work buffer when it is
+// its turn: sixteen moves per item buy static buffer roles, i.e. one copy of the transform code per item kind).
+template <int L, bool PF>
+__global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
+                                                        int n_blocks, float inv_n, const cf* __restrict__ tw,
+                                                        const cf* __restrict__ tb, const cf* __restrict__ ts,
+                                                        int half_flags) {
+    static_assert(L == 4096, "one row per 256-thread block");
+    constexpr int NA = 4;
+    const int ref_half = half_flags & HALF_REF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int LT = L / 16;
+    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]: conj(R_k)/N of the current block, thread-private columns
+    const int u = threadIdx.x;
+    int k1 = blockIdx.x;
+    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see k_mid_seg
+        const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
+        k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
+    }
+    RowAddr<L> addr(0, u);
+    const int C = 1 << log2C;
+    const bool no_fft = half_flags & DBG_NO_FFT;  // section experiments, see k_mid_seg_pipe
+    cf* base = work + (size_t)((half_flags & DBG_HOT_MEM) ? 0 : blockIdx.y) * n_blocks * n_slots * N;
+    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
+    const int na = s_end - 1;  // candidate slots of this row: 1..4 (the host falls back to k_mid_seg_pipe beyond)
+    if (na <= 0) return;
+    const bool mirrored = ref_half && k1 > N1 / 2;
+    const unsigned off0b = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1))) * (unsigned)sizeof(cf);
+    const unsigned offrb =
+        mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) * (unsigned)sizeof(cf) : off0b;
+    const cf scale = mk(inv_n, mirrored ? inv_n : -inv_n);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf acc[NA][16], x[16], xl[PF ? 16 : 1];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[a][q] = mk(0.f, 0.f);
+    // request row (block k, slot) into `dst`: a scalar row pointer that advances by the (opaque) stride + one 32-bit
+    // lane offset -- no per-load vector address arithmetic, no table of hoisted 64-bit offsets
+    auto request = [&](cf* dst, int k, int slot) {
+        const char* p = reinterpret_cast<const char*>(base + ((size_t)k * n_slots + slot) * N);
+        size_t stride = (size_t)LT * N1 * sizeof(cf);
+        unsigned off = slot ? off0b : offrb;
+        asm volatile("" : "+s"(stride), "+v"(off));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            dst[q] = *reinterpret_cast<const cf*>(p + off);
+            p += stride;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
+    };
+    // bring item (k, slot) into x; with PF it was requested one item earlier into xl, and (nk, nslot) is requested now
+    auto fetch = [&](int k, int slot, int nk, int nslot) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = xl[q];
+            if (nk < n_blocks) request(xl, nk, nslot);
+        } else {
+            request(x, k, slot);
+        }
+    };
+    if constexpr (PF) request(xl, 0, 0);
+    for (int k = 0; k < n_blocks; ++k) {
+        fetch(k, 0, k, 1);
+        if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+        if (mirrored && !no_fft) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
+            lds_barrier();
+            mirror_store(x, lds, addr, std::make_integer_sequence<int, 16>{});
+            lds_barrier();
+            mirror_load(x, lds, addr, std::make_integer_sequence<int, 16>{});
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = x[q] * scale;  // conj(R_k)/N
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            if (a >= na) break;
+            const bool last = a + 1 == na;
+            fetch(k, 1 + a, last ? k + 1 : k, last ? 0 : 2 + a);
+            if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][q] = cmac(acc[a][q], x[q], s_rr[q * LT + u]);
+        }
+    }
+    cf wbl = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        if (a >= na) break;
+        if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc[a], lds, u, addr, twr);
+        char* dst = reinterpret_cast<char*>(base + (size_t)(1 + a) * N);
+        size_t stride = (size_t)LT * N1 * sizeof(cf);
+        unsigned off = off0b;
+        asm volatile("" : "+s"(stride), "+v"(off), "+v"(wbl));  // opaque: the sixteen products wb*ts[q] are not hoisted
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf w = (q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+            *reinterpret_cast<cf*>(dst + off) = cmul(acc[a][q], w);
+            dst += stride;
         }
     }
 }

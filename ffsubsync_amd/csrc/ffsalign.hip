@@ -144,6 +144,7 @@ struct ffs_plan {
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
     int mid_debug = 0;              // FFS_MID_DEBUG: 1 = no row transforms, 2 = L2-resident traffic, 3 = both (WRONG RESULTS: timing only)
+    int mid_seg_one = 1;            // FFS_MID_SEG_ONE=0|1|2: k_mid_seg_one (single sweep, four accumulator rows; 2 = no load-ahead, 0 = off)
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
     bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
     bool pass_a_store8 = true;      // FFS_PASS_A_STORE8=0: 16-byte paired stores in pass A for 64-column tiles too
@@ -342,6 +343,23 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStr
 int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, int ref_half, hipStream_t st) {
     int rc_lds;
     const size_t lds = row_lds_bytes(4096);
+    if (sp->mid_seg_one && n_slots - 1 <= 4) {  // single sweep: all (<= 4) candidate slots accumulate at once
+        const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
+        const int flags = ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0) | sp->mid_debug;
+        if (sp->mid_seg_one == 1) {
+            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, true>, ldsp))) return rc_lds;
+            hipLaunchKernelGGL((k_mid_seg_one<4096, true>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
+                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
+                               sp->tbM, sp->tsM, flags);
+        } else {
+            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, false>, ldsp))) return rc_lds;
+            hipLaunchKernelGGL((k_mid_seg_one<4096, false>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
+                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
+                               sp->tbM, sp->tsM, flags);
+        }
+        HIP_TRY(hipGetLastError());
+        return FFS_OK;
+    }
     if (sp->mid_seg_pipe) {  // software-pipelined row loads (default)
         const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
         if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_pipe<4096>, ldsp))) return rc_lds;
@@ -700,6 +718,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->mid_seg_pairmap = !(e12 && e12[0] == '0');
         const char* e15 = getenv("FFS_MID_DEBUG");
         if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
+        const char* e16 = getenv("FFS_MID_SEG_ONE");
+        if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
         const char* e10 = getenv("FFS_MID_SEG_PIPE");
         p->mid_seg_pipe = !(e10 && e10[0] == '0');
         const char* e13 = getenv("FFS_RESCORE_SEG");

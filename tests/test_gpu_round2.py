@@ -337,7 +337,10 @@ def test_mid_pass_variants_give_identical_records(torch, monkeypatch, n_cand):
     base = solve({"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0"})  # plain two-slot k_mid_seg, rows in order
     for env in ({}, {"FFS_DISABLE_HALF_LAST": "1"},  # defaults: pipelined loads + mirror-row pairs per XCD
                 {"FFS_MID_SEG_PIPE": "0"}, {"FFS_MID_SEG_PAIRMAP": "0"},
-                {"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0", "FFS_DISABLE_HALF_LAST": "1"}):
+                {"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0", "FFS_DISABLE_HALF_LAST": "1"},
+                # single sweep (four accumulator rows), with and without load-ahead
+                {"FFS_MID_SEG_ONE": "1"}, {"FFS_MID_SEG_ONE": "2"},
+                {"FFS_MID_SEG_ONE": "1", "FFS_DISABLE_HALF_LAST": "1", "FFS_MID_SEG_PAIRMAP": "0"}):
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
