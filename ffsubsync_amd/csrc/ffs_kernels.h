@@ -533,11 +533,25 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
     const size_t qstride = (size_t)LT * N1;
     auto at = [&](cf* buf, int q) -> cf& {
+        const int x = u + LT * q;
+        return buf[((x >> log2C) * N1 + k1) * C + (x & (C - 1))];
+    };
+    // SEP: a scalar row pointer that advances by the (opaque) stride + one 32-bit lane offset per access -- no
+    // per-element vector address arithmetic and no hoisted table of sixteen 64-bit offsets (32 VGPRs)
+    auto load_row = [&](cf(&x)[16], const cf* buf, unsigned off_elems) {
         if constexpr (SEP) {
-            return (buf + q * qstride)[off0];
+            const char* p = reinterpret_cast<const char*>(buf);
+            size_t stride = qstride * sizeof(cf);
+            unsigned off = off_elems * (unsigned)sizeof(cf);
+            asm volatile("" : "+s"(stride), "+v"(off));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                x[q] = *reinterpret_cast<const cf*>(p + off);
+                p += stride;
+            }
         } else {
-            const int x = u + LT * q;
-            return buf[((x >> log2C) * N1 + k1) * C + (x & (C - 1))];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) x[q] = at(const_cast<cf*>(buf), q);
         }
     };
 
@@ -553,11 +567,9 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     const bool mirrored = (L == 4096) && SEP && ref_half && k1 > N1 / 2;
     if (mirrored) {
         const unsigned offr = (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1)));
-#pragma unroll
-        for (int q = 0; q < 16; ++q) rr[q] = (base + q * qstride)[offr];
+        load_row(rr, base, offr);
     } else {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) rr[q] = at(base, q);
+        load_row(rr, base, off0);
     }
     fft_regs<L>(rr, lds, u, addr, twr);
     if constexpr (L == 4096) {
@@ -576,16 +588,29 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     for (int s = 1; s < s_end; ++s) {
         cf* buf = base + (size_t)s * N;
         cf v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = at(buf, q);
+        load_row(v, buf, off0);
         fft_regs<L>(v, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], rr[q]);
         fft_regs<L>(v, lds, u, addr, twr);
+        if constexpr (SEP) {
+            char* p = reinterpret_cast<char*>(buf);
+            size_t stride = qstride * sizeof(cf);
+            unsigned off = off0 * (unsigned)sizeof(cf);
+            cf wbl = wb;  // opaque: the sixteen products wb*ts[q] are not hoisted out of the slot loop
+            asm volatile("" : "+s"(stride), "+v"(off), "+v"(wbl));
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            at(buf, q) = cmul(v[q], w);
+            for (int q = 0; q < 16; ++q) {
+                const cf w = (q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+                *reinterpret_cast<cf*>(p + off) = cmul(v[q], w);
+                p += stride;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
+                at(buf, q) = cmul(v[q], w);
+            }
         }
     }
 }
