@@ -496,4 +496,34 @@ FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape
     }
 }
 
+// ---- column transforms of length 3*LI with all three sub-transforms in ONE thread ---------------------------
+// col_fft's radix-3 path spreads the three interleaved sub-transforms over three threads and combines them through
+// LDS: 112 LDS operations per 16 values (the sub-transform's exchange, the twiddle table, 16 writes, 48 reads) against
+// 32 for a power-of-two column -- the windowless plans' pass A and last pass were LDS-bound at ~2 TB/s.  Here thread
+// u (of LTI = LI/16 per column) holds x[3(u + LTI*q) + g] for all g: 48 values.  The three sub-transforms run one
+// after the other through the same LI*C-element LDS tile (exactly a power-of-two column of length LI), then
+//     X[k' + LI*r] = F_0[k'] + W_3^r W_L^k' F_1[k'] + W_3^2r W_L^2k' F_2[k'],      k' = u + LTI*q
+// is register arithmetic.  W_L^k' = W_L^u * W_48^q (L = 48*LTI): one per-thread value and compile-time constants.
+// In:  v[g][q] = x[3(u + LTI*q) + g].   Out: v[r][q] = X[u + LTI*q + LI*r].
+static constexpr float kW48[16][2] = {{1.000000000e+00f, 0.000000000e+00f}, {9.914448614e-01f, -1.305261922e-01f}, {9.659258263e-01f, -2.588190451e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.660254038e-01f, -5.000000000e-01f}, {7.933533403e-01f, -6.087614290e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {6.087614290e-01f, -7.933533403e-01f}, {5.000000000e-01f, -8.660254038e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {2.588190451e-01f, -9.659258263e-01f}, {1.305261922e-01f, -9.914448614e-01f}, {0.000000000e+00f, -1.000000000e+00f}, {-1.305261922e-01f, -9.914448614e-01f}, {-2.588190451e-01f, -9.659258263e-01f}, {-3.826834324e-01f, -9.238795325e-01f}};
+static constexpr float kW24[16][2] = {{1.000000000e+00f, 0.000000000e+00f}, {9.659258263e-01f, -2.588190451e-01f}, {8.660254038e-01f, -5.000000000e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.000000000e-01f, -8.660254038e-01f}, {2.588190451e-01f, -9.659258263e-01f}, {0.000000000e+00f, -1.000000000e+00f}, {-2.588190451e-01f, -9.659258263e-01f}, {-5.000000000e-01f, -8.660254038e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.660254038e-01f, -5.000000000e-01f}, {-9.659258263e-01f, -2.588190451e-01f}, {-1.000000000e+00f, 0.000000000e+00f}, {-9.659258263e-01f, 2.588190451e-01f}, {-8.660254038e-01f, 5.000000000e-01f}, {-7.071067812e-01f, 7.071067812e-01f}};
+
+template <int LI, int C, bool LB = false>
+FFS_DEV void col3r_fft(cf (&v)[3][16], cf* lds, int u, int c, const TwRegs<LI>& twr, cf wu, cf wu2) {
+    ColAddr<LI, C> addr(u, c);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) fft_regs<LI, ColAddr<LI, C>, LB>(v[g], lds, u, addr, twr);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const cf t1 = cmul(cmul_k(v[1][q], kW48[q][0], kW48[q][1]), wu);
+        const cf t2 = cmul(cmul_k(v[2][q], kW24[q][0], kW24[q][1]), wu2);
+        const cf sum = cadd(t1, t2), dif = csub(t1, t2);
+        const cf m = mk(v[0][q].x - 0.5f * sum.x, v[0][q].y - 0.5f * sum.y);
+        const cf e = mk(FFS_SQRT3_HALF * dif.x, FFS_SQRT3_HALF * dif.y);
+        v[0][q] = cadd(v[0][q], sum);
+        v[1][q] = add_negi(m, e);  // W_3 = -1/2 - i sqrt(3)/2:  m - i*e
+        v[2][q] = sub_negi(m, e);  //                            m + i*e
+    }
+}
+
 }  // namespace ffsa

@@ -151,6 +151,8 @@ struct ffs_plan {
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
+    cf *tbR = nullptr, *tsR = nullptr, *thR = nullptr;  // pass-A twiddles of the three-sub-transforms-per-thread columns (k_pass_a3)
+    bool col3r = true;              // FFS_COL3R=0: radix-3 columns through LDS (k_pass_a / k_pass_c) instead of k_pass_a3 / k_pass_c3
     cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
     cf* twn1 = nullptr;                       // W_N1^k, k < N1 (pruned pass C)
     cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
@@ -287,9 +289,55 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     return FFS_OK;
 }
 
+// columns of length 3*LI with three sub-transforms per thread (bit-packed inputs): tiles of C = 4096/LI columns
+bool col3r_ok(const ffs_plan* p) { return p->col3r && p->tbR && (p->N1 == 192 || p->N1 == 384 || p->N1 == 768); }
+int col3r_cols(const ffs_plan* p) { return 4096 / (p->N1 / 3); }
+
+template <int LI, int C>
+int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
+                        int ref_half, hipStream_t st) {
+    const size_t lds = (size_t)LI * C * sizeof(cf);
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<LI, C>, lds))) return rc_lds;
+    const int nt = p->N2 / C;
+    hipLaunchKernelGGL((k_pass_a3<LI, C>), dim3(nt, n_xf), dim3(256), lds, st, descs, p->work, p->N2, (long long)p->N, p->tw1,
+                       p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ref_half);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+template <int LI, int C>
+int launch_pass_c3_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
+                        int n_pairs, int half_last, hipStream_t st) {
+    const size_t lds = (size_t)LI * C * sizeof(cf);
+    int rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<LI, C>, lds))) return rc_lds;
+    hipLaunchKernelGGL((k_pass_c3<LI, C>), dim3(p->N2 / C, n_pairs * n_packed), dim3(256), lds, st, p->work, p->N2,
+                       (long long)p->N, p->tw1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1,
+                       half_last);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+int launch_pass_c3(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
+                   int n_pairs, int half_last, hipStream_t st) {
+    switch (p->N1) {
+        case 192: return launch_pass_c3_inst<64, 64>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 384: return launch_pass_c3_inst<128, 32>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 768: return launch_pass_c3_inst<256, 16>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+    }
+    return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
+}
+
 template <int DT>
 int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, int ref_half,
                   hipStream_t st) {
+    if (DT == 2 && col3r_ok(p)) {
+        switch (p->N1) {
+            case 192: return launch_pass_a3_inst<64, 64>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 384: return launch_pass_a3_inst<128, 32>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 768: return launch_pass_a3_inst<256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        }
+    }
     switch (p->N1) {
         case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
         case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
@@ -720,6 +768,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
         const char* e16 = getenv("FFS_MID_SEG_ONE");
         if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
+        const char* e17 = getenv("FFS_COL3R");
+        p->col3r = !(e17 && e17[0] == '0');
         const char* e10 = getenv("FFS_MID_SEG_PIPE");
         p->mid_seg_pipe = !(e10 && e10[0] == '0');
         const char* e13 = getenv("FFS_RESCORE_SEG");
@@ -780,6 +830,18 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if ((rc = upload(&p->tbM, tb, &p->workspace_bytes))) return rc;
         if ((rc = upload(&p->tsM, ts, &p->workspace_bytes))) return rc;
     }
+    if (r3 && LI1 >= 64) {  // k_pass_a3: k1 = u + LTI*q + LI*r
+        const int LTI = LI1 / 16;
+        std::vector<cf> tb((size_t)LTI * N2), ts((size_t)4 * N2), th((size_t)2 * N2);
+        for (int n2 = 0; n2 < N2; ++n2) {
+            for (int u = 0; u < LTI; ++u) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * u);
+            for (int i = 0; i < 4; ++i) ts[(size_t)i * N2 + n2] = wn(N, (int64_t)n2 * LTI * (1 << i));
+            for (int r = 1; r <= 2; ++r) th[(size_t)(r - 1) * N2 + n2] = wn(N, (int64_t)n2 * LI1 * r);
+        }
+        if ((rc = upload(&p->tbR, tb, &p->workspace_bytes))) return rc;
+        if ((rc = upload(&p->tsR, ts, &p->workspace_bytes))) return rc;
+        if ((rc = upload(&p->thR, th, &p->workspace_bytes))) return rc;
+    }
     {
         std::vector<cf> t((size_t)N1);
         for (int k = 0; k < N1; ++k) t[k] = wn(N1, k);
@@ -811,6 +873,9 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->tw2);
     (void)hipFree(p->tbA);
     (void)hipFree(p->tsA);
+    (void)hipFree(p->tbR);
+    (void)hipFree(p->tsR);
+    (void)hipFree(p->thR);
     (void)hipFree(p->tbM);
     (void)hipFree(p->tsM);
     (void)hipFree(p->twn1);
@@ -1018,6 +1083,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     } else {
         HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
         const int tiles = p->N2 / p->C;
+        const bool full3 = !pruned && col3r_ok(p);  // full last pass over radix-3 columns: k_pass_c3's (wider) tiles
         for (int p0 = 0; seg && p0 < n_pairs; p0 += p->pairs_in_flight) {
             // block-segmented pipeline on the length-M sub-plan: 3x shorter transforms, the blocks'
             // spectrum products are added in the mid pass, last pass over one third of the data
@@ -1079,14 +1145,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             {
                 ProfSpan sp(p, st, FFS_K_PASS_C);
                 rc = pruned ? launch_pass_c_pruned<false>(p, dc, first_cand, n_cand, n_packed, slot_map, np, bins, pa, st)
-                            : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
+                     : full3 ? launch_pass_c3(p, dc, first_cand, n_cand, n_packed, slot_map, np, pa.half_last, st)
+                             : launch_pass_c<0>(p, dc, first_cand, n_cand, n_packed, slot_map, np, nullptr, nullptr, pa, st);
             }
             if (rc) return rc;
             HIP_TRY(hipMemsetAsync(p->xlist, 0, sizeof(int), st));
             {
                 ProfSpan sp(p, st, FFS_K_NOMINEES);
-                hipLaunchKernelGGL(k_nominees, dim3(np * n_cand), dim3(64), 0, st, p->bnom, tiles, n_cand, n_packed, dc,
-                                   dn, first_cand, p->xlist);
+                hipLaunchKernelGGL(k_nominees, dim3(np * n_cand), dim3(64), 0, st, p->bnom, full3 ? p->N2 / col3r_cols(p) : tiles,
+                                   n_cand, n_packed, dc, dn, first_cand, p->xlist);
             }
             HIP_TRY(hipGetLastError());
             // candidates whose nominee lists overflowed (listed by k_nominees): sweep their transforms again,

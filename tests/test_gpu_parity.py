@@ -89,7 +89,11 @@ def test_raw_correlation_three_times_power_of_two(torch, n):
     pk = lambda x: _native.pack_bits(d(x))
     bit_a, bit_b = plan.correlate_full(_native.FFS_DTYPE_U1, pk(ref), (0, 1), pk(a), (0, 1), pk(b), (0.0, 0.96),
                                        lens=(R, Sa, Sb))
-    assert torch.equal(bit_a, out_a) and torch.equal(bit_b, out_b)
+    if n < 3 << 18:
+        assert torch.equal(bit_a, out_a) and torch.equal(bit_b, out_b)
+    else:  # N1 >= 192: bit-packed inputs take k_pass_a3 (radix-3 step in registers) -- same values, other rounding
+        assert np.abs(bit_a.cpu().numpy() - ea).max() < tol / 8 and np.abs(bit_b.cpu().numpy() - eb).max() < tol / 8
+        assert not torch.equal(bit_a, out_a) or os.environ.get("FFS_COL3R") == "0"  # i.e. the new kernel did run
     if n <= 3 << 16:
         fa = rng.rand(Sa).astype(np.float32)
         out_f, _ = plan.correlate_full(_native.FFS_DTYPE_F32, d(ref.astype(np.float32)), (0, 1), d(fa), (0, 1))

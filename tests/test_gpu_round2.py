@@ -383,3 +383,42 @@ def test_float64_inputs_are_rescored_from_the_callers_samples(torch):
     assert abs(scores["f64"] - exact) <= 1e-12 * abs(exact)
     assert 1e-12 * abs(exact) < abs(scores["f32"] - exact) <= 1e-5 * abs(exact)
     plan.close()
+
+
+@pytest.mark.parametrize("case", ["n192_window", "n384_none", "n768_none"])
+def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, case):
+    """Plans with 3*2^k columns (N1 = 192 / 384 / 768): k_pass_a3 / k_pass_c3 keep the three sub-transforms of a
+    column in one thread (radix-3 step in registers); FFS_COL3R=0 selects the LDS-combined k_pass_a / k_pass_c.
+    Same records either way, with and without the half slots."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    dur = {"n192_window": 7200.0, "n384_none": 7000.0, "n768_none": 14000.0}[case]
+    specs = [synth.make_pair_spec(2100 + i, duration_s=dur - 300.0 * i) for i in range(2)]
+    db = synth.build_device_batch(specs)
+    max_offset = 6000 if case == "n192_window" else None
+    n_fft = db.required_fft_length(max_offset)
+    assert n_fft == {"n192_window": 786432, "n384_none": 1572864, "n768_none": 3145728}[case]
+
+    def solve(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        al = batch.BatchAligner(n_fft, 7, max_offset, pairs_in_flight=2)
+        out = al.solve(db)
+        al.plan.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    seg_off = {"FFS_DISABLE_SEGMENTED": "1"}  # the windowed case would otherwise run block-segmented (power-of-two columns)
+    base = solve(dict(seg_off, FFS_COL3R="0"))
+    for env in (dict(seg_off), dict(seg_off, FFS_DISABLE_HALF_LAST="1", FFS_DISABLE_REF_HALF="1"),
+                dict(seg_off, FFS_DISABLE_PRUNED_PASS_C="1")):
+        got = solve(env)
+        for f in ("score", "offset", "flags"):
+            assert np.array_equal(base[0][f], got[0][f]), (env, f)
+        assert np.array_equal(base[1], got[1])
+        assert np.abs(got[0]["score_f32"].astype(np.float64) - got[0]["score"]).max() < 1.0
+    for i, sp in enumerate(specs):  # and they are the right answers
+        assert int(base[1][i]["best_cand"]) == sp.true_ratio_index
+        assert abs(int(base[1][i]["offset"]) - sp.true_offset_samples) <= 30
