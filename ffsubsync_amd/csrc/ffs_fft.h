@@ -508,21 +508,34 @@ FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape
 static constexpr float kW48[16][2] = {{1.000000000e+00f, 0.000000000e+00f}, {9.914448614e-01f, -1.305261922e-01f}, {9.659258263e-01f, -2.588190451e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.660254038e-01f, -5.000000000e-01f}, {7.933533403e-01f, -6.087614290e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {6.087614290e-01f, -7.933533403e-01f}, {5.000000000e-01f, -8.660254038e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {2.588190451e-01f, -9.659258263e-01f}, {1.305261922e-01f, -9.914448614e-01f}, {0.000000000e+00f, -1.000000000e+00f}, {-1.305261922e-01f, -9.914448614e-01f}, {-2.588190451e-01f, -9.659258263e-01f}, {-3.826834324e-01f, -9.238795325e-01f}};
 static constexpr float kW24[16][2] = {{1.000000000e+00f, 0.000000000e+00f}, {9.659258263e-01f, -2.588190451e-01f}, {8.660254038e-01f, -5.000000000e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.000000000e-01f, -8.660254038e-01f}, {2.588190451e-01f, -9.659258263e-01f}, {0.000000000e+00f, -1.000000000e+00f}, {-2.588190451e-01f, -9.659258263e-01f}, {-5.000000000e-01f, -8.660254038e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.660254038e-01f, -5.000000000e-01f}, {-9.659258263e-01f, -2.588190451e-01f}, {-1.000000000e+00f, 0.000000000e+00f}, {-9.659258263e-01f, 2.588190451e-01f}, {-8.660254038e-01f, 5.000000000e-01f}, {-7.071067812e-01f, 7.071067812e-01f}};
 
-template <int LI, int C, bool LB = false>
-FFS_DEV void col3r_fft(cf (&v)[3][16], cf* lds, int u, int c, const TwRegs<LI>& twr, cf wu, cf wu2) {
+static constexpr float kW32[16][2] = {{1.000000000e+00f, 0.000000000e+00f}, {9.807852804e-01f, -1.950903220e-01f}, {9.238795325e-01f, -3.826834324e-01f}, {8.314696123e-01f, -5.555702330e-01f}, {7.071067812e-01f, -7.071067812e-01f}, {5.555702330e-01f, -8.314696123e-01f}, {3.826834324e-01f, -9.238795325e-01f}, {1.950903220e-01f, -9.807852804e-01f}, {0.000000000e+00f, -1.000000000e+00f}, {-1.950903220e-01f, -9.807852804e-01f}, {-3.826834324e-01f, -9.238795325e-01f}, {-5.555702330e-01f, -8.314696123e-01f}, {-7.071067812e-01f, -7.071067812e-01f}, {-8.314696123e-01f, -5.555702330e-01f}, {-9.238795325e-01f, -3.826834324e-01f}, {-9.807852804e-01f, -1.950903220e-01f}};
+
+// NS = 3 (L = 3*LI, above) or NS = 2 (L = 2*LI: X[k'] = F_0 + W_L^k' F_1, X[k' + LI] = F_0 - W_L^k' F_1 with
+// W_L^k' = W_L^u * W_32^q -- a 512-row column as two 256-row sub-transforms, one LDS exchange each, instead of the
+// three-stage 16*16*2 column with two).
+template <int NS, int LI, int C, bool LB = false>
+FFS_DEV void colnr_fft(cf (&v)[NS][16], cf* lds, int u, int c, const TwRegs<LI>& twr, cf wu, cf wu2) {
+    static_assert(NS == 2 || NS == 3, "two or three sub-transforms per thread");
     ColAddr<LI, C> addr(u, c);
 #pragma unroll
-    for (int g = 0; g < 3; ++g) fft_regs<LI, ColAddr<LI, C>, LB>(v[g], lds, u, addr, twr);
+    for (int g = 0; g < NS; ++g) fft_regs<LI, ColAddr<LI, C>, LB>(v[g], lds, u, addr, twr);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const cf t1 = cmul(cmul_k(v[1][q], kW48[q][0], kW48[q][1]), wu);
-        const cf t2 = cmul(cmul_k(v[2][q], kW24[q][0], kW24[q][1]), wu2);
-        const cf sum = cadd(t1, t2), dif = csub(t1, t2);
-        const cf m = mk(v[0][q].x - 0.5f * sum.x, v[0][q].y - 0.5f * sum.y);
-        const cf e = mk(FFS_SQRT3_HALF * dif.x, FFS_SQRT3_HALF * dif.y);
-        v[0][q] = cadd(v[0][q], sum);
-        v[1][q] = add_negi(m, e);  // W_3 = -1/2 - i sqrt(3)/2:  m - i*e
-        v[2][q] = sub_negi(m, e);  //                            m + i*e
+        if constexpr (NS == 2) {
+            const cf t1 = cmul(cmul_k(v[1][q], kW32[q][0], kW32[q][1]), wu);
+            const cf f0 = v[0][q];
+            v[0][q] = cadd(f0, t1);
+            v[1][q] = csub(f0, t1);
+        } else {
+            const cf t1 = cmul(cmul_k(v[1][q], kW48[q][0], kW48[q][1]), wu);
+            const cf t2 = cmul(cmul_k(v[2][q], kW24[q][0], kW24[q][1]), wu2);
+            const cf sum = cadd(t1, t2), dif = csub(t1, t2);
+            const cf m = mk(v[0][q].x - 0.5f * sum.x, v[0][q].y - 0.5f * sum.y);
+            const cf e = mk(FFS_SQRT3_HALF * dif.x, FFS_SQRT3_HALF * dif.y);
+            v[0][q] = cadd(v[0][q], sum);
+            v[1][q] = add_negi(m, e);  // W_3 = -1/2 - i sqrt(3)/2:  m - i*e
+            v[2][q] = sub_negi(m, e);  //                            m + i*e
+        }
     }
 }
 

@@ -1320,10 +1320,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
 #ifndef FFS_C3_WAVES
 #define FFS_C3_WAVES 3
 #endif
-// pass C for columns of length L = 3*LI, three sub-transforms per thread (col3r_fft): nominees only (MODE 0 of
+// pass C for columns of length L = NS*LI (NS = 3: 192/384/768 rows; NS = 2: 512 rows), all sub-transforms of a column in
+// one thread (colnr_fft): nominees only (MODE 0 of
 // k_pass_c; the diagnostic and exhaustive modes stay with k_pass_c, the work layout is the same).
 // grid = (N2/C, n_candidate_transforms); block = (LI/16)*C = 256 threads.
-template <int LI, int C>
+template <int NS, int LI, int C>
 __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restrict__ work, int N2, long long N,
                                                  const cf* __restrict__ tw, const CandDesc* __restrict__ cands,
                                                  int first_cand, int n_cand, int n_packed, int n_slots,
@@ -1331,7 +1332,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restr
                                                  int half_last) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int L = 3 * LI, LTI = LI / 16, NT = LTI * C, NW = NT / 64;
+    constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, NW = NT / 64;
     static_assert(NT == 256, "256 threads per block");
     const int tid = threadIdx.x;
     const int c = tid % C, u = tid / C;
@@ -1341,25 +1342,25 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restr
     TwRegs<LI> twr;
     twr.load(tw, u);
     const cf wu = tw3[u], wu2 = tw3[2 * u];  // W_L^u, W_L^2u
-    cf v[3][16];
+    cf v[NS][16];
     const cf* col = in + tile_base<L, C>(tile, c, log2CL);
     if (half_last && kp == n_packed - 1) {  // HALF_LAST: rows above L/2 are the conjugates of stored rows (k_pass_c)
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NS; ++g)
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int row = 3 * (u + LTI * q) + g;
+                const int row = NS * (u + LTI * q) + g;
                 const cf y = col[(size_t)(row <= L / 2 ? row : L - row) << log2CL];
                 v[g][q] = row <= L / 2 ? y : mk(y.x, -y.y);
             }
     } else {
         // scalar row pointer stepping by the (opaque) stride of 3*LTI rows + one 32-bit lane offset per sub-transform
-        size_t stride = ((size_t)(3 * LTI) << log2CL) * sizeof(cf);
-        unsigned off = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)(3 * u) << log2CL)) * (unsigned)sizeof(cf);
+        size_t stride = ((size_t)(NS * LTI) << log2CL) * sizeof(cf);
+        unsigned off = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)(NS * u) << log2CL)) * (unsigned)sizeof(cf);
         const unsigned row_bytes = (unsigned)sizeof(cf) << log2CL;
         asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
-        for (int g = 0; g < 3; ++g) {
+        for (int g = 0; g < NS; ++g) {
             const char* p = reinterpret_cast<const char*>(in);
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
@@ -1368,20 +1369,20 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restr
             }
         }
     }
-    col3r_fft<LI, C>(v, lds, u, c, twr, wu, wu2);
+    colnr_fft<NS, LI, C>(v, lds, u, c, twr, wu, wu2);
     // v[r][q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LTI*q + LI*r
     const int m1 = tile * C + c;
     const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, (int)N);
-    block_nominees<48, NW>(
+    block_nominees<16 * NS, NW>(
         &v[0][0], [&](int i) { return m1 + N2 * (u + LTI * (i % 16) + LI * (i / 16)); }, wp, (int)N, smem, tid,
         &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
 }
 
 // --------------------------------------------------------------------------------------------
-// pass A for columns of length L = 3*LI, bit-packed inputs, three sub-transforms per thread (col3r_fft).
+// pass A for columns of length L = NS*LI, bit-packed inputs, all sub-transforms of a column in one thread (colnr_fft).
 // grid = (N2/C, n_transforms); block = (LI/16)*C = 256 threads; same outputs as k_pass_a<L, ., 2>.
-// tbR[u][n2] = W_N^(n2*u) (u < LTI), tsR[i][n2] = W_N^(n2*LTI*2^i) (i < 4), thR[r-1][n2] = W_N^(n2*LI*r) (r = 1, 2).
-template <int LI, int C>
+// tbR[u][n2] = W_N^(n2*u) (u < LTI), tsR[i][n2] = W_N^(n2*LTI*2^i) (i < 4), thR[r-1][n2] = W_N^(n2*LI*r) (0 < r < NS).
+template <int NS, int LI, int C>
 __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* __restrict__ descs, cf* __restrict__ work, int N2,
                                                  long long N, const cf* __restrict__ tw, const cf* __restrict__ tbR,
                                                  const cf* __restrict__ tsR, const cf* __restrict__ thR,
@@ -1389,7 +1390,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
                                                  int slots_per_pair, int nt, int half_flags) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int L = 3 * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
+    constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
     static_assert(NT == 256, "256 threads per block");
     const int c = threadIdx.x % C, u = threadIdx.x / C;
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;  // see k_pass_a
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
     const cf wu = tw3[u], wu2 = tw3[2 * u];
     const cf b0 = tbR[(size_t)u * N2 + n2];
     const cf g1 = tsR[n2], g2 = tsR[(size_t)N2 + n2], g4 = tsR[(size_t)2 * N2 + n2], g8 = tsR[(size_t)3 * N2 + n2];
-    const cf h1 = thR[n2], h2 = thR[(size_t)N2 + n2];
+    const cf h1 = thR[n2], h2 = NS == 3 ? thR[(size_t)N2 + n2] : h1;
     // aligned C-bit windows of all L rows of both vectors in LDS (as in k_pass_a's bit path)
     unsigned* stage = reinterpret_cast<unsigned*>(smem);  // [2][L][CW]
     const int col0 = tile * C;
@@ -1419,37 +1420,37 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
         stage[i] = __builtin_amdgcn_alignbit(d1, d0, (unsigned)bit0 & 31u);
     }
     __syncthreads();
-    cf v[3][16];
+    cf v[NS][16];
     const unsigned sh = c & 31;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const unsigned* win = stage + h * (L * CW) + (3 * u) * CW + (c >> 5);
+        const unsigned* win = stage + h * (L * CW) + (NS * u) * CW + (c >> 5);
         const float v0 = h ? d.b0 : d.a0, v1 = h ? d.b1 : d.a1;
         const int len = h ? d.len_b : d.len_a, lead = h ? d.lead_b : d.lead_a;
         // rows [0, rows_full) lie inside the vector for every column of the tile, rows >= rows_any outside for all
-        // of them: per q (rows 3*LTI*q .. 3*LTI*(q+1)-1 over the block) the class is block-uniform
+        // of them: per q (rows NS*LTI*q .. NS*LTI*(q+1)-1 over the block) the class is block-uniform
         const int col_end = col0 + C;
         const int rows_full = (lead == 0 && len >= col_end) ? (len - col_end) / N2 + 1 : 0;
         const int rows_any = (len > col0) ? (len - col0 + N2 - 1) / N2 : 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int r0 = 3 * LTI * q;
+            const int r0 = NS * LTI * q;
             if (r0 >= rows_any) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
+                for (int g = 0; g < NS; ++g) {
                     if (h)
                         v[g][q].y = 0.0f;
                     else
                         v[g][q].x = 0.0f;
                 }
             } else {
-                const bool test = r0 + 3 * LTI > rows_full;
+                const bool test = r0 + NS * LTI > rows_full;
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const unsigned b = (unsigned)__builtin_amdgcn_sbfe((int)win[(3 * LTI * q + g) * CW], sh, 1u);  // 0 or ~0
+                for (int g = 0; g < NS; ++g) {
+                    const unsigned b = (unsigned)__builtin_amdgcn_sbfe((int)win[(NS * LTI * q + g) * CW], sh, 1u);  // 0 or ~0
                     float x = pick_level<true>(b, v0, v1);
                     if (test) {
-                        const int n = (3 * (u + LTI * q) + g) * N2 + n2;
+                        const int n = (NS * (u + LTI * q) + g) * N2 + n2;
                         x = (n >= lead && n < len) ? x : 0.0f;
                     }
                     if (h)
@@ -1460,7 +1461,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
             }
         }
     }
-    col3r_fft<LI, C>(v, lds, u, c, twr, wu, wu2);
+    colnr_fft<NS, LI, C>(v, lds, u, c, twr, wu, wu2);
     // v[r][q] = Y[k1 = u + LTI*q + LI*r][n2]; twiddle W_N^(n2*k1) = b0 * g^q * h_r
     cf wq[16];
     wq[0] = b0;
@@ -1479,7 +1480,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
     const unsigned o0 = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)u << log2CL)) * (unsigned)sizeof(cf);
     const unsigned ostep = ((unsigned)LTI << log2CL) * (unsigned)sizeof(cf);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NS; ++r) {
         if (LI * r >= k1_end) break;  // block-uniform: the whole third of the rows is beyond the stored half
 #pragma unroll
         for (int q = 0; q < 16; ++q) {

@@ -151,6 +151,7 @@ struct ffs_plan {
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
+    cf* tw1h = nullptr;                       // stage tables of the 256-row sub-transforms of a 512-row column
     cf *tbR = nullptr, *tsR = nullptr, *thR = nullptr;  // pass-A twiddles of the three-sub-transforms-per-thread columns (k_pass_a3)
     bool col3r = true;              // FFS_COL3R=0: radix-3 columns through LDS (k_pass_a / k_pass_c) instead of k_pass_a3 / k_pass_c3
     cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
@@ -290,30 +291,31 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
 }
 
 // columns of length 3*LI with three sub-transforms per thread (bit-packed inputs): tiles of C = 4096/LI columns
-bool col3r_ok(const ffs_plan* p) { return p->col3r && p->tbR && (p->N1 == 192 || p->N1 == 384 || p->N1 == 768); }
-int col3r_cols(const ffs_plan* p) { return 4096 / (p->N1 / 3); }
+bool col3r_ok(const ffs_plan* p) { return p->col3r && p->tbR && (p->N1 == 192 || p->N1 == 384 || p->N1 == 768 || p->N1 == 512); }
+int col3r_cols(const ffs_plan* p) { return p->N1 == 512 ? 16 : 4096 / (p->N1 / 3); }
 
-template <int LI, int C>
+template <int NS, int LI, int C>
 int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
                         int ref_half, hipStream_t st) {
     const size_t lds = (size_t)LI * C * sizeof(cf);
     int rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<LI, C>, lds))) return rc_lds;
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C>, lds))) return rc_lds;
     const int nt = p->N2 / C;
-    hipLaunchKernelGGL((k_pass_a3<LI, C>), dim3(nt, n_xf), dim3(256), lds, st, descs, p->work, p->N2, (long long)p->N, p->tw1,
+    hipLaunchKernelGGL((k_pass_a3<NS, LI, C>), dim3(nt, n_xf), dim3(256), lds, st, descs, p->work, p->N2, (long long)p->N,
+                       NS == 2 ? p->tw1h : p->tw1,
                        p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ref_half);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
-template <int LI, int C>
+template <int NS, int LI, int C>
 int launch_pass_c3_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
                         int n_pairs, int half_last, hipStream_t st) {
     const size_t lds = (size_t)LI * C * sizeof(cf);
     int rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<LI, C>, lds))) return rc_lds;
-    hipLaunchKernelGGL((k_pass_c3<LI, C>), dim3(p->N2 / C, n_pairs * n_packed), dim3(256), lds, st, p->work, p->N2,
-                       (long long)p->N, p->tw1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1,
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<NS, LI, C>, lds))) return rc_lds;
+    hipLaunchKernelGGL((k_pass_c3<NS, LI, C>), dim3(p->N2 / C, n_pairs * n_packed), dim3(256), lds, st, p->work, p->N2,
+                       (long long)p->N, NS == 2 ? p->tw1h : p->tw1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1,
                        half_last);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
@@ -321,9 +323,10 @@ int launch_pass_c3_inst(const ffs_plan* p, const CandDesc* cands, int first_cand
 int launch_pass_c3(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
                    int n_pairs, int half_last, hipStream_t st) {
     switch (p->N1) {
-        case 192: return launch_pass_c3_inst<64, 64>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
-        case 384: return launch_pass_c3_inst<128, 32>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
-        case 768: return launch_pass_c3_inst<256, 16>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 192: return launch_pass_c3_inst<3, 64, 64>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 384: return launch_pass_c3_inst<3, 128, 32>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 768: return launch_pass_c3_inst<3, 256, 16>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
+        case 512: return launch_pass_c3_inst<2, 256, 16>(p, cands, first_cand, n_cand, n_packed, n_slots, n_pairs, half_last, st);
     }
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
@@ -333,9 +336,10 @@ int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_pe
                   hipStream_t st) {
     if (DT == 2 && col3r_ok(p)) {
         switch (p->N1) {
-            case 192: return launch_pass_a3_inst<64, 64>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-            case 384: return launch_pass_a3_inst<128, 32>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-            case 768: return launch_pass_a3_inst<256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 192: return launch_pass_a3_inst<3, 64, 64>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 384: return launch_pass_a3_inst<3, 128, 32>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 768: return launch_pass_a3_inst<3, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 512: return launch_pass_a3_inst<2, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
         }
     }
     switch (p->N1) {
@@ -806,6 +810,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     const int LI1 = r3 ? N1 / 3 : N1;  // power-of-two part of the column length
     if ((rc = upload(&p->tw1, make_stage_tables(LI1), &p->workspace_bytes))) return rc;
     if ((rc = upload(&p->tw2, make_stage_tables(N2), &p->workspace_bytes))) return rc;
+    if (N1 == 512 && (rc = upload(&p->tw1h, make_stage_tables(256), &p->workspace_bytes))) return rc;  // sub-transforms of k_pass_a3/c3<2, 256>
     {
         // Power-of-two columns: thread u holds the outputs k1 = u + LT1*q.  3*2^k columns (k_pass_a's
         // radix-3 branch): store thread rg = r*KG + kg holds k1 = kg + LI*r + KG*j, KG = 2*(LI/16).
@@ -830,13 +835,14 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if ((rc = upload(&p->tbM, tb, &p->workspace_bytes))) return rc;
         if ((rc = upload(&p->tsM, ts, &p->workspace_bytes))) return rc;
     }
-    if (r3 && LI1 >= 64) {  // k_pass_a3: k1 = u + LTI*q + LI*r
-        const int LTI = LI1 / 16;
+    if ((r3 && LI1 >= 64) || N1 == 512) {  // k_pass_a3: k1 = u + LTI*q + LI*r (three sub-transforms; two for N1 = 512)
+        const int LIr = r3 ? LI1 : 256;
+        const int LTI = LIr / 16;
         std::vector<cf> tb((size_t)LTI * N2), ts((size_t)4 * N2), th((size_t)2 * N2);
         for (int n2 = 0; n2 < N2; ++n2) {
             for (int u = 0; u < LTI; ++u) tb[(size_t)u * N2 + n2] = wn(N, (int64_t)n2 * u);
             for (int i = 0; i < 4; ++i) ts[(size_t)i * N2 + n2] = wn(N, (int64_t)n2 * LTI * (1 << i));
-            for (int r = 1; r <= 2; ++r) th[(size_t)(r - 1) * N2 + n2] = wn(N, (int64_t)n2 * LI1 * r);
+            for (int r = 1; r <= 2; ++r) th[(size_t)(r - 1) * N2 + n2] = wn(N, (int64_t)n2 * LIr * r);
         }
         if ((rc = upload(&p->tbR, tb, &p->workspace_bytes))) return rc;
         if ((rc = upload(&p->tsR, ts, &p->workspace_bytes))) return rc;
@@ -873,6 +879,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->tw2);
     (void)hipFree(p->tbA);
     (void)hipFree(p->tsA);
+    (void)hipFree(p->tw1h);
     (void)hipFree(p->tbR);
     (void)hipFree(p->tsR);
     (void)hipFree(p->thR);

@@ -385,20 +385,23 @@ def test_float64_inputs_are_rescored_from_the_callers_samples(torch):
     plan.close()
 
 
-@pytest.mark.parametrize("case", ["n192_window", "n384_none", "n768_none"])
+@pytest.mark.parametrize("case", ["n192_window", "n384_none", "n768_none", "n512_none", "n512_reference_length"])
 def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, case):
-    """Plans with 3*2^k columns (N1 = 192 / 384 / 768): k_pass_a3 / k_pass_c3 keep the three sub-transforms of a
-    column in one thread (radix-3 step in registers); FFS_COL3R=0 selects the LDS-combined k_pass_a / k_pass_c.
-    Same records either way, with and without the half slots."""
+    """Plans with 3*2^k columns (N1 = 192 / 384 / 768) and with 512-row columns (N = 2^21): k_pass_a3 / k_pass_c3
+    keep the three (two) sub-transforms of a column in one thread (last radix step in registers); FFS_COL3R=0
+    selects k_pass_a / k_pass_c (radix-3 combine through LDS; three-stage 512-row columns).  Same records either
+    way, with and without the half slots."""
     from ffsubsync_amd import batch
     from workloads import synth
 
-    dur = {"n192_window": 7200.0, "n384_none": 7000.0, "n768_none": 14000.0}[case]
+    dur = {"n192_window": 7200.0, "n384_none": 7000.0, "n768_none": 14000.0, "n512_none": 9200.0,
+           "n512_reference_length": 7200.0}[case]
     specs = [synth.make_pair_spec(2100 + i, duration_s=dur - 300.0 * i) for i in range(2)]
     db = synth.build_device_batch(specs)
-    max_offset = 6000 if case == "n192_window" else None
-    n_fft = db.required_fft_length(max_offset)
-    assert n_fft == {"n192_window": 786432, "n384_none": 1572864, "n768_none": 3145728}[case]
+    max_offset = 6000 if case in ("n192_window", "n512_reference_length") else None
+    n_fft = db.required_fft_length(max_offset, reference_length=(case == "n512_reference_length"))
+    assert n_fft == {"n192_window": 786432, "n384_none": 1572864, "n768_none": 3145728, "n512_none": 2097152,
+                     "n512_reference_length": 2097152}[case]
 
     def solve(env):
         for k, v in env.items():
