@@ -28,7 +28,7 @@ for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
             continue
         if "ffsa::k_" in kn and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = row["Kernel_Name"].split("ffsa::k_")[1].split("<")[0].split("(")[0]
-            k = k.replace("pass_c_pruned", "pass_c").replace("mid_seg_one", "mid").replace("mid_seg_pipe", "mid").replace("mid_seg", "mid")  # bench.py's kernel ids
+            k = k.replace("pass_a3", "pass_a").replace("pass_c3", "pass_c").replace("pass_c_pruned", "pass_c").replace("mid_seg_one", "mid").replace("mid_seg_pipe", "mid").replace("mid_seg", "mid")  # bench.py's kernel ids
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, c in acc.items():
