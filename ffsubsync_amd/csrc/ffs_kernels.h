@@ -512,7 +512,7 @@ FFS_DEV void mirror_load(cf (&v)[16], const cf* lds, const RowAddr<L>& addr, std
 // Slot 0 of each pair is the reference transform; slots 1..n_slots-1 are transformed in place.
 // SEP: L/16 >= C, so element u + LT*q of a row sits at  off0 + q*(LT*N1)  (one 32-bit lane offset
 // plus a wave-uniform stride) instead of needing sixteen independent 64-bit addresses.
-template <int L, bool SEP>
+template <int L, bool SEP, bool PF = false>
 __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
                                                 float inv_n, const cf* __restrict__ tw, const cf* __restrict__ tb,
                                                 const cf* __restrict__ ts, int half_flags) {
@@ -571,12 +571,19 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     } else {
         load_row(rr, base, off0);
     }
-    fft_regs<L>(rr, lds, u, addr, twr);
+    // PF: the first candidate row is requested before the reference row is transformed, every further one before the
+    // two transforms of its predecessor (staging buffer xl, LDS-only barriers: see k_mid_seg_one)
+    cf xl[PF ? 16 : 1];
+    if constexpr (PF) {
+        load_row(xl, base + (size_t)1 * N, off0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    fft_regs<L, RowAddr<L>, PF>(rr, lds, u, addr, twr);
     if constexpr (L == 4096) {
         if (mirrored) {
-            __syncthreads();
+            block_sync<PF>();
             mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
-            __syncthreads();
+            block_sync<PF>();
             mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
         }
     }
@@ -588,11 +595,18 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     for (int s = 1; s < s_end; ++s) {
         cf* buf = base + (size_t)s * N;
         cf v[16];
-        load_row(v, buf, off0);
-        fft_regs<L>(v, lds, u, addr, twr);
+        if constexpr (PF) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = xl[q];
+            if (s + 1 < s_end) load_row(xl, base + (size_t)(s + 1) * N, off0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            load_row(v, buf, off0);
+        }
+        fft_regs<L, RowAddr<L>, PF>(v, lds, u, addr, twr);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], rr[q]);
-        fft_regs<L>(v, lds, u, addr, twr);
+        fft_regs<L, RowAddr<L>, PF>(v, lds, u, addr, twr);
         if constexpr (SEP) {
             char* p = reinterpret_cast<char*>(buf);
             size_t stride = qstride * sizeof(cf);

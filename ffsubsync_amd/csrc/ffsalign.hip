@@ -153,6 +153,7 @@ struct ffs_plan {
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
     cf* tw1h = nullptr;                       // stage tables of the 256-row sub-transforms of a 512-row column
     cf *tbR = nullptr, *tsR = nullptr, *thR = nullptr;  // pass-A twiddles of the three-sub-transforms-per-thread columns (k_pass_a3)
+    bool mid_pf = true;             // FFS_MID_PF=0: k_mid without the load-ahead of the next candidate row (4096-point rows)
     bool col3r = true;              // FFS_COL3R=0: radix-3 columns through LDS (k_pass_a / k_pass_c) instead of k_pass_a3 / k_pass_c3
     cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
     cf* twn1 = nullptr;                       // W_N1^k, k < N1 (pruned pass C)
@@ -379,6 +380,15 @@ bool ref_half_ok(const ffs_plan* p) { return p->allow_ref_half && p->N2 == 4096 
 
 int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStream_t st) {
     const bool sep = (p->N2 / 16) >= (1 << p->log2CL);
+    if (p->N2 == 4096 && sep && p->mid_pf) {  // one row per block: candidate rows requested one item ahead
+        const size_t lds = row_lds_bytes(4096);
+        int rc_lds;
+        if ((rc_lds = ensure_lds(p, (const void*)k_mid<4096, true, true>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_mid<4096, true, true>), dim3(p->N1, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
+                           (long long)p->N, n_slots, (float)(1.0 / (double)p->N), p->tw2, p->tbM, p->tsM, ref_half);
+        HIP_TRY(hipGetLastError());
+        return FFS_OK;
+    }
 #define FFS_MID(L) \
     case L: return sep ? launch_mid_inst<L, true>(p, n_pairs, n_slots, ref_half, st) : launch_mid_inst<L, false>(p, n_pairs, n_slots, ref_half, st)
     switch (p->N2) {
@@ -772,6 +782,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
         const char* e16 = getenv("FFS_MID_SEG_ONE");
         if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
+        const char* e19 = getenv("FFS_MID_PF");
+        if (e19) p->mid_pf = e19[0] == '1';
         const char* e17 = getenv("FFS_COL3R");
         p->col3r = !(e17 && e17[0] == '0');
         const char* e10 = getenv("FFS_MID_SEG_PIPE");

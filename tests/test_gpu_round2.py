@@ -416,7 +416,7 @@ def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, 
     seg_off = {"FFS_DISABLE_SEGMENTED": "1"}  # the windowed case would otherwise run block-segmented (power-of-two columns)
     base = solve(dict(seg_off, FFS_COL3R="0"))
     for env in (dict(seg_off), dict(seg_off, FFS_DISABLE_HALF_LAST="1", FFS_DISABLE_REF_HALF="1"),
-                dict(seg_off, FFS_DISABLE_PRUNED_PASS_C="1")):
+                dict(seg_off, FFS_DISABLE_PRUNED_PASS_C="1"), dict(seg_off, FFS_MID_PF="0")):  # k_mid without load-ahead
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
