@@ -97,6 +97,34 @@ def column_fft(x, dtype=np.complex64):
     return out.astype(dtype)
 
 
+def column_fft_in_thread(x, NS, dtype=np.complex64):
+    """Forward DFT along axis 0 for column lengths L = NS*LI (NS = 2 or 3) as the kernels' colnr_fft does it
+    (k_pass_a3 / k_pass_c3): thread u of LTI = LI/16 holds x[NS*(u + LTI*q) + g] for EVERY g (NS*16 values), runs
+    the NS length-LI sub-transforms one after the other, and finishes in registers
+        X[k' + LI*r] = sum_g W_NS^(g r) W_L^(g k') F_g[k'],   k' = u + LTI*q,
+    with W_L^(g k') = W_L^(g u) * W_(L/LTI)^(g q): one per-thread table value times a compile-time constant
+    (L/LTI = 16*NS: W_48^q and W_24^q for NS = 3, W_32^q for NS = 2), both fp32-rounded."""
+    L = x.shape[0]
+    assert NS in (2, 3) and L % (NS * E) == 0
+    LI = L // NS
+    LTI = LI // E
+    shape1 = (1,) * (x.ndim - 1)
+    F = [stockham_fft(x[g::NS], dtype) for g in range(NS)]  # sub-transform g: x[NS*j + g], j = u + LTI*q
+    out = np.empty(x.shape, dtype)
+    for u in range(LTI):
+        wu = [np.exp(-2j * np.pi * g * u / L).astype(dtype) for g in range(NS)]  # W_L^(g u): tw3[g*u] on the device
+        for q in range(E):
+            kq = [np.exp(-2j * np.pi * g * q / (E * NS)).astype(dtype) for g in range(NS)]  # W_(16 NS)^(g q)
+            k = u + LTI * q
+            t = [F[0][k]] + [(F[g][k] * kq[g]).astype(dtype) * wu[g] for g in range(1, NS)]
+            for r in range(NS):
+                acc = t[0].astype(dtype)
+                for g in range(1, NS):
+                    acc = acc + np.exp(-2j * np.pi * g * r / NS) * t[g]
+                out[k + LI * r] = acc
+    return out.astype(dtype).reshape((L,) + x.shape[1:]) if shape1 else out.astype(dtype)
+
+
 def split_n(N):
     """N = N1 * N2 (N1: column length of pass A/C, N2: row length of the mid pass).  Lengths
     3 * 2^k keep the factor three in N1 (48..768 columns)."""

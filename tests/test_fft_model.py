@@ -22,6 +22,18 @@ def test_radix3_columns_match_numpy(L):
     assert np.abs(got - np.fft.fft(x, axis=0)).max() < 1e-5 * np.sqrt(L)
 
 
+@pytest.mark.parametrize("L,NS", [(192, 3), (384, 3), (768, 3), (512, 2)])
+def test_sub_transforms_in_one_thread_match_numpy(L, NS):
+    """colnr_fft (k_pass_a3 / k_pass_c3): all NS sub-transforms of a column in one thread, last radix step in
+    registers with W_L^(g k') = W_L^(g u) * W_(16 NS)^(g q)."""
+    rng = np.random.RandomState(L + NS)
+    x = rng.randn(L, 2) + 1j * rng.randn(L, 2)
+    got = fm.column_fft_in_thread(x, NS, np.complex128)
+    assert np.abs(got - np.fft.fft(x, axis=0)).max() < 1e-5 * np.sqrt(L)  # the stage tables are fp32-rounded
+    got32 = fm.column_fft_in_thread(x.astype(np.complex64), NS, np.complex64)
+    assert np.abs(got32 - np.fft.fft(x, axis=0)).max() < 2e-5 * np.sqrt(L)
+
+
 @pytest.mark.parametrize("N", [4096, 8192, 1 << 15, 1 << 17, 3 << 12, 3 << 14, 3 << 16])
 def test_pipeline_matches_direct_correlation(N):
     rng = np.random.RandomState(N % 97)
