@@ -147,6 +147,41 @@ FFS_DEV float eff_margin(float cand_margin, float vmax) {
 
 FFS_DEV bool better(float v1, int d1, float v2, int d2) { return v1 > v2 || (v1 == v2 && d1 > d2); }
 
+// Row walks of the mid / last passes: ONE wave-uniform 64-bit row pointer that advances by a wave-uniform stride plus
+// one 32-bit byte offset per lane, i.e. `global_load_dwordx2 v, v_off, s[ptr:ptr+1]` and two scalar adds per row.
+// Left to itself the compiler re-associates the chain into p + q*stride and evaluates it per lane (two v_mad_u64_u32,
+// two moves and a 64-bit vector add per load: 55 of the ~410 VALU instructions of every mid-pass item, plus 30
+// transient address VGPRs).  gstep() makes the advanced pointer opaque, so the chain stays s_add_u32/s_addc_u32; the
+// pointers carry the global address space explicitly because an opaque generic pointer would turn the access into a
+// flat_load (which also counts against lgkmcnt, i.e. against the LDS-only barriers).
+typedef const __attribute__((address_space(1))) char* gcptr;
+typedef __attribute__((address_space(1))) char* gptr;
+FFS_DEV cf gload(gcptr p, unsigned off) { return *(const __attribute__((address_space(1))) cf*)(p + off); }
+FFS_DEV void gstore(gptr p, unsigned off, cf v) { *(__attribute__((address_space(1))) cf*)(p + off) = v; }
+FFS_DEV void gstep(gcptr& p, size_t stride) {
+    p += stride;
+    asm volatile("" : "+s"(p));
+}
+// The sixteen step twiddles W_N^(k1*LT*q) of a row are wave-uniform when a block owns one row: fetched once into
+// scalar registers (s_load + SGPR operands of the packed multiplies) instead of inside the store loop, where every
+// store to the work buffer would force a reload (the stores go through opaque pointers: no restrict information).
+struct RowStepTw {
+    float x[16], y[16];
+    FFS_DEV void load(const cf* __restrict__ ts, int k1) {
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {  // k1 wave-uniform: scalar loads; the "s" operand of cmul_k keeps them in SGPRs
+            const cf t = ts[k1 * 16 + q];
+            x[q] = t.x;
+            y[q] = t.y;
+        }
+    }
+    FFS_DEV cf times(cf wb, int q) const { return q == 0 ? wb : cmul_k(wb, x[q], y[q]); }
+};
+FFS_DEV void gstep(gptr& p, size_t stride) {
+    p += stride;
+    asm volatile("" : "+s"(p));
+}
+
 // Branch-free sample fetch: the load is always issued (index clamped to element 0, so the sixteen
 // loads of a thread are in flight together) and the zero padding is applied by a select.
 template <int DT>
@@ -540,14 +575,14 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     // per-element vector address arithmetic and no hoisted table of sixteen 64-bit offsets (32 VGPRs)
     auto load_row = [&](cf(&x)[16], const cf* buf, unsigned off_elems) {
         if constexpr (SEP) {
-            const char* p = reinterpret_cast<const char*>(buf);
+            gcptr p = (gcptr)buf;
             size_t stride = qstride * sizeof(cf);
             unsigned off = off_elems * (unsigned)sizeof(cf);
             asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                x[q] = *reinterpret_cast<const cf*>(p + off);
-                p += stride;
+                x[q] = gload(p, off);
+                gstep(p, stride);
             }
         } else {
 #pragma unroll
@@ -592,6 +627,9 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
     for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R)/N
 
     const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    constexpr bool ONE_ROW = (L == 4096) && SEP;  // one row per block: k1 is wave-uniform
+    RowStepTw stw;
+    if constexpr (ONE_ROW) stw.load(ts, __builtin_amdgcn_readfirstlane(k1));
     for (int s = 1; s < s_end; ++s) {
         cf* buf = base + (size_t)s * N;
         cf v[16];
@@ -608,16 +646,16 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
         for (int q = 0; q < 16; ++q) v[q] = cmul(v[q], rr[q]);
         fft_regs<L, RowAddr<L>, PF>(v, lds, u, addr, twr);
         if constexpr (SEP) {
-            char* p = reinterpret_cast<char*>(buf);
+            gptr p = (gptr)buf;
             size_t stride = qstride * sizeof(cf);
             unsigned off = off0 * (unsigned)sizeof(cf);
             cf wbl = wb;  // opaque: the sixteen products wb*ts[q] are not hoisted out of the slot loop
             asm volatile("" : "+s"(stride), "+v"(off), "+v"(wbl));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const cf w = (q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-                *reinterpret_cast<cf*>(p + off) = cmul(v[q], w);
-                p += stride;
+                const cf w = ONE_ROW ? stw.times(wbl, q) : ((q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]));  // W_N^(k1*(u + LT*q))
+                gstore(p, off, cmul(v[q], w));
+                gstep(p, stride);
             }
         } else {
 #pragma unroll
@@ -765,6 +803,8 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
     TwRegs<L> twr;
     twr.load(tw, u);
     const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    RowStepTw stw;
+    stw.load(ts, k1);
     for (int s = 1; s < s_end; s += 2) {
         const bool two = s + 1 < s_end;
         cf acc_a[16], acc_b[16], x0[16], x1[16];
@@ -772,13 +812,17 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
         for (int q = 0; q < 16; ++q) acc_a[q] = acc_b[q] = mk(0.f, 0.f);
         auto issue = [&](cf(&x)[16], int k, int slot) {  // slot 0 = the reference row
             // uniform 64-bit row pointer + 32-bit byte offset per lane: the load takes its base from an SGPR pair
-            const char* src = reinterpret_cast<const char*>(base + ((size_t)k * n_slots + slot) * N);
+            gcptr src = (gcptr)(base + ((size_t)k * n_slots + slot) * N);
             unsigned off = slot ? off0b : offrb;
+            size_t stride = qstride * sizeof(cf);
             // opaque: otherwise off + q*stride is hoisted as sixteen loop-invariant 64-bit VGPR offsets (32 registers
             // and a 64-bit add per load); this way the row pointers are scalar adds and the lane offset one VGPR
-            asm volatile("" : "+v"(off));
+            asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
-            for (int q = 0; q < 16; ++q) x[q] = *reinterpret_cast<const cf*>(src + q * qstride * sizeof(cf) + off);
+            for (int q = 0; q < 16; ++q) {
+                x[q] = gload(src, off);
+                gstep(src, stride);
+            }
             __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
         };
         auto consume_ref = [&](cf(&x)[16]) {
@@ -823,18 +867,21 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
             for (int k = 0; k < n_blocks; ++k) block1(x0, x1, k);
         }
         if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_a, lds, u, addr, twr);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            *reinterpret_cast<cf*>(reinterpret_cast<char*>(base + (size_t)s * N + q * qstride) + off0b) = cmul(acc_a[q], w);
-        }
-        if (two) {
-            if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
+        auto put = [&](const cf(&acc)[16], int slot) {
+            gptr dst = (gptr)(base + (size_t)slot * N);
+            size_t stride = qstride * sizeof(cf);
+            unsigned off = off0b;
+            asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
-                *reinterpret_cast<cf*>(reinterpret_cast<char*>(base + (size_t)(s + 1) * N + q * qstride) + off0b) = cmul(acc_b[q], w);
+                gstore(dst, off, cmul(acc[q], stw.times(wb, q)));  // W_N^(k1*(u + LT*q))
+                gstep(dst, stride);
             }
+        };
+        put(acc_a, s);
+        if (two) {
+            if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc_b, lds, u, addr, twr);
+            put(acc_b, s + 1);
         }
     }
 }
@@ -887,14 +934,14 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, i
     // request row (block k, slot) into `dst`: a scalar row pointer that advances by the (opaque) stride + one 32-bit
     // lane offset -- no per-load vector address arithmetic, no table of hoisted 64-bit offsets
     auto request = [&](cf* dst, int k, int slot) {
-        const char* p = reinterpret_cast<const char*>(base + ((size_t)k * n_slots + slot) * N);
+        gcptr p = (gcptr)(base + ((size_t)k * n_slots + slot) * N);
         size_t stride = (size_t)LT * N1 * sizeof(cf);
         unsigned off = slot ? off0b : offrb;
         asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            dst[q] = *reinterpret_cast<const cf*>(p + off);
-            p += stride;
+            dst[q] = gload(p, off);
+            gstep(p, stride);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
     };
@@ -931,19 +978,20 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, i
         }
     }
     cf wbl = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
+    RowStepTw stw;
+    stw.load(ts, k1);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         if (a >= na) break;
         if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc[a], lds, u, addr, twr);
-        char* dst = reinterpret_cast<char*>(base + (size_t)(1 + a) * N);
+        gptr dst = (gptr)(base + (size_t)(1 + a) * N);
         size_t stride = (size_t)LT * N1 * sizeof(cf);
         unsigned off = off0b;
         asm volatile("" : "+s"(stride), "+v"(off), "+v"(wbl));  // opaque: the sixteen products wb*ts[q] are not hoisted
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            *reinterpret_cast<cf*>(dst + off) = cmul(acc[a][q], w);
-            dst += stride;
+            gstore(dst, off, cmul(acc[a][q], stw.times(wbl, q)));  // W_N^(k1*(u + LT*q))
+            gstep(dst, stride);
         }
     }
 }
@@ -1375,11 +1423,11 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restr
         asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
         for (int g = 0; g < NS; ++g) {
-            const char* p = reinterpret_cast<const char*>(in);
+            gcptr p = (gcptr)in;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                v[g][q] = *reinterpret_cast<const cf*>(p + (off + g * row_bytes));
-                p += stride;
+                v[g][q] = gload(p, off + g * row_bytes);
+                gstep(p, stride);
             }
         }
     }
