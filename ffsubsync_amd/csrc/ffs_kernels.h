@@ -1108,6 +1108,12 @@ struct WinParams {
     // the window in output-index space: m passes iff (unsigned)(m - ra[h][i]) <= rw[h][i] for i = 0 or 1
     int ra[2][2];
     unsigned rw[2][2];
+    // the same window as ONE range test for callers whose m is always a valid output index (0 <= m < N): the
+    // window is either one range of m or -- lags on both sides of zero -- everything but one gap in the middle:
+    // m passes iff ((unsigned)(m - g0[h]) <= gw[h]) != ginv[h]
+    int g0[2];
+    unsigned gw[2];
+    int ginv[2];
 };
 
 // lag of output index m: circular (lags 0..d_hi at m = d, negative ones at m = d + N) or, in
@@ -1120,6 +1126,14 @@ FFS_DEV int lag_of(const WinParams& wp, int h, int m, int nN) {
 // Is output index m (>= 0; -1 = "no value") inside half h's lag window?  Two unsigned range tests.
 FFS_DEV bool in_window(const WinParams& wp, int h, int m) {
     return (unsigned)(m - wp.ra[h][0]) <= wp.rw[h][0] || (unsigned)(m - wp.ra[h][1]) <= wp.rw[h][1];
+}
+// ALLM: every m the caller passes is a valid output index -- one range test (two instructions per value)
+template <bool ALLM>
+FFS_DEV bool in_window_t(const WinParams& wp, int h, int m) {
+    if constexpr (ALLM)
+        return ((unsigned)(m - wp.g0[h]) <= wp.gw[h]) != (wp.ginv[h] != 0);
+    else
+        return in_window(wp, h, m);
 }
 
 FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int kp, int n_cand, int nN, int seg_shift = 0,
@@ -1138,11 +1152,29 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
         const int lo = w.lo[h], hi = w.hi[h];
         w.ra[h][0] = w.ra[h][1] = NEVER;
         w.rw[h][0] = w.rw[h][1] = 0u;
+        w.g0[h] = NEVER;
+        w.gw[h] = 0u;
+        w.ginv[h] = 0;
         if (hi >= lo) {
             if (seg) {  // m = d - shift
                 w.ra[h][0] = lo - seg_shift;
                 w.rw[h][0] = (unsigned)(hi - lo);
+                w.g0[h] = lo - seg_shift;
+                w.gw[h] = (unsigned)(hi - lo);
             } else {
+                if (lo >= 0) {  // one range at m = d
+                    w.g0[h] = lo;
+                    w.gw[h] = (unsigned)(hi - lo);
+                } else if (hi < 0) {  // one range at m = d + N
+                    w.g0[h] = nN + lo;
+                    w.gw[h] = (unsigned)(hi - lo);
+                } else {  // m in [0, hi] or [N + lo, N - 1]: everything but the gap hi + 1 .. N + lo - 1
+                    w.ginv[h] = 1;
+                    if (nN + lo - 1 >= hi + 1) {
+                        w.g0[h] = hi + 1;
+                        w.gw[h] = (unsigned)(nN + lo - hi - 2);
+                    }
+                }
                 if (hi >= 0) {  // lags 0..hi sit at m = d
                     const int a = lo > 0 ? lo : 0;
                     w.ra[h][0] = a;
@@ -1166,19 +1198,20 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
 template <int NV, int NW, class MOf>
 FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, unsigned char* smem, int tid,
                             BlockNom* __restrict__ out_a, BlockNom* __restrict__ out_b) {
+    // callers with a whole column per thread (NV >= 16) only ever pass valid output indices
+    constexpr bool ALLM = NV >= 16;
     float bv[2] = {-INFINITY, -INFINITY};
-    unsigned okmask[(NV + 15) / 16] = {};  // one validity bit per value and half, sixteen values per word
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const int m = m_of(q);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const bool ok = in_window(wp, h, m);
-            okmask[q / 16] |= (ok ? 1u : 0u) << (2 * (q % 16) + h);
+            const bool ok = in_window_t<ALLM>(wp, h, m);
             const float val = h ? v[q].y : v[q].x;
             bv[h] = fmaxf(bv[h], ok ? val : -INFINITY);
         }
     }
+    const float tmax[2] = {bv[0], bv[1]};  // this thread's own in-window maxima
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -1206,14 +1239,21 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const float thr = s_bmax[h] - eff_margin(wp.marg[h], s_bmax[h]);
+        // A thread holds a nominee iff its own maximum reaches the threshold, so nearly every wave skips the NV
+        // per-value tests (each one a divergent branch around an LDS atomic) in one step; the window test is simply
+        // repeated for the few threads that get here (keeping NV validity bits alive across the barriers cost more:
+        // the compiler held them as 2*NV lane masks in scalar registers and spilled those).
+        if (!(tmax[h] >= thr)) continue;
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const float val = h ? v[q].y : v[q].x;
-            if (((okmask[q / 16] >> (2 * (q % 16) + h)) & 1u) && val >= thr) {
+            int m = m_of(q);
+            asm volatile("" : "+v"(m));  // opaque: a fresh test here, not the first loop's results kept alive
+            if (val >= thr && in_window_t<ALLM>(wp, h, m)) {
                 const int slot = atomicAdd(&s_cnt[h], 1);
                 if (slot < KBLK) {
                     s_lval[h * KBLK + slot] = val;
-                    s_ld[h * KBLK + slot] = lag_of(wp, h, m_of(q), nN);
+                    s_ld[h * KBLK + slot] = lag_of(wp, h, m, nN);
                 }
             }
         }
@@ -1495,31 +1535,31 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
         const int rows_full = (lead == 0 && len >= col_end) ? (len - col_end) / N2 + 1 : 0;
         const int rows_any = (len > col0) ? (len - col0 + N2 - 1) / N2 : 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r0 = NS * LTI * q;
-            if (r0 >= rows_any) {
+        for (int g = 0; g < NS; ++g) {
+            // the sixteen window words of sub-transform g are requested back to back and pinned: left alone, the
+            // compiler sinks every read into the block-uniform branches below and waits for each one separately
+            // (one exposed LDS round trip per sample: 64-96 per thread)
+            unsigned w[16];
 #pragma unroll
-                for (int g = 0; g < NS; ++g) {
-                    if (h)
-                        v[g][q].y = 0.0f;
-                    else
-                        v[g][q].x = 0.0f;
-                }
-            } else {
-                const bool test = r0 + NS * LTI > rows_full;
+            for (int q = 0; q < 16; ++q) w[q] = win[(NS * LTI * q + g) * CW];
 #pragma unroll
-                for (int g = 0; g < NS; ++g) {
-                    const unsigned b = (unsigned)__builtin_amdgcn_sbfe((int)win[(NS * LTI * q + g) * CW], sh, 1u);  // 0 or ~0
-                    float x = pick_level<true>(b, v0, v1);
-                    if (test) {
+            for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(w[q]));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r0 = NS * LTI * q;
+                float x = 0.0f;
+                if (r0 < rows_any) {
+                    const unsigned b = (unsigned)__builtin_amdgcn_sbfe((int)w[q], sh, 1u);  // 0 or ~0
+                    x = pick_level<true>(b, v0, v1);
+                    if (r0 + NS * LTI > rows_full) {
                         const int n = (NS * (u + LTI * q) + g) * N2 + n2;
                         x = (n >= lead && n < len) ? x : 0.0f;
                     }
-                    if (h)
-                        v[g][q].y = x;
-                    else
-                        v[g][q].x = x;
                 }
+                if (h)
+                    v[g][q].y = x;
+                else
+                    v[g][q].x = x;
             }
         }
     }
