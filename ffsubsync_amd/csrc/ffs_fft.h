@@ -193,10 +193,14 @@ struct Shape {
 // Per-thread twiddle registers of one twiddled stage.  For a fixed thread the butterfly indices
 // j = u + LT*b never change, so the values are loaded once, up front, and reused by every
 // transform the thread takes part in.
-template <int L, int R, int NS>
+// SC: the caller's u is wave-uniform (column tiles of 64+ columns: a wave is one row phase), so the values are the
+// same for the whole wave -- scalar loads into SGPRs, used as the scalar operand of the packed multiplies (no vector
+// loads, no VGPRs; only for stages of radix < 16).
+template <int L, int R, int NS, bool SC = false>
 struct StageTw {
     static constexpr int NB = 16 / R;
     static constexpr int COUNT = (R == 16) ? 6 : (R > 1 ? (R - 1) * NB : 1);
+    static_assert(!SC || R < 16, "scalar stage twiddles: radix < 16 only");
     cf w[COUNT];
     FFS_DEV void load(const cf* __restrict__ tab, int u) {
         constexpr int LT = L / 16;
@@ -212,11 +216,11 @@ struct StageTw {
     }
 };
 
-template <int L>
+template <int L, bool SC = false>
 struct TwRegs {
     typedef Shape<L> S;
-    StageTw<L, S::R1, 16> s1;
-    StageTw<L, S::R2, 256> s2;
+    StageTw<L, S::R1, 16, SC> s1;
+    StageTw<L, S::R2, 256, SC> s2;
     FFS_DEV void load(const cf* __restrict__ tw, int u) {
         if constexpr (S::R1 > 1) s1.load(tw + S::TW1, u);
         if constexpr (S::R2 > 1) s2.load(tw + S::TW2, u);
@@ -256,8 +260,8 @@ FFS_DEV void bfly16_twiddled(cf* t, const cf* w /* w1 w2 w3 w4 w8 w12 */) {
 
 // One Stockham stage on registers: NB = 16/R butterflies per thread; butterfly b works on
 // register slots b + r*NB and has butterfly index j = u + (L/16)*b.
-template <int L, int R, int NS>
-FFS_DEV void stage_compute(cf (&v)[16], const StageTw<L, R, NS>& tw) {
+template <int L, int R, int NS, bool SC>
+FFS_DEV void stage_compute(cf (&v)[16], const StageTw<L, R, NS, SC>& tw) {
     constexpr int NB = 16 / R;
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -268,7 +272,10 @@ FFS_DEV void stage_compute(cf (&v)[16], const StageTw<L, R, NS>& tw) {
             bfly16_twiddled(t, tw.w);
         } else {
 #pragma unroll
-            for (int r = 1; r < R; ++r) t[r] = cmul(t[r], tw.w[b * (R - 1) + (r - 1)]);
+            for (int r = 1; r < R; ++r) {
+                const cf w = tw.w[b * (R - 1) + (r - 1)];
+                t[r] = SC ? cmul_k(t[r], w.x, w.y) : cmul(t[r], w);
+            }
             Bfly<R>::run(t);
         }
 #pragma unroll
@@ -403,8 +410,8 @@ FFS_DEV void block_sync() {
 // In: v[q] = x[u + LT*q].  Out: v[q] = X[u + LT*q].  All threads of the block must call it
 // (it contains __syncthreads()).  tw = this thread's preloaded stage twiddles.
 // LB: barriers wait for LDS traffic only (lds_barrier), so global loads issued before the call stay in flight.
-template <int L, class Addr, bool LB = false>
-FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& tw) {
+template <int L, class Addr, bool LB = false, bool SC = false>
+FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L, SC>& tw) {
     typedef Shape<L> S;
     auto barrier = [] { block_sync<LB>(); };
     addr.refresh();
@@ -414,13 +421,13 @@ FFS_DEV void fft_regs(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& 
         stage_scatter<L, 16, 1>(v, lds, u, addr);
         barrier();
         stage_gather<L>(v, lds, u, addr);
-        stage_compute<L, S::R1, 16>(v, tw.s1);
+        stage_compute<L, S::R1, 16, SC>(v, tw.s1);
         if constexpr (S::R2 > 1) {
             barrier();
             stage_scatter<L, S::R1, 16>(v, lds, u, addr);
             barrier();
             stage_gather<L>(v, lds, u, addr);
-            stage_compute<L, S::R2, 256>(v, tw.s2);
+            stage_compute<L, S::R2, 256, SC>(v, tw.s2);
         }
     }
 }
@@ -475,14 +482,15 @@ FFS_DEV cf radix3_out(cf a, cf b, cf cc, float alpha, float beta) {
 // Forward DFT of one column of a C-column tile.  In: v[q] = x[u12 + LT*q].  Out: v[q] =
 // X[out_base(u12) + OSTEP*q].  tw3 = W_L^k (k < L) in LDS, outside the L*C elements at `lds`; used only
 // for L = 3*LI.
-template <int L, int C, bool LB = false>
-FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI>& twr,
+template <int L, int C, bool LB = false, bool SC = false>
+FFS_DEV void col_fft(cf (&v)[16], cf* lds, int u12, int c, const TwRegs<ColShape<L>::LI, SC>& twr,
                      const cf* __restrict__ tw3) {
     typedef ColShape<L> CS;
     if constexpr (!CS::R3) {
         ColAddr<L, C> addr(u12, c);
-        fft_regs<L, ColAddr<L, C>, LB>(v, lds, u12, addr, twr);
+        fft_regs<L, ColAddr<L, C>, LB, SC>(v, lds, u12, addr, twr);
     } else {
+        static_assert(!SC, "scalar stage twiddles: power-of-two columns only");
         constexpr int LI = CS::LI, LTI = CS::LTI;
         const int u = u12 / 3, g = u12 % 3;
         col_fft3_front<L, C, LB>(v, lds, u12, c, twr, tw3);

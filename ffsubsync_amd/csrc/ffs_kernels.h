@@ -300,8 +300,10 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     const int n2 = tile * C + c;
     const XformDesc d = descs[blockIdx.y];
     // every table value this thread needs is requested up front, together with the inputs
-    TwRegs<CS::LI> twr;
-    twr.load(tw, CS::R3 ? u / 3 : u);
+    // (tiles of 64+ columns: u is the wave's row phase, the stage twiddles are wave-uniform -> scalar registers)
+    constexpr bool TWS = (C % 64 == 0) && !CS::R3 && (LT > 1) && (LT < 16);
+    TwRegs<CS::LI, TWS> twr;
+    twr.load(tw, TWS ? __builtin_amdgcn_readfirstlane(u) : (CS::R3 ? u / 3 : u));
     cf* s_tw3 = lds + L * C;  // block copy of W_L^k for the radix-3 combine (behind the column tile)
     if constexpr (CS::R3) {
         for (int i = threadIdx.x; i < L; i += LT * C) s_tw3[i] = tw3[i];
@@ -376,7 +378,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         const int col0 = tile * C;
         for (int i = threadIdx.x; i < 2 * L * CW; i += LT * C) {
             const int h = i / (L * CW), row = (i / CW) % L, j = i % CW;
-            const unsigned* src = reinterpret_cast<const unsigned*>(h ? d.b : d.a);
+            // (descriptor pointers are generic: say "global" so the loads are global_load, not flat_load)
+            const auto* src = (const __attribute__((address_space(1))) unsigned*)(h ? d.b : d.a);
             const int off = h ? d.off_b : d.off_a, len = h ? d.len_b : d.len_a, lead = h ? d.lead_b : d.lead_a;
             const int bit0 = off + row * N2 + col0 + 32 * j;  // first bit of this dword of the window
             const int w = bit0 >> 5;                          // arithmetic shift: floor
@@ -467,7 +470,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         }
         return;
     }
-    col_fft<L, C>(v, lds, u, c, twr, s_tw3);
+    col_fft<L, C, false, TWS>(v, lds, u, c, twr, s_tw3);
     // v[q] = Y[k1 = u + LT*q][n2];  twiddle W_N^(n2*k1) = h_q = wq[0] * g^q, built as h_(q-b) * g^b
     const int ob = CS::out_base(u);
     wq[3] = cmul(wq[0], wq[1]);   // h_1
@@ -1509,7 +1512,7 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
     const int col0 = tile * C;
     for (int i = threadIdx.x; i < 2 * L * CW; i += NT) {
         const int h = i / (L * CW), row = (i / CW) % L, j = i % CW;
-        const unsigned* src = reinterpret_cast<const unsigned*>(h ? d.b : d.a);
+        const auto* src = (const __attribute__((address_space(1))) unsigned*)(h ? d.b : d.a);
         const int off = h ? d.off_b : d.off_a, len = h ? d.len_b : d.len_a, lead = h ? d.lead_b : d.lead_a;
         const int bit0 = off + row * N2 + col0 + 32 * j;
         const int w = bit0 >> 5;
