@@ -1,9 +1,13 @@
+"""Concurrent sub-batches on several HIP streams (one plan per stream, the batch split between them): solves/s.
+
+    python profiles/overlap_experiment.py [pairs=1024] [STREAMSxPAIRS_IN_FLIGHT ...]
+"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
 from ffsubsync_amd import batch, _native
 from workloads import synth
-P = 1024
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 specs = [synth.make_pair_spec(i) for i in range(P)]
 db = synth.build_device_batch(specs)
 n = db.required_fft_length(6000)
@@ -23,5 +27,6 @@ def run(nstreams, pif, steps=4):
     dt = time.perf_counter() - t0
     for a in als: a.plan.close()
     return P*steps/dt
-for ns, pif in [(1,64),(2,32),(2,64),(4,16),(4,32)]:
-    print(ns, pif, round(run(ns,pif)))
+CASES = [(1,64),(2,32),(2,64),(4,16),(4,32)] if len(sys.argv) <= 2 else [tuple(int(x) for x in a.split('x')) for a in sys.argv[2:]]
+for ns, pif in CASES:  # streams x pairs-in-flight, e.g. 1x512 2x256 2x512
+    print(ns, pif, round(run(ns,pif)), flush=True)
