@@ -33,6 +33,10 @@ constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
 constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD (default; FFS_MID_SEG_PAIRMAP=0 turns it off)
 constexpr int DBG_NO_FFT = 256, DBG_HOT_MEM = 512;  // section experiments of the mid pass (FFS_MID_DEBUG=1 / 2 / 3)
+// section experiments of pass A (FFS_PASS_A_DEBUG bit mask; WRONG RESULTS, timing only): no stores / no input loads /
+// unit twiddles instead of the table loads / every block stores into tile 0 of slot 0 (writes stay in L2)
+constexpr int DBG_PA_NO_STORE = 1024, DBG_PA_NO_INPUT = 2048, DBG_PA_NO_TW = 4096, DBG_PA_HOT_STORE = 8192;
+constexpr int DBG_PA_HOT_INPUT = 16384;  // every block reads transform 0's vectors (input reads become L2 hits)
 constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (default; FFS_PASS_A_STORE8=0 turns it off)
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
@@ -254,6 +258,34 @@ FFS_DEV size_t tile_base(int tile, int c, int log2CL) {
     return (((size_t)(x >> log2CL) * L) << log2CL) + (size_t)(x & ((1 << log2CL) - 1));
 }
 
+// Prefetch block of pass A, bit-packed inputs.  Pass A is a write stream (26 MB per pair) with 0.7 MB of input reads
+// sprinkled over it, and those few reads cost a quarter of its time: section experiments (FFS_PASS_A_DEBUG) give 6.15
+// us/pair as is, 4.37 without the input loads and 4.55 when every block reads the same, L2-resident vectors -- the
+// reads are slow, and slow the writes down, only when they go to HBM one line at a time in the middle of the write
+// traffic.  So the lines of the transform a few grid rows further down are fetched in ONE burst per XCD: the last
+// eight workgroups of a grid row (gridDim.x = nt + 8 = 0 mod 8, so workgroup x runs on XCD x % 8, which also runs
+// the tiles (x % 8) * nt/8 ...) each touch the lines under their XCD's `ncols` columns, all L rows of both vectors;
+// the consumers find them in their L2 a few microseconds later (6.1 -> 5.0 us/pair at twelve rows ahead).
+FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int xcd, int L, int N2, int ncols, int nthreads) {
+    if (y >= (int)gridDim.y) return;
+    const XformDesc dn = descs[y];
+    const int colA = xcd * ncols;
+    unsigned acc = 0;
+    for (int t = threadIdx.x; t < 2 * L; t += nthreads) {
+        const int h = t / L, row = t % L;
+        const auto* src = (const __attribute__((address_space(1))) unsigned*)(h ? dn.b : dn.a);
+        const int off = h ? dn.off_b : dn.off_a, len = h ? dn.len_b : dn.len_a, lead = h ? dn.lead_b : dn.lead_a;
+        if (len <= lead) continue;
+        // bits [b0, b1] of this row under the XCD's columns, clipped to the vector (ncols = 512 bits: at most two lines)
+        int b0 = off + row * N2 + colA, b1 = b0 + ncols - 1;
+        b0 = b0 > off + lead ? b0 : off + lead;
+        b1 = b1 < off + len - 1 ? b1 : off + len - 1;
+        if (b0 > b1) continue;
+        acc |= src[b0 >> 5] | src[b1 >> 5];
+    }
+    asm volatile("" ::"v"(acc));  // keeps the loads alive
+}
+
 // --------------------------------------------------------------------------------------------
 // pass A.  grid = (N2/C column tiles [+ N2/128 prefetch blocks for byte inputs], n_transforms);
 // block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
@@ -291,6 +323,10 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         if (acc == 0xdeadbeefu && pf_sink) *pf_sink = acc;  // keeps the loads alive (pf_sink is scratch)
         return;
     }
+    if (DT == 2 && blockIdx.x >= (unsigned)nt) {
+        prefetch_bit_inputs(descs, (int)blockIdx.y + pf_ahead, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, LT * C);
+        return;
+    }
     const int c = threadIdx.x % C;
     const int u = threadIdx.x / C;
     // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), and the input
@@ -298,7 +334,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // tiles instead of every eighth one -- otherwise each input line is fetched by up to 8 L2s.
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int n2 = tile * C + c;
-    const XformDesc d = descs[blockIdx.y];
+    const XformDesc d = descs[(half_flags & DBG_PA_HOT_INPUT) ? 0 : blockIdx.y];
     // every table value this thread needs is requested up front, together with the inputs
     // (tiles of 64+ columns: u is the wave's row phase, the stage twiddles are wave-uniform -> scalar registers)
     constexpr bool TWS = (C % 64 == 0) && !CS::R3 && (LT > 1) && (LT < 16);
@@ -315,11 +351,15 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // each, which trades eleven table loads per thread for eleven packed complex multiplies.
     cf wq[16];
     if constexpr (!CS::R3) {
-        wq[0] = tb[u * N2 + n2];
-        wq[1] = ts[1 * N2 + n2];
-        wq[2] = ts[2 * N2 + n2];
-        wq[4] = ts[4 * N2 + n2];
-        wq[8] = ts[8 * N2 + n2];
+        if (half_flags & DBG_PA_NO_TW) {
+            wq[0] = wq[1] = wq[2] = wq[4] = wq[8] = mk(1.0f, 0.0f);
+        } else {
+            wq[0] = tb[u * N2 + n2];
+            wq[1] = ts[1 * N2 + n2];
+            wq[2] = ts[2 * N2 + n2];
+            wq[4] = ts[4 * N2 + n2];
+            wq[8] = ts[8 * N2 + n2];
+        }
     }
     cf v[16];
     if constexpr (DT == 0 && (C == 16 || C == 32 || C == 64)) {
@@ -368,6 +408,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
     } else if constexpr (DT == 2) {
+      {
         // Bit-packed inputs: the tile's L rows x C columns are L windows of C bits per vector, at arbitrary
         // bit offsets.  The block first builds the ALIGNED windows in LDS -- one thread per 32 window bits:
         // two dword loads and a funnel shift (v_alignbit) -- so that bit c of a row's window is column c;
@@ -386,7 +427,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             // only dwords that hold a valid sample (bits off+lead .. off+len-1) are touched
             const int w_lo = (off + lead) >> 5, w_hi = (off + len - 1) >> 5;
             unsigned d0 = 0, d1 = 0;
-            if (len > lead) {
+            if (len > lead && !(half_flags & DBG_PA_NO_INPUT)) {
                 if (w >= w_lo && w <= w_hi) d0 = src[w];
                 if (w + 1 >= w_lo && w + 1 <= w_hi) d1 = src[w + 1];
             }
@@ -407,6 +448,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         map_bytes<LT, true>(bb, d.b0, d.b1, d.len_b, u * N2 + n2, N2, tile * C + C, d.lead_b, xb);
 #pragma unroll
         for (int q = 0; q < 16; ++q) v[q] = mk(xa[q], xb[q]);
+      }
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -418,6 +460,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+    if (half_flags & DBG_PA_HOT_STORE) out = work;
     // HALF_REF: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
     // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all.
     // HALF_LAST: with an odd candidate count the last packed transform carries ONE real candidate; its
@@ -496,10 +539,15 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         // one add per store; the row guard only exists for the two half slots (block-uniform choice)
         // (byte offsets in 32-bit arithmetic -- 2^27 at most -- so that the stores can use the scalar base +
         // 32-bit lane offset addressing mode instead of 64-bit address pairs)
-        const unsigned o0 = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)ob << log2CL)) * (unsigned)sizeof(cf);
+        const unsigned o0 = ((unsigned)tile_base<L, C>((half_flags & DBG_PA_HOT_STORE) ? 0 : tile, c, log2CL) +
+                             ((unsigned)ob << log2CL)) * (unsigned)sizeof(cf);
         const unsigned ostep = ((unsigned)CS::OSTEP << log2CL) * (unsigned)sizeof(cf);
         char* outb = reinterpret_cast<char*>(out);
-        if (k1_end == L) {
+        if (half_flags & DBG_PA_NO_STORE) {
+            // keep the values alive without memory traffic
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(v[q]));
+        } else if (k1_end == L) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) *reinterpret_cast<cf*>(outb + (o0 + ostep * q)) = v[q];
         } else {
@@ -1497,6 +1545,10 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
     static_assert(NT == 256, "256 threads per block");
+    if (blockIdx.x >= (unsigned)nt) {  // input prefetch block (see prefetch_bit_inputs); distance in bits 16..23 of half_flags
+        prefetch_bit_inputs(descs, (int)blockIdx.y + ((half_flags >> 16) & 255), (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
+        return;
+    }
     const int c = threadIdx.x % C, u = threadIdx.x / C;
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;  // see k_pass_a
     const int n2 = tile * C + c;

@@ -136,13 +136,15 @@ struct ffs_plan {
     int N1 = 0, N2 = 0, C = 0, log2C = 0;
     int log2CL = 0;  // tile layout T[x/CL][k1][x%CL]: CL = max(C, 64) columns (512-byte row chunks)
     int pairs_in_flight = 0, max_cand = 0, max_slots = 0;
-    int pass_a_prefetch = 3;  // grid rows the input prefetch blocks of pass A run ahead (FFS_PASS_A_PREFETCH, 0 = off)
+    int pass_a_prefetch = 3;  // grid rows the input prefetch blocks of pass A run ahead, byte inputs (FFS_PASS_A_PREFETCH, 0 = off)
+    int pass_a_prefetch_bits = 12;  // the same for bit-packed inputs, in rows of a 2^18-point transform (scaled by length)
     bool direct_only = false;
     bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
     bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
     bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
+    int pass_a_debug = 0;           // FFS_PASS_A_DEBUG: DBG_PA_* bit mask >> 10 (WRONG RESULTS: timing only)
     int mid_debug = 0;              // FFS_MID_DEBUG: 1 = no row transforms, 2 = L2-resident traffic, 3 = both (WRONG RESULTS: timing only)
     int mid_seg_one = 1;            // FFS_MID_SEG_ONE=0|1|2: k_mid_seg_one (single sweep, four accumulator rows; 2 = no load-ahead, 0 = off)
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
@@ -273,6 +275,14 @@ struct ProfSpan {
 };
 
 // ---- kernel dispatch -------------------------------------------------------------------------
+// Bit-packed inputs: how many grid rows (transforms) the prefetch blocks of pass A run ahead -- about the time of
+// twelve 2^18-point transforms (measured plateau: 9-14), at least one row, 0 = off.
+int bit_prefetch_rows(const ffs_plan* p) {
+    if (p->pass_a_prefetch_bits <= 0) return 0;
+    const long long rows = ((long long)p->pass_a_prefetch_bits << 18) / (long long)p->N;
+    return (int)(rows < 1 ? 1 : (rows > 255 ? 255 : rows));
+}
+
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
                        int ref_half, hipStream_t st) {
@@ -282,11 +292,14 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     const int nt = p->N2 / C;
     // byte inputs: one prefetch block per 128-column line group and grid row (see the kernel)
     const int groups = p->N2 / 128;
-    const int pf = (DT == 0 && p->pass_a_prefetch > 0 && nt % 8 == 0 && groups % 8 == 0) ? groups : 0;
+    // bit-packed inputs: eight prefetch blocks per grid row, one per XCD (see the kernel)
+    const int ahead = DT == 2 ? bit_prefetch_rows(p) : p->pass_a_prefetch;
+    const int pf = (DT == 0 && ahead > 0 && nt % 8 == 0 && groups % 8 == 0) ? groups
+                   : (DT == 2 && ahead > 0 && nt % 8 == 0) ? 8 : 0;
     dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, p->pass_a_prefetch,
-                       (unsigned*)p->bnom, ref_half | (p->pass_a_store8 ? STORE_8B : 0));
+                       p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ahead,
+                       (unsigned*)p->bnom, ref_half | (p->pass_a_store8 ? STORE_8B : 0) | p->pass_a_debug);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -302,9 +315,10 @@ int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int
     int rc_lds;
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C>, lds))) return rc_lds;
     const int nt = p->N2 / C;
-    hipLaunchKernelGGL((k_pass_a3<NS, LI, C>), dim3(nt, n_xf), dim3(256), lds, st, descs, p->work, p->N2, (long long)p->N,
-                       NS == 2 ? p->tw1h : p->tw1,
-                       p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ref_half);
+    const int ahead = nt % 8 == 0 ? bit_prefetch_rows(p) : 0;  // eight prefetch blocks per grid row, one per XCD
+    hipLaunchKernelGGL((k_pass_a3<NS, LI, C>), dim3(nt + (ahead ? 8 : 0), n_xf), dim3(256), lds, st, descs, p->work, p->N2,
+                       (long long)p->N, NS == 2 ? p->tw1h : p->tw1,
+                       p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ref_half | (ahead << 16));
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -778,6 +792,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->pass_a_store8 = !(e9 && e9[0] == '0');
         const char* e12 = getenv("FFS_MID_SEG_PAIRMAP");
         p->mid_seg_pairmap = !(e12 && e12[0] == '0');
+        const char* e20 = getenv("FFS_PASS_A_DEBUG");
+        if (e20) p->pass_a_debug = (atoi(e20) & 31) << 10;
         const char* e15 = getenv("FFS_MID_DEBUG");
         if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
         const char* e16 = getenv("FFS_MID_SEG_ONE");
@@ -793,7 +809,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
         p->allow_half_last = !(e7 && e7[0] == '1');
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
-        if (e3) p->pass_a_prefetch = atoi(e3);
+        if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
         const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
         p->allow_packed_ref = (e2 && e2[0] == '1');
     }

@@ -425,3 +425,4 @@ def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, 
     for i, sp in enumerate(specs):  # and they are the right answers
         assert int(base[1][i]["best_cand"]) == sp.true_ratio_index
         assert abs(int(base[1][i]["offset"]) - sp.true_offset_samples) <= 30
+
