@@ -32,6 +32,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
 constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD (default; FFS_MID_SEG_PAIRMAP=0 turns it off)
+constexpr int DBG_NO_STORE = 32768;  // FFS_MID_DEBUG=4: the mid pass keeps its results (read-only kernel)
 constexpr int DBG_NO_FFT = 256, DBG_HOT_MEM = 512;  // section experiments of the mid pass (FFS_MID_DEBUG=1 / 2 / 3)
 // section experiments of pass A (FFS_PASS_A_DEBUG bit mask; WRONG RESULTS, timing only): no stores / no input loads /
 // unit twiddles instead of the table loads / every block stores into tile 0 of slot 0 (writes stay in L2)
@@ -1035,6 +1036,11 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, i
     for (int a = 0; a < NA; ++a) {
         if (a >= na) break;
         if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc[a], lds, u, addr, twr);
+        if (half_flags & DBG_NO_STORE) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(acc[a][q]));
+            continue;
+        }
         gptr dst = (gptr)(base + (size_t)(1 + a) * N);
         size_t stride = (size_t)LT * N1 * sizeof(cf);
         unsigned off = off0b;

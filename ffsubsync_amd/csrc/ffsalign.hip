@@ -145,7 +145,7 @@ struct ffs_plan {
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
     int pass_a_debug = 0;           // FFS_PASS_A_DEBUG: DBG_PA_* bit mask >> 10 (WRONG RESULTS: timing only)
-    int mid_debug = 0;              // FFS_MID_DEBUG: 1 = no row transforms, 2 = L2-resident traffic, 3 = both (WRONG RESULTS: timing only)
+    int mid_debug = 0;              // FFS_MID_DEBUG bits: 1 = no row transforms, 2 = L2-resident traffic, 4 = no stores (WRONG RESULTS: timing only)
     int mid_seg_one = 1;            // FFS_MID_SEG_ONE=0|1|2: k_mid_seg_one (single sweep, four accumulator rows; 2 = no load-ahead, 0 = off)
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
     bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
@@ -795,7 +795,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         const char* e20 = getenv("FFS_PASS_A_DEBUG");
         if (e20) p->pass_a_debug = (atoi(e20) & 31) << 10;
         const char* e15 = getenv("FFS_MID_DEBUG");
-        if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0);
+        if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0) | ((atoi(e15) & 4) ? DBG_NO_STORE : 0);
         const char* e16 = getenv("FFS_MID_SEG_ONE");
         if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
         const char* e19 = getenv("FFS_MID_PF");
