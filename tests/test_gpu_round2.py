@@ -426,3 +426,25 @@ def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, 
         assert int(base[1][i]["best_cand"]) == sp.true_ratio_index
         assert abs(int(base[1][i]["offset"]) - sp.true_offset_samples) <= 30
 
+
+
+def test_pass_a_prefetch_blocks_change_nothing_but_time(torch, monkeypatch):
+    """The input prefetch blocks of pass A (eight extra workgroups per grid row that touch the bit-packed vectors of a
+    transform a few rows ahead) only warm L2: records with and without them are identical, window or not."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(2200 + i, duration_s=d) for i, d in enumerate((7200.0, 6999.7, 3611.3))]
+    db = synth.build_device_batch(specs)
+    for max_offset in (6000, None):
+        out = []
+        for pf in ("0", "12", "200"):
+            monkeypatch.setenv("FFS_PASS_A_PREFETCH", pf)
+            al = batch.BatchAligner(db.required_fft_length(max_offset), 7, max_offset, pairs_in_flight=2)
+            out.append(al.solve(db))
+            al.plan.close()
+        monkeypatch.delenv("FFS_PASS_A_PREFETCH")
+        for got in out[1:]:
+            for f in ("score", "offset", "flags", "score_f32"):
+                assert np.array_equal(out[0][0][f], got[0][f]), (max_offset, f)
+            assert np.array_equal(out[0][1], got[1])
