@@ -2389,6 +2389,128 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
     }
 }
 
+// The same smoothing as a parallel kernel: one workgroup per chunk, every step a scan.  What makes that possible: the
+// state of the tokenizer (SILENCE / NOISE / POSSIBLE_SILENCE and its silence counter) depends on the validity runs
+// alone, never on token lengths -- truncation at max_len only cuts the frames of an "island" into pieces:
+//   * an island starts at a valid frame that follows more than max_sil invalid ones (or none valid at all) and runs
+//     until max_sil frames past its last valid frame (to the end of the chunk if no longer gap follows);
+//   * inside an island a token is cut every max_len frames; full pieces are always delivered (max_len >= min_len, the
+//     host falls back to k_vad_tokenize otherwise), the remainder of r frames iff max_sil < r (gap) or r > trailing
+//     silence (end of chunk) and (r >= min_len or "contiguous": it follows a cut, or -- first piece -- the previous
+//     island ended with a cut followed by at most max_sil frames, which leaves the tokenizer's flag set);
+//   * markers: +1 at the first frame of a delivered piece, non_speech - 1 behind its last (the +1 wins where both
+//     fall on one frame, as the reference's in-order assignments do), then clip(cumsum, 0, 1).
+// Scans: last valid index (forward max), island start (forward), first frame outside any island (backward min),
+// marker prefix sum (fp64).  oracle/vad_oracle.py::tokenize_chunk_scan is the numpy model of exactly this, tested
+// against the state machine on the CPU.  Chunks of up to TOK_SCAN_MAX frames (16-bit indices in LDS).
+constexpr int TOK_SCAN_MAX = 20480;
+struct TokView {
+    const short* lastv;  // last valid index <= i, -1 if none
+    const short* isl;    // start of the island frame i belongs to, -1 if outside
+    const short* nxt;    // first index > i outside every island (n if none)
+    int n, min_len, max_len, max_sil;
+    FFS_DEV bool c_in(int s) const {
+        if (max_sil <= 0 || s == 0) return false;
+        const int lp = lastv[s - 1];
+        if (lp < 0) return false;
+        const int lenp = lp + max_sil - isl[lp] + 1;
+        return lenp / max_len >= 1 && lenp % max_len <= max_sil;
+    }
+    FFS_DEV bool delivered(int i0) const {  // the piece that starts at frame i0
+        const int s = isl[i0], e_isl = nxt[i0] - 1;
+        const int j = (i0 - s) / max_len;
+        const int e = (i0 + max_len - 1) < e_isl ? (i0 + max_len - 1) : e_isl;
+        const int r = e - i0 + 1;
+        if (r == max_len) return true;
+        const bool c = j >= 1 ? true : c_in(s);
+        const bool ok_len = r >= min_len || (r > 0 && c);
+        if (e_isl + 1 < n) return max_sil <= 0 ? ok_len : (max_sil < r && ok_len);  // ended by a long gap
+        const int t = e_isl - lastv[e_isl];  // trailing silence at the end of the chunk
+        return r > 0 && r > t && ok_len;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_vad_tokenize_scan(const float* __restrict__ valid, long long n_frames, long long chunk,
+                                                          int min_len, int max_len, int max_sil, float non_speech,
+                                                          float* __restrict__ out, int lds_frames) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    short* s_lastv = reinterpret_cast<short*>(smem);
+    short* s_isl = s_lastv + lds_frames;
+    short* s_nxt = s_isl + lds_frames;
+    __shared__ int s_carry[256];
+    __shared__ double s_sum[256];
+    const long long f0 = (long long)blockIdx.x * chunk;
+    if (f0 >= n_frames) return;
+    const int n = (int)((f0 + chunk) < n_frames ? chunk : (n_frames - f0));
+    const float* v = valid + f0;
+    float* o = out + f0;
+    const int tid = threadIdx.x;
+    const int seg = (n + 255) / 256, a = tid * seg < n ? tid * seg : n, b = (a + seg) < n ? (a + seg) : n;
+    const int ms = max_sil > 0 ? max_sil : 0;
+    // scan 1: last valid index
+    int cur = -1;
+    for (int i = a; i < b; ++i) {
+        if (v[i] != 0.0f) cur = i;
+        s_lastv[i] = (short)cur;
+    }
+    s_carry[tid] = cur;
+    __syncthreads();
+    int pre = -1;
+    for (int t = 0; t < tid; ++t) pre = s_carry[t] > pre ? s_carry[t] : pre;
+    for (int i = a; i < b && s_lastv[i] < 0; ++i) s_lastv[i] = (short)pre;
+    __syncthreads();
+    auto in_island = [&](int i) { const int lv = s_lastv[i]; return lv >= 0 && i - lv <= ms; };
+    // scan 2: island start (-2 = inside an island that started in an earlier segment)
+    cur = -2;
+    for (int i = a; i < b; ++i) {
+        const bool in = in_island(i);
+        if (in && s_lastv[i] == i && !(i > 0 && in_island(i - 1))) cur = i;
+        s_isl[i] = (short)(in ? cur : -1);
+    }
+    __syncthreads();
+    s_carry[tid] = cur;
+    __syncthreads();
+    pre = -2;
+    for (int t = 0; t < tid; ++t) pre = s_carry[t] > pre ? s_carry[t] : pre;  // starts are increasing: the latest one
+    for (int i = a; i < b && s_isl[i] == -2; ++i) s_isl[i] = (short)pre;
+    // scan 3 (backward): first frame behind i that is outside every island
+    cur = -1;  // unknown within this segment
+    for (int i = b - 1; i >= a; --i) {
+        s_nxt[i] = (short)cur;
+        if (!in_island(i)) cur = i;
+    }
+    __syncthreads();
+    s_carry[tid] = cur;
+    __syncthreads();
+    pre = n;
+    for (int t = 255; t > tid; --t) pre = (s_carry[t] >= 0) ? s_carry[t] : pre;  // the nearest later segment that has one
+    for (int i = b - 1; i >= a && s_nxt[i] < 0; --i) s_nxt[i] = (short)pre;
+    __syncthreads();
+    // markers (kept in the output buffer) and their fp64 prefix sum
+    TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil};
+    double acc = 0.0;
+    for (int i = a; i < b; ++i) {
+        float m = 0.0f;
+        const int s = s_isl[i];
+        if (s >= 0 && (i - s) % max_len == 0 && tv.delivered(i)) {
+            m = 1.0f;
+        } else if (i >= 1 && s_isl[i - 1] >= 0) {
+            const int off = (i - 1 - s_isl[i - 1]) % max_len;
+            if ((off == max_len - 1 || i == s_nxt[i - 1]) && tv.delivered(i - 1 - off)) m = non_speech - 1.0f;
+        }
+        o[i] = m;
+        acc += (double)m;
+    }
+    s_sum[tid] = acc;
+    __syncthreads();
+    acc = 0.0;
+    for (int t = 0; t < tid; ++t) acc += s_sum[t];
+    for (int i = a; i < b; ++i) {
+        acc += (double)o[i];
+        o[i] = (float)fmin(fmax(acc, 0.0), 1.0);
+    }
+}
+
 // subtitle rasteriser: one wave per [start, end) interval, byte stores of 1 (overlaps are unions)
 __global__ __launch_bounds__(256) void k_fill_intervals(const int2* __restrict__ iv, int n, unsigned char* __restrict__ out) {
     const int lane = threadIdx.x & 63;

@@ -1547,9 +1547,28 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
     int rc_dev;
     if ((rc_dev = use_device_of(labels_dev))) return rc_dev;
     const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
-    hipLaunchKernelGGL(k_vad_tokenize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream, valid_dev,
-                       (long long)n_frames, (long long)chunk_frames, min_length, max_length, max_continuous_silence,
-                       non_speech_label, labels_dev);
+    const long long longest = chunk_frames < n_frames ? chunk_frames : n_frames;
+    const char* serial = getenv("FFS_VAD_TOKENIZE_SERIAL");
+    if (longest <= TOK_SCAN_MAX && max_length >= min_length && min_length >= 0 && !(serial && serial[0] == '1')) {
+        // one workgroup per chunk, every step a scan (three 16-bit index arrays of the chunk in LDS)
+        const int lds_frames = (int)((longest + 7) / 8 * 8);
+        const size_t lds = (size_t)lds_frames * 3 * sizeof(short);
+        static thread_local size_t lds_set[64] = {};
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && lds_set[dev] < lds) {
+            HIP_TRY(hipFuncSetAttribute((const void*)k_vad_tokenize_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(TOK_SCAN_MAX * 3 * sizeof(short))));
+            lds_set[dev] = (size_t)TOK_SCAN_MAX * 3 * sizeof(short);
+        }
+        hipLaunchKernelGGL(k_vad_tokenize_scan, dim3((unsigned)chunks), dim3(256), lds, (hipStream_t)hip_stream, valid_dev,
+                           (long long)n_frames, (long long)chunk_frames, min_length, max_length, max_continuous_silence,
+                           non_speech_label, labels_dev, lds_frames);
+    } else {
+        hipLaunchKernelGGL(k_vad_tokenize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream,
+                           valid_dev, (long long)n_frames, (long long)chunk_frames, min_length, max_length,
+                           max_continuous_silence, non_speech_label, labels_dev);
+    }
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }

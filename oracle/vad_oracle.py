@@ -173,6 +173,61 @@ def tokenize_chunk(valid, non_speech_label=0.0, sample_rate=100):
     return np.clip(np.cumsum(media_bstring)[:-1], 0.0, 1.0)
 
 
+def tokenize_chunk_scan(valid, non_speech_label=0.0, min_length=20, max_length=500, max_continuous_silence=25):
+    """numpy model of the device's PARALLEL formulation of the same smoothing (k_vad_tokenize_scan: one workgroup per
+    chunk, every step a scan) -- test infrastructure like fft_model.py; tests/test_oracle_vad.py checks it against the
+    state machine above.  Requires max_length >= min_length.
+
+    The tokenizer's state (and its silence counter) depends on the validity runs alone, so the frames fall into
+    islands: an island starts at a valid frame that follows more than max_continuous_silence invalid ones (or no
+    valid frame at all) and ends max_continuous_silence frames behind its last valid frame (at the end of the chunk
+    if no longer gap follows).  Truncation cuts an island into pieces of max_length frames; full pieces are always
+    delivered, the remainder r iff  max_continuous_silence < r  (island ended by a gap)  resp.  r > trailing silence
+    (end of chunk)  and  r >= min_length or the tokenizer's `contiguous` flag is set: after a cut, or -- first piece --
+    when the previous island ended with a cut followed by at most max_continuous_silence frames."""
+    v = np.asarray(valid, bool)
+    n = v.size
+    if n == 0:
+        return np.zeros(0)
+    mn, mx, msil = int(min_length), int(max_length), int(max_continuous_silence)
+    assert mx >= mn
+    idx = np.arange(n)
+    lastv = np.maximum.accumulate(np.where(v, idx, -1))                       # scan 1: last valid index <= i
+    in_isl = v | ((lastv >= 0) & (idx - lastv <= max(msil, 0)))
+    prev_in = np.concatenate([[False], in_isl[:-1]])
+    isl = np.where(in_isl, np.maximum.accumulate(np.where(v & ~prev_in, idx, -1)), -1)   # scan 2: island start
+    first_out = np.minimum.accumulate(np.where(~in_isl, idx, n)[::-1])[::-1]
+    nxt = np.concatenate([first_out[1:], [n]])                                # scan 3: first outside index > i
+
+    def c_in(s):
+        if msil <= 0 or s == 0 or lastv[s - 1] < 0:
+            return False
+        lp = lastv[s - 1]
+        lenp = lp + msil - isl[lp] + 1
+        return lenp // mx >= 1 and lenp % mx <= msil
+
+    def delivered(i0):
+        s, e_isl = isl[i0], nxt[i0] - 1
+        j = (i0 - s) // mx
+        r = min(i0 + mx - 1, e_isl) - i0 + 1
+        if r == mx:
+            return True
+        ok_len = r >= mn or (r > 0 and (j >= 1 or c_in(s)))
+        if e_isl + 1 < n:
+            return ok_len if msil <= 0 else (msil < r and ok_len)
+        return r > 0 and r > e_isl - lastv[e_isl] and ok_len
+
+    m = np.zeros(n)
+    for i in range(n):
+        if isl[i] >= 0 and (i - isl[i]) % mx == 0 and delivered(i):
+            m[i] = 1.0
+        elif i >= 1 and isl[i - 1] >= 0:
+            off = (i - 1 - isl[i - 1]) % mx
+            if (off == mx - 1 or i == nxt[i - 1]) and delivered(i - 1 - off):
+                m[i] = non_speech_label - 1.0
+    return np.clip(np.cumsum(m), 0.0, 1.0)                                    # scan 4
+
+
 def tokenize(valid, non_speech_label=0.0, chunk_frames=10000, sample_rate=100):
     """Chunk loop: the reference builds the tokenizer once but every detector call starts a fresh
     tokenize() pass over its own 100 s buffer."""

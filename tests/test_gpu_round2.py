@@ -448,3 +448,39 @@ def test_pass_a_prefetch_blocks_change_nothing_but_time(torch, monkeypatch):
             for f in ("score", "offset", "flags", "score_f32"):
                 assert np.array_equal(out[0][0][f], got[0][f]), (max_offset, f)
             assert np.array_equal(out[0][1], got[1])
+
+
+def test_scan_tokenizer_equals_serial_kernel_and_restatement(torch, monkeypatch):
+    """ffs_vad_tokenize runs one workgroup per chunk with every step a scan (k_vad_tokenize_scan) for chunks of up to
+    20480 frames and max_length >= min_length, the one-thread-per-chunk state machine (k_vad_tokenize) otherwise
+    (FFS_VAD_TOKENIZE_SERIAL=1: always).  Both against the Python restatement: reference parameters and degenerate
+    ones, several labels, chunk lengths around the segment size of the scans, chunks too long for the scan kernel."""
+    from ffsubsync_amd import _native
+
+    rng = np.random.RandomState(21)
+    cases = [(20, 500, 25), (3, 10, 2), (5, 5, 1), (1, 7, 0), (4, 40, 30), (2, 9, 9)]
+    for trial in range(10):
+        n = int(rng.choice([1, 255, 256, 257, 3000, 10000, 20480, 30011]))
+        p_on = rng.choice([0.02, 0.2, 0.6, 0.95])
+        runs = rng.geometric(1.0 / rng.choice([1, 3, 15, 80, 700]), size=n + 4)
+        valid = np.repeat(rng.rand(runs.size) < p_on, runs)[:n]
+        dev = torch.from_numpy(valid.astype(np.float32)).cuda()
+        mn, mx, msil = cases[trial % len(cases)]
+        for label in (0.0, 0.25, -1.0):
+            for chunk in (10000, 997, 20480, 25000):
+                tok = lambda c: vo._Tokenizer(mn, mx, msil).tokenize(c)
+                want = []
+                for o in range(0, n, chunk):
+                    c = valid[o:o + chunk]
+                    marks = np.zeros(c.size + 1)
+                    for s, e in tok(c):
+                        marks[s] = 1.0
+                        marks[e + 1] = label - 1.0
+                    want.append(np.clip(np.cumsum(marks)[:-1], 0.0, 1.0))
+                want = np.concatenate(want)
+                got = _native.vad_tokenize(dev, chunk, mn, mx, msil, label).cpu().numpy().astype(float)
+                assert np.array_equal(got, want), ("scan", trial, n, (mn, mx, msil), label, chunk)
+                monkeypatch.setenv("FFS_VAD_TOKENIZE_SERIAL", "1")
+                got = _native.vad_tokenize(dev, chunk, mn, mx, msil, label).cpu().numpy().astype(float)
+                monkeypatch.delenv("FFS_VAD_TOKENIZE_SERIAL")
+                assert np.array_equal(got, want), ("serial", trial, n, (mn, mx, msil), label, chunk)
