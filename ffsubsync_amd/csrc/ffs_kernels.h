@@ -946,18 +946,24 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
 // pointers are scalar, lane offsets opaque to the optimiser (no hoisted address tables).  PF: the loads of the next
 // item are issued into a staging buffer before the current item is transformed (copied to the work buffer when it is
 // its turn: sixteen moves per item buy static buffer roles, i.e. one copy of the transform code per item kind).
-template <int L, bool PF>
-__global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
-                                                        int n_blocks, float inv_n, const cf* __restrict__ tw,
-                                                        const cf* __restrict__ tb, const cf* __restrict__ ts,
-                                                        int half_flags) {
+// NA = accumulator rows: 4 in general; solves with ONE packed slot (one or two candidates: every FFTAligner.fit) use the
+// NA = 1 instantiation, which keeps conj(R_k)/N in registers, needs the row buffer only and fits three blocks on a CU
+// (the transform core runs 9 % faster there: profiles/fft_core_rate.hip).
+template <int L, bool PF, int NA = 4>
+__global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __restrict__ work, int N1, int log2C, long long N,
+                                                                      int n_slots, int n_blocks, float inv_n,
+                                                                      const cf* __restrict__ tw, const cf* __restrict__ tb,
+                                                                      const cf* __restrict__ ts, int half_flags) {
     static_assert(L == 4096, "one row per 256-thread block");
-    constexpr int NA = 4;
     const int ref_half = half_flags & HALF_REF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int LT = L / 16;
-    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]: conj(R_k)/N of the current block, thread-private columns
+    // conj(R_k)/N of the current block: parked in LDS ([16][LT], thread-private columns) next to four accumulator rows,
+    // in registers next to one (then the block needs the row buffer only and three blocks share a CU)
+    constexpr bool RR_REGS = NA == 1;
+    cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;
+    cf rr[RR_REGS ? 16 : 1];
     const int u = threadIdx.x;
     int k1 = blockIdx.x;
     if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see k_mid_seg
@@ -1018,7 +1024,12 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, i
             mirror_load(x, lds, addr, std::make_integer_sequence<int, 16>{});
         }
 #pragma unroll
-        for (int q = 0; q < 16; ++q) s_rr[q * LT + u] = x[q] * scale;  // conj(R_k)/N
+        for (int q = 0; q < 16; ++q) {  // conj(R_k)/N
+            if constexpr (RR_REGS)
+                rr[q] = x[q] * scale;
+            else
+                s_rr[q * LT + u] = x[q] * scale;
+        }
 #pragma unroll
         for (int a = 0; a < NA; ++a) {
             if (a >= na) break;
@@ -1026,7 +1037,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_one(cf* __restrict__ work, i
             fetch(k, 1 + a, last ? k + 1 : k, last ? 0 : 2 + a);
             if (!no_fft) fft_regs<L, RowAddr<L>, true>(x, lds, u, addr, twr);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[a][q] = cmac(acc[a][q], x[q], s_rr[q * LT + u]);
+            for (int q = 0; q < 16; ++q) acc[a][q] = cmac(acc[a][q], x[q], RR_REGS ? rr[q] : s_rr[q * LT + u]);
         }
     }
     cf wbl = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)

@@ -146,6 +146,7 @@ struct ffs_plan {
     int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
     int pass_a_debug = 0;           // FFS_PASS_A_DEBUG: DBG_PA_* bit mask >> 10 (WRONG RESULTS: timing only)
     int mid_debug = 0;              // FFS_MID_DEBUG bits: 1 = no row transforms, 2 = L2-resident traffic, 4 = no stores (WRONG RESULTS: timing only)
+    bool mid_seg_one_na2 = true;    // FFS_MID_SEG_ONE_NA1=0: the four-accumulator kernel also for solves with one packed slot
     int mid_seg_one = 1;            // FFS_MID_SEG_ONE=0|1|2: k_mid_seg_one (single sweep, four accumulator rows; 2 = no load-ahead, 0 = off)
     bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
     bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
@@ -422,7 +423,12 @@ int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, i
     if (sp->mid_seg_one && n_slots - 1 <= 4) {  // single sweep: all (<= 4) candidate slots accumulate at once
         const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
         const int flags = ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0) | sp->mid_debug;
-        if (sp->mid_seg_one == 1) {
+        if (sp->mid_seg_one >= 1 && n_slots - 1 == 1 && sp->mid_seg_one_na2) {  // one accumulator row: 3 blocks per CU
+            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, false, 1>, lds))) return rc_lds;
+            hipLaunchKernelGGL((k_mid_seg_one<4096, false, 1>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1,
+                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
+                               sp->tbM, sp->tsM, flags);
+        } else if (sp->mid_seg_one == 1) {
             if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, true>, ldsp))) return rc_lds;
             hipLaunchKernelGGL((k_mid_seg_one<4096, true>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
                                sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
@@ -796,6 +802,8 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         if (e20) p->pass_a_debug = (atoi(e20) & 31) << 10;
         const char* e15 = getenv("FFS_MID_DEBUG");
         if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0) | ((atoi(e15) & 4) ? DBG_NO_STORE : 0);
+        const char* e23 = getenv("FFS_MID_SEG_ONE_NA1");
+        p->mid_seg_one_na2 = !(e23 && e23[0] == '0');
         const char* e16 = getenv("FFS_MID_SEG_ONE");
         if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
         const char* e19 = getenv("FFS_MID_PF");

@@ -484,3 +484,29 @@ def test_scan_tokenizer_equals_serial_kernel_and_restatement(torch, monkeypatch)
                 got = _native.vad_tokenize(dev, chunk, mn, mx, msil, label).cpu().numpy().astype(float)
                 monkeypatch.delenv("FFS_VAD_TOKENIZE_SERIAL")
                 assert np.array_equal(got, want), ("serial", trial, n, (mn, mx, msil), label, chunk)
+
+
+@pytest.mark.parametrize("n_cand", [1, 2])
+def test_one_slot_mid_kernel_gives_identical_records(torch, monkeypatch, n_cand):
+    """Solves with one packed slot (every FFTAligner.fit: one or two candidates) run the block-segmented mid pass with
+    ONE accumulator row and conj(R)/N in registers (k_mid_seg_one<.., 1>: three blocks per CU); FFS_MID_SEG_ONE_NA1=0
+    keeps the four-row kernel.  Identical records, fp32 values included."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(2300 + i, duration_s=d) for i, d in enumerate((7200.0, 6800.0, 4000.0))]
+    db8 = synth.build_device_batch(specs)
+    pick = lambda a: np.ascontiguousarray(a[:, : 1 + n_cand])
+    db = batch.DeviceBatch(db8.data, pick(db8.offs), pick(db8.lens), pick(db8.lo), pick(db8.hi), db8.dtype)
+    out = []
+    for env in ("0", None):
+        if env is not None:
+            monkeypatch.setenv("FFS_MID_SEG_ONE_NA1", env)
+        al = batch.BatchAligner(db.required_fft_length(6000), n_cand, 6000, pairs_in_flight=2)
+        out.append(al.solve(db))
+        al.plan.close()
+        if env is not None:
+            monkeypatch.delenv("FFS_MID_SEG_ONE_NA1")
+    for f in ("score", "offset", "flags", "score_f32"):
+        assert np.array_equal(out[0][0][f], out[1][0][f]), f
+    assert np.array_equal(out[0][1], out[1][1])
