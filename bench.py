@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--duration", type=float, default=7200.0, help="seconds of activity per vector")
     ap.add_argument("--pairs-in-flight", type=int, default=512)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams (one plan each, pairs-in-flight shared) the sub-batches of a step are spread over; "
+                         "above 1 the per-kernel table and the roofline record are omitted (concurrent kernels share the chip)")
     ap.add_argument("--input-format", choices=("bits", "bytes"), default="bits",
                     help="bits = FFS_DTYPE_U1 (native), bytes = FFS_DTYPE_U8")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
@@ -260,7 +263,7 @@ def main():
     cand_out = torch.empty(max(P, 1) * n_cand * 24, dtype=torch.uint8, device="cuda")
     pair_out = torch.zeros(per * 24, dtype=torch.uint8, device="cuda")
     gathered = torch.empty(world * per * 24, dtype=torch.uint8, device="cuda") if use_dist else None
-    profile = not args.no_profile
+    profile = not args.no_profile and args.streams == 1
     gather_impl = None
     comm = None
     if use_dist:
@@ -295,7 +298,8 @@ def main():
     def timed(n_fft, steps, warmup, max_offset=6000, the_db=None, cands=n_cand):
         """W untimed + K timed passes over this rank's pairs with a plan of length n_fft."""
         the_db = db if the_db is None else the_db
-        aligner = batch.BatchAligner(n_fft, cands, max_offset_samples=max_offset, pairs_in_flight=args.pairs_in_flight)
+        aligner = batch.BatchAligner(n_fft, cands, max_offset_samples=max_offset, pairs_in_flight=args.pairs_in_flight,
+                                     streams=args.streams)
 
         def step():
             aligner.solve_async(the_db, 0, P, cand_out, pair_out)
@@ -322,7 +326,7 @@ def main():
             elapsed = float(t.item())
         seg = (n_fft % 3 == 0 and n_fft // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1"
                and max_offset is not None)
-        aligner.plan.close()
+        aligner.close()
         return elapsed, ktimes, seg
 
     # Bytes every kernel HAS to move per pair, in units of one complex fp32 transform
@@ -416,6 +420,7 @@ def main():
             "n_fft_device": n_dev,
             "pairs_per_gpu": P,
             "pairs_in_flight": args.pairs_in_flight,
+            "streams": args.streams,
             "input_format": "bit-packed 0/1 vectors (FFS_DTYPE_U1) resident in HBM" if db.dtype == _native.FFS_DTYPE_U1
                             else "0/1 bytes (FFS_DTYPE_U8) resident in HBM",
             "arithmetic": "fp32 transforms nominate lags; integer (popcount) re-evaluation of the winners: offsets and "

@@ -107,11 +107,23 @@ class BatchAligner:
     """MaxScoreAligner(FFTAligner, None, sample_rate, max_offset_seconds) over a DeviceBatch."""
 
     def __init__(self, n_fft: int, n_cand: int, max_offset_samples: Optional[int] = 6000,
-                 pairs_in_flight: int = 4, device: Optional[int] = None) -> None:
+                 pairs_in_flight: int = 4, device: Optional[int] = None, streams: int = 1) -> None:
+        """``streams`` > 1: the pairs of a call are split into that many contiguous parts, each solved by its own
+        plan (own workspace, ``pairs_in_flight`` shared between them) on its own HIP stream -- concurrent sub-batches
+        fill each other's launch tails (+2-3 % solves/s at two streams, profiles/overlap_experiment.py).  The caller's
+        current stream orders the whole call as before."""
         self.torch = _native.require_gpu()
-        self.plan = _native.Plan(n_fft, pairs_in_flight, max(n_cand, 1), device)
+        self.streams = max(1, int(streams))
+        per_plan = max(1, (pairs_in_flight + self.streams - 1) // self.streams)
+        self.plans = [_native.Plan(n_fft, per_plan, max(n_cand, 1), device) for _ in range(self.streams)]
+        self.plan = self.plans[0]
+        self._side = [self.torch.cuda.Stream(device=device) for _ in range(self.streams)] if self.streams > 1 else []
         self.n_cand = n_cand
         self.max_offset_samples = max_offset_samples
+
+    def close(self) -> None:
+        for p in self.plans:
+            p.close()
 
     def solve_async(self, batch: DeviceBatch, pair_lo: int = 0, pair_hi: Optional[int] = None,
                     cand_out=None, pair_out=None):
@@ -124,12 +136,33 @@ class BatchAligner:
             cand_out = torch.empty(max(n, 1) * self.n_cand * 24, dtype=torch.uint8, device=batch.data.device)
         if pair_out is None:
             pair_out = torch.empty(max(n, 1) * 24, dtype=torch.uint8, device=batch.data.device)
-        if n > 0:
-            sl = slice(pair_lo, pair_hi)
+        def run(plan, lo, hi):
+            sl = slice(lo, hi)
             ptrs = (batch.data.data_ptr() + batch.offs[sl]).astype(np.uint64)
-            self.plan.align_batch(n, self.n_cand, batch.dtype, ptrs.ravel(), batch.lens[sl].ravel(),
-                                  batch.lo[sl].ravel(), batch.hi[sl].ravel(), self.max_offset_samples,
-                                  self.max_offset_samples, cand_out, pair_out)
+            c0, p0 = (lo - pair_lo) * self.n_cand * 24, (lo - pair_lo) * 24
+            plan.align_batch(hi - lo, self.n_cand, batch.dtype, ptrs.ravel(), batch.lens[sl].ravel(),
+                             batch.lo[sl].ravel(), batch.hi[sl].ravel(), self.max_offset_samples,
+                             self.max_offset_samples, cand_out[c0:], pair_out[p0:])
+
+        if n > 0 and (self.streams == 1 or n < 2 * self.streams):
+            run(self.plan, pair_lo, pair_hi)
+        elif n > 0:
+            main = torch.cuda.current_stream()
+            start = torch.cuda.Event()
+            start.record(main)
+            for i, (plan, side) in enumerate(zip(self.plans, self._side)):
+                lo, hi = shard_bounds(n, i, self.streams)
+                if hi <= lo:
+                    continue
+                side.wait_event(start)
+                with torch.cuda.stream(side):
+                    run(plan, pair_lo + lo, pair_lo + hi)
+                    done = torch.cuda.Event()
+                    done.record(side)
+                main.wait_event(done)
+            for t in (batch.data, cand_out, pair_out):
+                for side in self._side:
+                    t.record_stream(side)  # the caching allocator must not recycle them under the side streams
         return cand_out, pair_out
 
     def solve(self, batch: DeviceBatch, pair_lo: int = 0, pair_hi: Optional[int] = None):

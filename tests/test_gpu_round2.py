@@ -510,3 +510,31 @@ def test_one_slot_mid_kernel_gives_identical_records(torch, monkeypatch, n_cand)
     for f in ("score", "offset", "flags", "score_f32"):
         assert np.array_equal(out[0][0][f], out[1][0][f]), f
     assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_two_streams_give_identical_records(torch):
+    """BatchAligner(streams=2): the pairs of a call split over two plans on two HIP streams, ordered by the caller's
+    current stream -- same records as one stream, also when the call is issued on a non-default stream and the
+    results are consumed right away on it."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(2400 + i, duration_s=1800.0 + 37.0 * i) for i in range(11)]
+    db = synth.build_device_batch(specs)
+    n_fft = db.required_fft_length(6000)
+    one = batch.BatchAligner(n_fft, 7, 6000, pairs_in_flight=4)
+    want = one.solve(db)
+    one.close()
+    two = batch.BatchAligner(n_fft, 7, 6000, pairs_in_flight=4, streams=2)
+    got = two.solve(db)
+    for f in ("score", "offset", "flags", "score_f32"):
+        assert np.array_equal(want[0][f], got[0][f]), f
+    assert np.array_equal(want[1], got[1])
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            c, p = two.solve_async(db, 2, 9)
+            snap = p.clone()  # consumed on the caller's stream right behind the call
+    side.synchronize()
+    assert np.array_equal(snap.cpu().numpy().view(got[1].dtype)[:7], want[1][2:9])
+    two.close()
