@@ -277,11 +277,12 @@ struct ProfSpan {
 
 // ---- kernel dispatch -------------------------------------------------------------------------
 // Bit-packed inputs: how many grid rows (transforms) the prefetch blocks of pass A run ahead -- about the time of
-// twelve 2^18-point transforms (measured plateau: 9-14), at least one row, 0 = off.
+// twelve 2^18-point transforms (measured plateau: 9-14 rows there), but at least four rows (2^21-point transforms:
+// pass A 17.3 us/pair at one row ahead, 15.8 at four, 15.9 at twelve), 0 = off.
 int bit_prefetch_rows(const ffs_plan* p) {
     if (p->pass_a_prefetch_bits <= 0) return 0;
     const long long rows = ((long long)p->pass_a_prefetch_bits << 18) / (long long)p->N;
-    return (int)(rows < 1 ? 1 : (rows > 255 ? 255 : rows));
+    return (int)(rows < 4 ? 4 : (rows > 255 ? 255 : rows));
 }
 
 template <int L, int C, int DT>
