@@ -219,3 +219,43 @@ def segmented_window_correlation(ref_pm, sub_pm, d_lo, d_hi, M):
             r[src_lo - lo: src_hi - lo] = ref_pm[src_lo:src_hi]
         acc += np.conj(np.fft.fft(s)) * np.fft.fft(r)  # sum_i s[i] r[(i + m) % M] in the spectrum domain
     return np.real(np.fft.ifft(acc))[:W], K
+
+
+# ---- lag window in output-index space (mirrors load_window / in_window / in_window_t of csrc/ffs_kernels.h) ----------
+NEVER = 0x40000000
+
+
+def window_two_ranges(lo, hi, n, seg=False, seg_shift=0):
+    """The window [lo, hi] of lags as (start, width) ranges of output indices m: lags 0..hi sit at m = d, negative ones
+    at m = d + n (circular transform); block-segmented mode: m = d - seg_shift.  Returns [(a0, w0), (a1, w1)]; m passes
+    iff a_i <= m <= a_i + w_i for one of them (NEVER = empty)."""
+    r = [(NEVER, 0), (NEVER, 0)]
+    if hi >= lo:
+        if seg:
+            r[0] = (lo - seg_shift, hi - lo)
+        else:
+            if hi >= 0:
+                a = max(lo, 0)
+                r[0] = (a, hi - a)
+            if lo < 0:
+                b = min(hi, -1)
+                r[1] = (n + lo, b - lo)
+    return r
+
+
+def window_one_range(lo, hi, n, seg=False, seg_shift=0):
+    """The same window as ONE range test for 0 <= m < n: (g0, gw, inv) with  m passes iff (g0 <= m <= g0 + gw) != inv
+    -- a window is one range of m or, with lags on both sides of zero, everything but one gap in the middle."""
+    g0, gw, inv = NEVER, 0, False
+    if hi >= lo:
+        if seg:
+            g0, gw = lo - seg_shift, hi - lo
+        elif lo >= 0:
+            g0, gw = lo, hi - lo
+        elif hi < 0:
+            g0, gw = n + lo, hi - lo
+        else:
+            inv = True
+            if n + lo - 1 >= hi + 1:
+                g0, gw = hi + 1, n + lo - hi - 2
+    return g0, gw, inv

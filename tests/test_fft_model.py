@@ -78,3 +78,34 @@ def test_block_segmented_accumulation_identity(R, S, d_lo, d_hi, M):
     off = max(0, -d_lo)
     exp = np.array([np.dot(sub, rp[off + d: off + d + S]) for d in range(d_lo, d_hi + 1)])
     assert np.abs(got - exp).max() < 1e-7 * max(1.0, np.abs(exp).max())
+
+
+def test_one_range_window_test_equals_the_two_range_one():
+    """The last pass tests a lag window with ONE unsigned range compare (in_window_t in csrc/ffs_kernels.h); the model of
+    that mapping against the two-range definition it replaced, for every output index of random windows -- one-sided,
+    two-sided, empty, covering everything, block-segmented."""
+    rng = np.random.RandomState(5)
+    for trial in range(400):
+        n = int(rng.choice([16, 48, 64, 96, 256, 768]))
+        seg = bool(trial % 5 == 4)
+        if seg:
+            shift = int(rng.randint(-n, 1))
+            lo = shift + int(rng.randint(0, n))
+            hi = lo + int(rng.randint(-1, shift + n - lo))     # 0 <= lo - shift <= hi - shift < n  (or empty)
+        else:
+            shift = 0
+            lo = int(rng.randint(-n + 1, n))
+            hi = int(rng.randint(lo - 1, min(n - 1, lo + n - 1) + 1))   # at most n lags, hi < n (hi = lo - 1: empty)
+        m = np.arange(n)
+        two = np.zeros(n, bool)
+        for a, w in fm.window_two_ranges(lo, hi, n, seg, shift):
+            two |= (m >= a) & (m <= a + w)
+        g0, gw, inv = fm.window_one_range(lo, hi, n, seg, shift)
+        one = ((m >= g0) & (m <= g0 + gw)) != inv
+        assert np.array_equal(one, two), (trial, n, lo, hi, seg, shift)
+        # and both are the lags of the window
+        if hi >= lo:
+            lag = (m + shift) if seg else np.where(m <= hi, m, m - n) if hi >= 0 else m - n
+            if not seg and hi >= 0:
+                lag = np.where(m <= hi, m, m - n)
+            assert np.array_equal(two, (lag >= lo) & (lag <= hi)), (trial, n, lo, hi, seg, shift)
