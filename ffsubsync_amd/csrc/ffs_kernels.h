@@ -288,8 +288,8 @@ FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int
 }
 
 // --------------------------------------------------------------------------------------------
-// pass A.  grid = (N2/C column tiles [+ N2/128 prefetch blocks for byte inputs], n_transforms);
-// block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
+// pass A.  grid = (N2/C column tiles [+ input prefetch blocks: N2/128 for byte inputs, 8 (one per XCD) for bit-packed
+// ones], n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
 template <int L, int C, int DT>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
