@@ -16,6 +16,140 @@
 
 using namespace ffsa;
 
+// ---- experimental exchange / schedule variants (measured here, NOT part of the product header) ----------------------
+namespace ffsa {
+// The two halves are separate functions because the phase-staggered transform (fft4096_stag) puts a barrier between them.
+FFS_DEV void bfly16_tw_front(cf* t, const cf* w /* w1 w2 w3 w4 w8 w12 */) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        t[4 + b] = cmul(t[4 + b], w[3]);
+        t[8 + b] = cmul(t[8 + b], w[4]);
+        t[12 + b] = cmul(t[12 + b], w[5]);
+        dft4(t[b], t[4 + b], t[8 + b], t[12 + b]);
+    }
+}
+FFS_DEV void bfly16_tw_back(cf* t, const cf* w) {
+    // slot b + 4*k1 holds A_b[k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+        t[4 * k1 + 1] = cmul(t[4 * k1 + 1], w[0]);
+        t[4 * k1 + 2] = cmul(t[4 * k1 + 2], w[1]);
+        t[4 * k1 + 3] = cmul(t[4 * k1 + 3], w[2]);
+    }
+    t[5] = cmul_k(t[5], FFS_COS_PI_8, -FFS_SIN_PI_8);
+    t[6] = cmul_k(t[6], FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[7] = cmul_k(t[7], FFS_SIN_PI_8, -FFS_COS_PI_8);
+    t[9] = cmul_k(t[9], FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[10] = cmul_negi(t[10]);
+    t[11] = cmul_k(t[11], -FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[13] = cmul_k(t[13], FFS_SIN_PI_8, -FFS_COS_PI_8);
+    t[14] = cmul_k(t[14], -FFS_SQRT_HALF, -FFS_SQRT_HALF);
+    t[15] = cmul_k(t[15], -FFS_COS_PI_8, FFS_SIN_PI_8);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(t[4 * k1], t[4 * k1 + 1], t[4 * k1 + 2], t[4 * k1 + 3]);
+}
+// ---- planar row exchange through ds_write_addtid_b32 -------------------------------------------------------------
+// A ds_write_b64 moves three dwords per lane (address + two data) from the VGPRs to the LDS at two cycles each: six
+// cycles per wave-instruction, whatever the LDS array could do.  ds_write_addtid_b32 carries ONE dword -- its address
+// is M0 + immediate + 4*lane -- and takes two, so a complex value costs four cycles instead of six when its real and
+// imaginary parts go to two planes laid out [slot][thread] (the only layout "address = lane" allows).  The gathers then
+// read the two planes with ds_read_b32 (two cycles each, like one ds_read_b64 with the two-way conflict the padded
+// row buffer has); the plane row strides (258 / 272 dwords) make both gathers conflict-free.  Registers, butterflies and
+// barriers are those of fft_regs<4096>; only the sixteen-value exchanges differ.
+struct RowPlanar {
+    static constexpr int S1 = 258, S2 = 272;          // dwords between the slot rows of exchange 1 / exchange 2
+    static constexpr int PLANE = 16 * S2;             // dwords per plane (the larger of the two layouts)
+    static constexpr int ROW_DWORDS = 2 * PLANE;      // real plane + imaginary plane
+    unsigned m0;      // byte address of this wave's first thread in the buffer: the addtid base
+    int g1, g2;       // gather bases (dwords)
+    // lds_byte_base: byte address of the buffer in the LDS; u = thread of the transform (0..255), wave-contiguous
+    FFS_DEV RowPlanar(unsigned lds_byte_base, int u) {
+        m0 = __builtin_amdgcn_readfirstlane(lds_byte_base + 4u * (unsigned)(u & ~63));
+        g1 = (u & 15) * S1 + (u >> 4);   // exchange 1: element p = 16*w + r sits at [r][w]; thread u wants p = u + 256 q
+        g2 = (u >> 4) * S2 + (u & 15);   // exchange 2: element p = 256*(w>>4) + (w&15) + 16 r sits at [r][w]
+    }
+};
+template <int OFF>
+FFS_DEV void addtid_store(float x) {
+    asm volatile("ds_write_addtid_b32 %0 offset:%1" ::"v"(x), "i"(OFF) : "memory");
+}
+template <int S, int... Q>
+FFS_DEV void planar_scatter_impl(const cf (&v)[16], unsigned m0, std::integer_sequence<int, Q...>) {
+    // volatile statements keep their order; nothing the compiler emits in these kernels touches M0 in between
+    asm volatile("s_mov_b32 m0, %0" ::"s"(m0) : "memory", "m0");
+    (addtid_store<4 * Q * S>(v[Q].x), ...);
+    (addtid_store<4 * (Q * S + RowPlanar::PLANE)>(v[Q].y), ...);
+}
+template <int S, int... Q>
+FFS_DEV void planar_gather_impl(cf (&v)[16], const float* lds, int g, std::integer_sequence<int, Q...>) {
+    ((v[Q].x = lds[g + 16 * Q]), ...);
+    ((v[Q].y = lds[g + 16 * Q + RowPlanar::PLANE]), ...);
+}
+// fft_regs<4096> with the planar exchanges.  `lds` = the buffer as floats (RowPlanar::ROW_DWORDS of them).
+template <bool LB>
+FFS_DEV void fft4096_planar(cf (&v)[16], float* lds, const RowPlanar& ad, const TwRegs<4096>& tw) {
+    constexpr int L = 4096;
+    typedef Shape<L> S;
+    const auto seq = std::make_integer_sequence<int, 16>{};
+    stage_first(v);
+    block_sync<LB>();
+    planar_scatter_impl<RowPlanar::S1>(v, ad.m0, seq);
+    block_sync<LB>();
+    planar_gather_impl<RowPlanar::S1>(v, lds, ad.g1, seq);
+    stage_compute<L, S::R1, 16, false>(v, tw.s1);
+    block_sync<LB>();
+    planar_scatter_impl<RowPlanar::S2>(v, ad.m0, seq);
+    block_sync<LB>();
+    planar_gather_impl<RowPlanar::S2>(v, lds, ad.g2, seq);
+    stage_compute<L, S::R2, 256, false>(v, tw.s2);
+}
+
+// Phase-staggered 4096-point transform for blocks made of TWO teams of 256 threads (k_mid_seg_duo).  Same arithmetic
+// and LDS traffic as fft_regs<4096>, but the barrier that protects the exchange buffer against the next scatter (all
+// gathers done) sits in the MIDDLE of the following butterfly instead of at its end.  The workgroup barrier counts
+// arrivals of all eight waves, so a team that starts one barrier later than the other stays exactly one interval
+// behind: while one team waits for its exchange (scatter drained -> barrier -> gather returned) the other team's waves
+// own the VALUs, and the other way round in the next interval.  Two independent 256-thread blocks on a CU do not settle
+// into that alternation by themselves (both stations are shared: measured 1097 ns per transform per CU against 729 if
+// perfect, profiles/fft_core_rate.hip).  Every call executes exactly FOUR barriers; an idle team calls stag_idle().
+template <class Addr>
+FFS_DEV void fft4096_stag(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<4096>& tw) {
+    constexpr int L = 4096;
+    stage_first(v);
+    stage_scatter<L, 16, 1>(v, lds, u, addr);
+    lds_barrier();  // the team's scatter is complete
+    stage_gather<L>(v, lds, u, addr);
+    {
+        cf t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = v[r];
+        bfly16_tw_front(t, tw.s1.w);
+        lds_barrier();  // every wave of the team has its gathered values: the buffer may be overwritten
+        bfly16_tw_back(t, tw.s1.w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = t[Bfly<16>::slot_of(r)];
+    }
+    stage_scatter<L, 16, 16>(v, lds, u, addr);
+    lds_barrier();
+    stage_gather<L>(v, lds, u, addr);
+    {
+        cf t[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t[r] = v[r];
+        bfly16_tw_front(t, tw.s2.w);
+        lds_barrier();
+        bfly16_tw_back(t, tw.s2.w);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = t[Bfly<16>::slot_of(r)];
+    }
+}
+FFS_DEV void stag_idle() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_barrier();
+}
+
+}  // namespace ffsa
+
 #define CHECK(x)                                                   \
     do {                                                           \
         hipError_t e = (x);                                        \
@@ -25,7 +159,7 @@ using namespace ffsa;
         }                                                          \
     } while (0)
 
-enum { FULL = 0, NO_LDS, NO_VALU, NO_BARRIER };
+enum { FULL = 0, NO_LDS, NO_VALU, NO_BARRIER, PLANAR, PLANAR_NO_VALU };
 
 template <int VARIANT>
 __global__ __launch_bounds__(256) void k_core(const cf* __restrict__ tw, cf* __restrict__ out, int iters) {
@@ -43,9 +177,23 @@ __global__ __launch_bounds__(256) void k_core(const cf* __restrict__ tw, cf* __r
         v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
         acc[q] = mk(0.f, 0.f);
     }
+    RowPlanar pad((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem, u);
+    float* ldsf = reinterpret_cast<float*>(smem);
+    const auto seq = std::make_integer_sequence<int, 16>{};
     for (int it = 0; it < iters; ++it) {
         if constexpr (VARIANT == FULL) {
             fft_regs<L, RowAddr<L>, true>(v, lds, u, addr, twr);
+        } else if constexpr (VARIANT == PLANAR) {
+            fft4096_planar<true>(v, ldsf, pad, twr);
+        } else if constexpr (VARIANT == PLANAR_NO_VALU) {
+            lds_barrier();
+            planar_scatter_impl<RowPlanar::S1>(v, pad.m0, seq);
+            lds_barrier();
+            planar_gather_impl<RowPlanar::S1>(v, ldsf, pad.g1, seq);
+            lds_barrier();
+            planar_scatter_impl<RowPlanar::S2>(v, pad.m0, seq);
+            lds_barrier();
+            planar_gather_impl<RowPlanar::S2>(v, ldsf, pad.g2, seq);
         } else {
             if constexpr (VARIANT != NO_VALU) stage_first(v);
             if constexpr (VARIANT != NO_LDS) {
@@ -63,7 +211,7 @@ __global__ __launch_bounds__(256) void k_core(const cf* __restrict__ tw, cf* __r
             }
             if constexpr (VARIANT != NO_VALU) stage_compute<L, S::R2, 256>(v, twr.s2);
         }
-        if constexpr (VARIANT != NO_VALU) {
+        if constexpr (VARIANT != NO_VALU && VARIANT != PLANAR_NO_VALU) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], twr.s1.w[q % 6]);
         }
@@ -74,9 +222,64 @@ __global__ __launch_bounds__(256) void k_core(const cf* __restrict__ tw, cf* __r
     for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 256 + u) * 16 + q] = acc[q] + v[q];
 }
 
+// Two teams of 256 threads in ONE 512-thread block, each with its own row buffer, running fft4096_stag: the barrier
+// that frees the exchange buffer sits in the middle of the next butterfly.  OFFSET: team 1 starts one barrier later,
+// so the teams alternate between "waiting for the exchange" and "owning the VALUs" (k_mid_seg_duo's schedule);
+// without it the eight waves move in lockstep.
+template <bool OFFSET>
+__global__ __launch_bounds__(512, 1) void k_core_duo(const cf* __restrict__ tw, cf* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int L = 4096;
+    const int team = threadIdx.x >> 8, u = threadIdx.x & 255;
+    cf* lds = reinterpret_cast<cf*>(smem) + team * RowAddr<L>::ROW_ELEMS;
+    RowAddr<L> addr(0, u);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf v[16], acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
+        acc[q] = mk(0.f, 0.f);
+    }
+    if (OFFSET && team == 1) lds_barrier();
+    for (int it = 0; it < iters; ++it) {
+        fft4096_stag(v, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], twr.s1.w[q % 6]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(v[q]));
+    }
+    if (OFFSET && team == 0) lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 512 + threadIdx.x) * 16 + q] = acc[q] + v[q];
+}
+
+template <bool OFFSET>
+static void run_duo(const char* name, const cf* tw, cf* out, int n_cu, bool last) {
+    const size_t lds = 2 * (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf);
+    CHECK(hipFuncSetAttribute((const void*)k_core_duo<OFFSET>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    printf("  \"%s\": {", name);
+    const int iters = 400;
+    for (int bpc = 1; bpc <= 2; ++bpc) {  // one 512-thread block per CU = the occupancy of two 256-thread blocks
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_core_duo<OFFSET>, dim3(n_cu * bpc), dim3(512), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_core_duo<OFFSET>, dim3(n_cu * bpc), dim3(512), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        // a block does two transforms per iteration
+        printf("\"%d_duo_blocks_per_cu\": [%.0f, %.0f]%s", bpc, ms * 1e6 / iters, ms * 1e6 / iters / (2 * bpc), bpc < 2 ? ", " : "");
+    }
+    printf("}%s\n", last ? "" : ",");
+}
+
 template <int VARIANT>
 static void run(const char* name, const cf* tw, cf* out, int n_cu, bool last) {
-    const size_t lds = (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf);
+    const size_t lds = (size_t)RowPlanar::ROW_DWORDS * 4 > (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf) ? (size_t)RowPlanar::ROW_DWORDS * 4 : (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf);
     CHECK(hipFuncSetAttribute((const void*)k_core<VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     printf("  \"%s\": {", name);
     const int iters = 400;
@@ -104,12 +307,16 @@ int main() {
     cf *tw, *out;
     CHECK(hipMalloc(&tw, 1 << 20));
     CHECK(hipMemset(tw, 0x3c, 1 << 20));  // small finite floats: timing only
-    CHECK(hipMalloc(&out, (size_t)n_cu * 4 * 256 * 16 * sizeof(cf)));
+    CHECK(hipMalloc(&out, (size_t)n_cu * 4 * 512 * 16 * sizeof(cf)));
     printf("{\"cus\": %d, \"unit\": \"[ns per transform per block, ns per transform per CU] for one 4096-point row transform + 16 cmacs\",\n", n_cu);
     run<FULL>("full", tw, out, n_cu, false);
     run<NO_LDS>("no_lds", tw, out, n_cu, false);
     run<NO_VALU>("no_valu", tw, out, n_cu, false);
-    run<NO_BARRIER>("no_barrier", tw, out, n_cu, true);
+    run<NO_BARRIER>("no_barrier", tw, out, n_cu, false);
+    run<PLANAR>("planar_addtid_full", tw, out, n_cu, false);
+    run<PLANAR_NO_VALU>("planar_addtid_no_valu", tw, out, n_cu, false);
+    run_duo<true>("duo_staggered", tw, out, n_cu, false);
+    run_duo<false>("duo_lockstep", tw, out, n_cu, true);
     printf("}\n");
     return 0;
 }
