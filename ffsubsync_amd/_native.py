@@ -44,6 +44,7 @@ EXPORTED_SYMBOLS = (
     "ffs_align_batch",
     "ffs_correlate_full",
     "ffs_vad_energy",
+    "ffs_vad_energy_bits",
     "ffs_speech_bounds",
     "ffs_vad_tokenize",
     "ffs_raster_length",
@@ -127,6 +128,8 @@ def load():
         ]
         lib.ffs_vad_energy.restype = c.c_int
         lib.ffs_vad_energy.argtypes = [c.c_void_p, c.c_int64, c.c_int, c.c_double, c.c_float, c.c_void_p, c.c_void_p]
+        lib.ffs_vad_energy_bits.restype = c.c_int
+        lib.ffs_vad_energy_bits.argtypes = [c.c_void_p, c.c_int64, c.c_int, c.c_double, c.c_void_p, c.c_void_p]
         lib.ffs_vad_tokenize.restype = c.c_int
         lib.ffs_vad_tokenize.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_int, c.c_int, c.c_int, c.c_float,
                                          c.c_void_p, c.c_void_p]
@@ -337,6 +340,25 @@ def vad_energy(pcm, frame_len: int, threshold_db: float, non_speech_label: float
         check(load().ffs_vad_energy(pcm.data_ptr(), n, int(frame_len), float(threshold_db), float(non_speech_label),
                                     labels.data_ptr(), current_stream_ptr(torch)))
     return labels
+
+
+def vad_energy_bits(pcm, frame_len: int, threshold_db: float, out=None, first_frame: int = 0):
+    """Bit-packed labels (int32 CUDA words, FFS_DTYPE_U1 order) for an int16 CUDA tensor of mono PCM.
+    ``out`` / ``first_frame``: write into an existing zero-initialised word tensor at a frame offset that is a
+    multiple of 8 (chunk-by-chunk sweeps of one file); returns (words, n_frames)."""
+    torch = require_gpu()
+    n = pcm.numel()
+    n_frames = (n + frame_len - 1) // frame_len
+    if first_frame % 8:
+        raise ValueError("first_frame must be a multiple of 8")
+    if out is None:
+        out = torch.zeros((first_frame + n_frames + 31) // 32, dtype=torch.int32, device=pcm.device)
+    elif out.numel() * 32 < first_frame + n_frames:
+        raise ValueError("output word buffer too small")
+    if n:
+        check(load().ffs_vad_energy_bits(pcm.data_ptr(), n, int(frame_len), float(threshold_db),
+                                         out.data_ptr() + first_frame // 8, current_stream_ptr(torch)))
+    return out, n_frames
 
 
 def vad_tokenize(valid, chunk_frames: int, min_length: int, max_length: int, max_continuous_silence: int,

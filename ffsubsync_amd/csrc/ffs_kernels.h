@@ -2275,42 +2275,98 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
 }
 
 // --------------------------------------------------------------------------------------------
-// VAD frame-energy sweep.  One wave per frame per iteration; lanes read 16 B (8 samples) each.
-// speech  <=>  sum(x^2) >= thr_lin * n   (== 10*log10(mean x^2) >= thr_db, evaluated exactly in
-// integers/fp64), n = samples in the frame (the last frame may be short).
+// VAD frame-energy sweep (speech_transformers.py:133-150: one Python call per 10 ms frame).
+// speech  <=>  sum(x^2) >= thr_lin * n   (== 10*log10(mean x^2) >= thr_db, evaluated exactly in integers / fp64),
+// n = samples in the frame (the last frame may be short).
+//
+// A wave owns VAD_FPT = 8 consecutive frames -- one BYTE of the bit-packed label vector -- and walks them four at a
+// time: lane l < frame_len/8 loads its 16-byte vector of each of the four frames (four independent nontemporal loads in
+// flight per lane; the sweep reads every byte once), squares with v_dot2_i32_i16 (two samples per instruction; a pair
+// of squares is at most 2^31 and is taken as an unsigned value) and adds in 64 bits.  The wave sum is split into a
+// 20-bit and a 14-bit half so that both reduce in 32-bit DPP adds (quad / half-mirror / mirror: every lane of a row
+// ends up with the row total) and the four row totals are combined on the scalar unit.  Round 2's kernel (one frame
+// per wave iteration, v_mad_u64_u32 chains: ~40 VALU instructions per 16 bytes) was VALU-bound at 4.6-5.3 TB/s; a
+// read-only sweep reaches 6.2-6.9 (profiles/read_ceiling.hip).
+// Outputs (either may be null): labels[f] = 1.0f / non_speech (fp32), bits[f >> 3] bit (f & 7) = speech.
+#define VAD_FPT 8
+FFS_DEV unsigned row_total(unsigned v) {  // sum over the 16 lanes of a DPP row, in every lane of the row
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror
+    return v;
+}
+FFS_DEV unsigned long long wave_total(unsigned long long part) {  // part < 2^34 per lane; wave-uniform result
+    const unsigned lo = row_total((unsigned)part & 0xFFFFFu), hi = row_total((unsigned)(part >> 20));
+    unsigned long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        t += (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, 16 * r) +
+             ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)hi, 16 * r) << 20);
+    return t;
+}
+typedef int vad_v4i __attribute__((ext_vector_type(4)));
+// lo^2 + hi^2 of the two int16 halves of w (at most 2^31: the bit pattern is the unsigned sum).  Inline asm: the
+// __builtin_amdgcn_sdot2 + bit_cast form of this loop is folded wrongly by this compiler (all four words become word 0).
+FFS_DEV unsigned squares2(int w) {
+    int d = 0;
+    asm("v_dot2c_i32_i16 %0, %1, %1" : "+v"(d) : "v"(w));
+    return (unsigned)d;
+}
+FFS_DEV unsigned long long squares8(vad_v4i w) {  // exact sum of the eight squared int16 samples of a 16-byte vector
+    unsigned long long a = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a += squares2(w[k]);
+    return a;
+}
 __global__ __launch_bounds__(256) void k_vad_energy(const int16_t* __restrict__ pcm, long long n_samples, int frame_len,
                                                     long long n_frames, double thr_lin, float non_speech,
-                                                    float* __restrict__ labels) {
+                                                    float* __restrict__ labels, unsigned char* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * (blockDim.x / 64) + (threadIdx.x / 64);
     const long long nwaves = (long long)gridDim.x * (blockDim.x / 64);
-    const bool vec_ok = (frame_len % 8 == 0) && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
-    for (long long f = wave0; f < n_frames; f += nwaves) {
-        const long long s0 = f * frame_len;
-        const long long s1 = (s0 + frame_len) < n_samples ? (s0 + frame_len) : n_samples;
-        const int n = (int)(s1 - s0);
-        unsigned long long acc = 0;
-        if (vec_ok && n == frame_len) {
-            const int nvec = frame_len / 8;
-            const int4* p = reinterpret_cast<const int4*>(pcm + s0);
-            for (int i = lane; i < nvec; i += 64) {
-                const int4 w = p[i];
-                const int ws[4] = {w.x, w.y, w.z, w.w};
+    const long long n_tasks = (n_frames + VAD_FPT - 1) / VAD_FPT;
+    const int nvec = frame_len / 8;
+    const bool vec_ok = (frame_len % 8 == 0) && nvec <= 64 && ((reinterpret_cast<uintptr_t>(pcm) & 15) == 0);
+    const double thr_full = thr_lin * (double)frame_len;
+    for (long long t = wave0; t < n_tasks; t += nwaves) {
+        const long long f0 = t * VAD_FPT;
+        unsigned word = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int lo = (int)(short)(ws[k] & 0xffff), hi = ws[k] >> 16;
-                    acc += (unsigned long long)(lo * lo) + (unsigned long long)((long long)hi * hi);
+        for (int g = 0; g < VAD_FPT; g += 4) {
+            const long long fg = f0 + g;
+            if (fg >= n_frames) break;
+            if (vec_ok && (fg + 4) * frame_len <= n_samples) {  // four whole frames: wave-uniform fast path
+                const vad_v4i* p = reinterpret_cast<const vad_v4i*>(pcm + fg * frame_len);
+                vad_v4i w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    w[i] = lane < nvec ? __builtin_nontemporal_load(p + i * nvec + lane) : vad_v4i{0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned long long e = wave_total(squares8(w[i]));
+                    word |= ((double)e >= thr_full ? 1u : 0u) << (g + i);
+                }
+            } else {  // short tail frame, unaligned buffer, odd frame length: one frame at a time, element loop
+                for (int i = 0; i < 4 && fg + i < n_frames; ++i) {
+                    const long long s0 = (fg + i) * frame_len;
+                    const long long s1 = (s0 + frame_len) < n_samples ? (s0 + frame_len) : n_samples;
+                    const int n = (int)(s1 - s0);
+                    unsigned long long e = 0;
+                    for (int base = 0; base < n; base += 512) {  // <= 8 samples per lane per round: part < 2^34
+                        unsigned long long part = 0;
+                        for (int j = base + lane; j < n && j < base + 512; j += 64) {
+                            const int x = pcm[s0 + j];
+                            part += (unsigned)(x * x);
+                        }
+                        e += wave_total(part);
+                    }
+                    word |= ((double)e >= thr_lin * (double)n ? 1u : 0u) << (g + i);
                 }
             }
-        } else {
-            for (int i = lane; i < n; i += 64) {
-                const long long x = pcm[s0 + i];
-                acc += (unsigned long long)(x * x);
-            }
         }
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
-        if (lane == 0) labels[f] = ((double)acc >= thr_lin * (double)n) ? 1.0f : non_speech;
+        if (bits && lane == 0) bits[t] = (unsigned char)word;
+        if (labels && lane < VAD_FPT && f0 + lane < n_frames) labels[f0 + lane] = ((word >> lane) & 1u) ? 1.0f : non_speech;
     }
 }
 

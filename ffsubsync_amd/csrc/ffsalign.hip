@@ -235,16 +235,28 @@ int leave_stream(ffs_plan* p, hipStream_t st) {
     return FFS_OK;
 }
 
-// Entry points without a plan work on whatever device owns the caller's buffer.
-int use_device_of(const void* dev_ptr) {
-    hipPointerAttribute_t attr;
-    if (dev_ptr && hipPointerGetAttributes(&attr, dev_ptr) == hipSuccess) {
-        HIP_TRY(hipSetDevice(attr.device));
-    } else {
-        (void)hipGetLastError();  // not a tracked allocation: stay on the caller's current device
+// Entry points without a plan work on whatever device owns the caller's buffer -- and leave the thread's current
+// device as they found it (a torch process would otherwise see its current device change under it).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    int enter(const void* dev_ptr) {
+        hipPointerAttribute_t attr;
+        if (dev_ptr && hipPointerGetAttributes(&attr, dev_ptr) == hipSuccess) {
+            HIP_TRY(hipGetDevice(&prev));
+            if (attr.device != prev) {
+                HIP_TRY(hipSetDevice(attr.device));
+                switched = true;
+            }
+        } else {
+            (void)hipGetLastError();  // not a tracked allocation: stay on the caller's current device
+        }
+        return FFS_OK;
     }
-    return FFS_OK;
-}
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
 
 hipEvent_t prof_event(ffs_plan* p) {
     if (p->ev_used == p->ev_pool.size()) {
@@ -1315,8 +1327,9 @@ static int rasterize_impl(const int64_t* start_us, const int64_t* end_us, const 
     if (out_len >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
     if (bits && ((uintptr_t)out_dev & 3)) return fail(FFS_E_INVALID, "bit-packed output must be 4-byte aligned");
     hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
     int rc_dev;
-    if ((rc_dev = use_device_of(out_dev))) return rc_dev;
+    if ((rc_dev = guard.enter(out_dev))) return rc_dev;
     if (out_len > 0) HIP_TRY(hipMemsetAsync(out_dev, 0, bits ? (size_t)((out_len + 31) / 32) * 4 : (size_t)out_len, st));
     // The interval list is a host temporary that an asynchronous copy reads later: park it in a
     // per-thread keep-alive list that is only emptied after a stream synchronisation, so that a run
@@ -1369,8 +1382,9 @@ int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshol
     if (n < 0 || (src_dtype != FFS_DTYPE_U8 && src_dtype != FFS_DTYPE_F32)) return fail(FFS_E_INVALID, "bad argument");
     if (n == 0) return FFS_OK;
     if (!src_dev || !dst_dev || ((uintptr_t)dst_dev & 3)) return fail(FFS_E_INVALID, "null or misaligned buffer");
+    DeviceGuard guard;
     int rc;
-    if ((rc = use_device_of(dst_dev))) return rc;
+    if ((rc = guard.enter(dst_dev))) return rc;
     const long long n_words = (n + 31) / 32;
     long long blocks = (n_words + 255) / 256;
     if (blocks > 65536) blocks = 65536;
@@ -1391,8 +1405,9 @@ int ffs_scatter_segments(const float* seg_labels_dev, const int64_t* seg_src_off
     if (out_len == 0) return FFS_OK;
     if (!out_dev || (n_segments > 0 && !seg_labels_dev)) return fail(FFS_E_INVALID, "null device pointer");
     hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
     int rc;
-    if ((rc = use_device_of(out_dev))) return rc;
+    if ((rc = guard.enter(out_dev))) return rc;
     HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_len * sizeof(float), st));
     for (int s0 = 0; s0 < n_segments; s0 += SCATTER_MAX) {
         ScatterSegs segs;
@@ -1531,21 +1546,35 @@ int ffs_plan_profile_read(ffs_plan* p, double* ms_total, int64_t* launches) {
     return FFS_OK;
 }
 
-int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len, double energy_threshold_db,
-                   float non_speech_label, float* labels_dev, void* hip_stream) {
+static int vad_energy_impl(const int16_t* pcm_dev, int64_t n_samples, int frame_len, double energy_threshold_db,
+                           float non_speech_label, float* labels_dev, uint8_t* bits_dev, void* hip_stream) {
     if (n_samples < 0 || frame_len < 1) return fail(FFS_E_INVALID, "bad n_samples/frame_len");
     if (n_samples == 0) return FFS_OK;
-    if (!pcm_dev || !labels_dev) return fail(FFS_E_INVALID, "null device pointer");
+    if (!pcm_dev || (!labels_dev && !bits_dev)) return fail(FFS_E_INVALID, "null device pointer");
+    DeviceGuard guard;
     int rc_dev;
-    if ((rc_dev = use_device_of(labels_dev))) return rc_dev;
+    if ((rc_dev = guard.enter(labels_dev ? (const void*)labels_dev : (const void*)bits_dev))) return rc_dev;
     const long long n_frames = (n_samples + frame_len - 1) / frame_len;
     const double thr_lin = pow(10.0, energy_threshold_db / 10.0);
-    long long blocks = (n_frames + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
+    long long blocks = ((n_frames + VAD_FPT - 1) / VAD_FPT + 3) / 4;  // one wave per VAD_FPT frames, four waves per block
+    if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(k_vad_energy, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)hip_stream, pcm_dev,
-                       (long long)n_samples, frame_len, n_frames, thr_lin, non_speech_label, labels_dev);
+                       (long long)n_samples, frame_len, n_frames, thr_lin, non_speech_label, labels_dev, bits_dev);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
+}
+
+int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len, double energy_threshold_db,
+                   float non_speech_label, float* labels_dev, void* hip_stream) {
+    if (n_samples > 0 && !labels_dev) return fail(FFS_E_INVALID, "null device pointer");
+    return vad_energy_impl(pcm_dev, n_samples, frame_len, energy_threshold_db, non_speech_label, labels_dev, nullptr,
+                           hip_stream);
+}
+
+int ffs_vad_energy_bits(const int16_t* pcm_dev, int64_t n_samples, int frame_len, double energy_threshold_db,
+                        uint8_t* bits_dev, void* hip_stream) {
+    if (n_samples > 0 && !bits_dev) return fail(FFS_E_INVALID, "null device pointer");
+    return vad_energy_impl(pcm_dev, n_samples, frame_len, energy_threshold_db, 0.0f, nullptr, bits_dev, hip_stream);
 }
 
 int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_frames, int min_length, int max_length,
@@ -1553,8 +1582,9 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
     if (n_frames < 0 || chunk_frames < 1 || max_length < 1) return fail(FFS_E_INVALID, "bad argument");
     if (n_frames == 0) return FFS_OK;
     if (!valid_dev || !labels_dev || valid_dev == labels_dev) return fail(FFS_E_INVALID, "null or aliased buffers");
+    DeviceGuard guard;
     int rc_dev;
-    if ((rc_dev = use_device_of(labels_dev))) return rc_dev;
+    if ((rc_dev = guard.enter(labels_dev))) return rc_dev;
     const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     const long long longest = chunk_frames < n_frames ? chunk_frames : n_frames;
     const char* serial = getenv("FFS_VAD_TOKENIZE_SERIAL");
@@ -1585,8 +1615,9 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
 int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds_dev, void* hip_stream) {
     if (!bounds_dev || (n_frames > 0 && !frames_dev) || n_frames < 0) return fail(FFS_E_INVALID, "bad argument");
     hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
     int rc_dev;
-    if ((rc_dev = use_device_of(bounds_dev))) return rc_dev;
+    if ((rc_dev = guard.enter(bounds_dev))) return rc_dev;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(1), 0, st, (long long*)bounds_dev);
     if (n_frames > 0) {
         long long blocks = (n_frames + 255) / 256;

