@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _native
 from .golden_section_search import gss
-from .sklearn_shim import Pipeline, TransformerMixin  # the reference's own classes when ffsubsync is importable
+from .sklearn_shim import Pipeline, TransformerMixin, reference_module  # the reference's own classes when importable
 
 logger: logging.Logger = logging.getLogger(__name__)
 
@@ -21,8 +21,14 @@ MIN_FRAMERATE_RATIO = 0.9  # aligners.py:16
 MAX_FRAMERATE_RATIO = 1.1  # aligners.py:17
 
 
-class FailedToFindAlignmentException(Exception):
-    """aligners.py:20"""
+_ref_aligners = reference_module("aligners")
+
+if _ref_aligners is not None:
+    FailedToFindAlignmentException = _ref_aligners.FailedToFindAlignmentException  # `except` clauses in the caller
+else:
+
+    class FailedToFindAlignmentException(Exception):
+        """aligners.py:20"""
 
 
 def _as_array(x: Any) -> np.ndarray:
@@ -185,44 +191,46 @@ class FFTAligner(TransformerMixin):
         return self.best_offset_
 
 
-class MaxScoreAligner(TransformerMixin):
-    """aligners.py:89-167.  Runs the base aligner over candidate substrings / pipelines (one per
-    framerate ratio) and keeps the best-scoring one."""
+class _MaxScoreStandIn(TransformerMixin):
+    """What ``MaxScoreAligner`` needs around ``fit`` when ffsubsync is not installed (aligners.py:89-129, 154-167):
+    the constructor contract of SURVEY 8b, the golden-section wrapper and the pick of the best candidate."""
 
-    def __init__(
-        self,
-        base_aligner: Union[FFTAligner, Type[FFTAligner]],
-        srtin: Optional[str] = None,
-        sample_rate=None,
-        max_offset_seconds=None,
-    ) -> None:
-        self.srtin: Optional[str] = srtin
-        if sample_rate is None or max_offset_seconds is None:
-            self.max_offset_samples: Optional[int] = None
-        else:
-            self.max_offset_samples = abs(int(max_offset_seconds * sample_rate))
-        if isinstance(base_aligner, type):
-            self.base_aligner: FFTAligner = base_aligner(max_offset_samples=self.max_offset_samples)
-        else:
-            self.base_aligner = base_aligner
-        self.max_offset_seconds: Optional[int] = max_offset_seconds
-        self._scores: List[Tuple[Tuple[float, int], Pipeline]] = []
+    def __init__(self, base_aligner, srtin: Optional[str] = None, sample_rate=None, max_offset_seconds=None) -> None:
+        have_window = sample_rate is not None and max_offset_seconds is not None
+        self.max_offset_samples: Optional[int] = abs(int(max_offset_seconds * sample_rate)) if have_window else None
+        # a class is instantiated with the window; an instance keeps whatever window it was built with (:103-108)
+        self.base_aligner = (base_aligner(max_offset_samples=self.max_offset_samples)
+                             if isinstance(base_aligner, type) else base_aligner)
+        self.srtin, self.max_offset_seconds = srtin, max_offset_seconds
+        self._scores: List[Tuple[Tuple[float, int], Pipeline]] = []  # append-only across fits (:109)
 
     def fit_gss(self, refstring, subpipe_maker):
-        """aligners.py:111-129 -- golden-section search over the framerate ratio; only the final
-        evaluation is recorded."""
+        def negated_score(ratio, is_last_iter):
+            pipe = subpipe_maker(ratio)
+            result = self.base_aligner.fit_transform(refstring, pipe.fit_transform(self.srtin), get_score=True)
+            logger.info("got score %.0f (offset %d) for ratio %.3f", result[0], result[1], ratio)
+            if is_last_iter:  # only the search's final evaluation is a candidate (:124-125)
+                self._scores.append((result, pipe))
+            return -result[0]
 
-        def opt_func(framerate_ratio, is_last_iter):
-            subpipe = subpipe_maker(framerate_ratio)
-            substring = subpipe.fit_transform(self.srtin)
-            score = self.base_aligner.fit_transform(refstring, substring, get_score=True)
-            logger.info("got score %.0f (offset %d) for ratio %.3f", score[0], score[1], framerate_ratio)
-            if is_last_iter:
-                self._scores.append((score, subpipe))
-            return -score[0]
-
-        gss(opt_func, MIN_FRAMERATE_RATIO, MAX_FRAMERATE_RATIO)
+        gss(negated_score, MIN_FRAMERATE_RATIO, MAX_FRAMERATE_RATIO)
         return self
+
+    def transform(self, *_):
+        window = self.max_offset_samples
+        kept = [entry for entry in self._scores if window is None or abs(entry[0][1]) <= window]
+        if not kept:
+            raise FailedToFindAlignmentException(
+                "Synchronization failed; consider passing --max-offset-seconds with a number larger than %s"
+                % (self.max_offset_seconds,))
+        best = max(kept, key=lambda entry: entry[0][0])  # first of equal scores, like the reference's max()
+        return best[0], best[1]
+
+
+class MaxScoreAligner(_ref_aligners.MaxScoreAligner if _ref_aligners is not None else _MaxScoreStandIn):
+    """aligners.py:89-167 with ``fit`` re-done for the device: all candidate substrings / pipelines of a call (one per
+    framerate ratio) go through ONE batched solve.  Constructor, ``fit_gss`` and ``transform`` are the reference's own
+    when ffsubsync is importable (this class derives from its ``MaxScoreAligner``), the stand-in's otherwise."""
 
     def fit(self, refstring, subpipes: Union[Pipeline, List[Pipeline]]) -> "MaxScoreAligner":
         if not isinstance(subpipes, list):
@@ -254,16 +262,3 @@ class MaxScoreAligner(TransformerMixin):
             run.append((subpipe, substring))
         flush()
         return self
-
-    def transform(self, *_) -> Tuple[Tuple[float, float], Pipeline]:
-        scores = self._scores
-        if self.max_offset_samples is not None:
-            scores = [s for s in scores if abs(s[0][1]) <= self.max_offset_samples]
-        if len(scores) == 0:
-            raise FailedToFindAlignmentException(
-                "Synchronization failed; consider passing "
-                "--max-offset-seconds with a number larger than "
-                "{}".format(self.max_offset_seconds)
-            )
-        (score, offset), subpipe = max(scores, key=lambda x: x[0][0])
-        return (score, offset), subpipe

@@ -128,7 +128,29 @@ def _make_pipeline(*steps, **kwargs) -> "_Pipeline":
 # When the reference package is importable its own classes are used, so the drop-in aligners are
 # instances of ffsubsync.sklearn_shim.TransformerMixin and pipelines are the caller's Pipeline type;
 # otherwise (e.g. on a GPU box without ffsubsync) the stand-ins above provide the same contract.
+# Only a missing package selects the stand-ins: any other failure of the reference import is the caller's
+# broken install and is not papered over.  (Importing ffsubsync runs its own logging.basicConfig -- that is
+# what every ffsubsync user gets; nothing here adds to it.)
+import logging as _logging
+
 try:
     from ffsubsync.sklearn_shim import Pipeline, TransformerMixin, make_pipeline  # type: ignore  # noqa: F401
-except Exception:  # ffsubsync (or one of its imports) is not available
+
+    USING_REFERENCE_CLASSES = True
+except ImportError:  # ffsubsync (or one of its dependencies) is not installed
     TransformerMixin, Pipeline, make_pipeline = _TransformerMixin, _Pipeline, _make_pipeline
+    USING_REFERENCE_CLASSES = False
+_logging.getLogger(__name__).debug("Pipeline / TransformerMixin: %s",
+                                   "ffsubsync.sklearn_shim" if USING_REFERENCE_CLASSES else "built-in stand-ins")
+
+
+def reference_module(name: str):
+    """``ffsubsync.<name>`` when the reference package is importable, else None (a missing package only)."""
+    if not USING_REFERENCE_CLASSES:
+        return None
+    import importlib
+
+    try:
+        return importlib.import_module("ffsubsync." + name)
+    except ImportError:
+        return None

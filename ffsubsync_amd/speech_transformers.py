@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _native
 from .constants import DEFAULT_ENERGY_THRESHOLD_DB
-from .sklearn_shim import TransformerMixin
+from .sklearn_shim import TransformerMixin, reference_module
 
 BYTES_PER_SAMPLE = 2  # s16le (speech_transformers.py:122, :160, :683)
 WINDOWS_PER_BUFFER = 10000  # speech_transformers.py:685
@@ -102,35 +102,35 @@ def _make_silero_detector(sample_rate: int, frame_rate: int, non_speech_label: f
     return ref_factory(sample_rate, frame_rate, non_speech_label)
 
 
-_FUSION_STRATEGIES = ("weighted", "intersection", "union")  # speech_transformers.py:253
+_FUSION_RULES = {  # speech_transformers.py:253-296: how two label vectors of equal length combine
+    "weighted": lambda webrtc, silero: 0.6 * silero + 0.4 * webrtc,
+    "intersection": np.minimum,
+    "union": np.maximum,
+}
 
 
 def _make_fused_detector(sample_rate: int, frame_rate: int, non_speech_label: float,
                          fusion_strategy: str = "weighted") -> Callable[[bytes], np.ndarray]:
-    """speech_transformers.py:256-296: combine two detectors frame by frame -- ``intersection``
-    (minimum), ``union`` (maximum) or ``weighted`` (0.6 * silero + 0.4 * webrtc) -- after clipping
-    both label vectors to their common length.  The two factories are looked up as module attributes
-    at call time, the seam the reference's tests/test_vad_fused.py:11-18 patches."""
-    if fusion_strategy not in _FUSION_STRATEGIES:
-        raise ValueError(
-            "unknown fused VAD strategy %r; choose one of %s" % (fusion_strategy, ", ".join(_FUSION_STRATEGIES))
-        )
+    """speech_transformers.py:256-296 (webrtc and silero labels combined frame by frame).  Both detectors are
+    third-party CPU arithmetic (seams): with ffsubsync installed its own factory is used; the stand-in below
+    keeps the contract -- strategies, error text, clipping to the common length, factories looked up as module
+    attributes at call time (the seam tests/test_vad_fused.py:11-18 patches) -- for boxes without it."""
+    ref = reference_module("speech_transformers")
+    if ref is not None:
+        return ref._make_fused_detector(sample_rate, frame_rate, non_speech_label, fusion_strategy)
+    rule = _FUSION_RULES.get(fusion_strategy)
+    if rule is None:
+        raise ValueError("unknown fused VAD strategy %r; choose one of weighted, intersection, union" % (fusion_strategy,))
     import sys
 
-    mod = sys.modules[__name__]
-    webrtc_detector = mod._make_webrtcvad_detector(sample_rate, frame_rate, non_speech_label)
-    silero_detector = mod._make_silero_detector(sample_rate, frame_rate, non_speech_label)
+    here = sys.modules[__name__]
+    parts = [factory(sample_rate, frame_rate, non_speech_label)
+             for factory in (here._make_webrtcvad_detector, here._make_silero_detector)]
 
     def _detect(asegment) -> np.ndarray:
-        webrtc_result = webrtc_detector(asegment)
-        silero_result = silero_detector(asegment)
-        n = min(len(webrtc_result), len(silero_result))
-        webrtc_result, silero_result = webrtc_result[:n], silero_result[:n]
-        if fusion_strategy == "intersection":
-            return np.minimum(webrtc_result, silero_result)
-        if fusion_strategy == "union":
-            return np.maximum(webrtc_result, silero_result)
-        return 0.6 * silero_result + 0.4 * webrtc_result
+        webrtc, silero = (np.asarray(part(asegment)) for part in parts)
+        n = min(len(webrtc), len(silero))
+        return rule(webrtc[:n], silero[:n])
 
     return _detect
 
@@ -143,55 +143,74 @@ def detect_device(pcm_dev, sample_rate: int, frame_rate: int, non_speech_label: 
 
 
 def detect_pinned_stream(pcm_host, sample_rate: int, frame_rate: int, non_speech_label: float,
-                         energy_threshold_db: float = DEFAULT_ENERGY_THRESHOLD_DB, staging=None):
+                         energy_threshold_db: float = DEFAULT_ENERGY_THRESHOLD_DB, staging=None, packed: bool = False):
     """The chunk loop of ``_fit_using_audio`` (speech_transformers.py:683-753) for decoded s16le PCM that
     sits in pinned host memory (int16 CPU tensor): every 100 s buffer (:683-685) is copied to one of two
     HBM staging buffers on a copy stream while the frame-energy sweep of the previous buffer runs on the
     caller's stream -- PCIe transfer and VAD overlap, the labels never leave the GPU.
-    Returns the float32 CUDA label vector.  ``staging`` = (buffers, copy_stream) to reuse across files."""
+    Returns the float32 CUDA label vector, or with ``packed`` the bit-packed ``DeviceRaster`` the aligner reads
+    (``ffs_vad_energy_bits``: no fp32 label round trip, no packing pass; ``non_speech_label`` becomes the raster's
+    low level).  ``staging`` = (buffers, copy_stream) to reuse across files."""
     torch = _native.require_gpu()
     frame_len = frames_per_window(sample_rate, frame_rate)
-    chunk = frame_len * WINDOWS_PER_BUFFER  # samples per buffer; a multiple of the frame length
+    chunk = frame_len * WINDOWS_PER_BUFFER  # samples per buffer; a multiple of the frame length (and of 8 frames)
     n = int(pcm_host.numel())
     n_frames = (n + frame_len - 1) // frame_len
-    labels = torch.empty(n_frames, dtype=torch.float32, device="cuda")
-    if n == 0:
-        return labels
-    if staging is None:
-        staging = ([torch.empty(chunk, dtype=torch.int16, device="cuda") for _ in range(2)], torch.cuda.Stream())
-    bufs, copy_stream = staging
+    if packed:
+        out = torch.zeros((n_frames + 31) // 32, dtype=torch.int32, device="cuda")
+    else:
+        out = torch.empty(n_frames, dtype=torch.float32, device="cuda")
     main = torch.cuda.current_stream()
-    filled = [torch.cuda.Event() for _ in range(2)]
-    drained = [None, None]
-    for i, o in enumerate(range(0, n, chunk)):
-        k = i % 2
-        m = min(chunk, n - o)
-        with torch.cuda.stream(copy_stream):
-            if drained[k] is not None:
-                copy_stream.wait_event(drained[k])  # the sweep that last read this staging buffer is done
-            bufs[k][:m].copy_(pcm_host[o:o + m], non_blocking=True)
-            filled[k].record(copy_stream)
-        main.wait_event(filled[k])
-        f0 = o // frame_len
-        _native.check(_native.load().ffs_vad_energy(bufs[k].data_ptr(), m, frame_len, float(energy_threshold_db),
-                                                    float(non_speech_label), labels[f0:].data_ptr(), main.cuda_stream))
-        drained[k] = torch.cuda.Event()
-        drained[k].record(main)
-    return labels
+    if n:
+        own = staging is None
+        if own:
+            staging = ([torch.empty(chunk, dtype=torch.int16, device="cuda") for _ in range(2)], torch.cuda.Stream())
+        bufs, copy_stream = staging
+        # the staging blocks may still carry work of the caller's stream (fresh from the caching allocator, or the
+        # previous file's last sweep): the first copies wait for it
+        copy_stream.wait_stream(main)
+        if own:
+            for b in bufs:
+                b.record_stream(copy_stream)
+        filled = [torch.cuda.Event() for _ in range(2)]
+        drained = [None, None]
+        lib = _native.load()
+        for i, o in enumerate(range(0, n, chunk)):
+            k = i % 2
+            m = min(chunk, n - o)
+            with torch.cuda.stream(copy_stream):
+                if drained[k] is not None:
+                    copy_stream.wait_event(drained[k])  # the sweep that last read this staging buffer is done
+                bufs[k][:m].copy_(pcm_host[o:o + m], non_blocking=True)
+                filled[k].record(copy_stream)
+            main.wait_event(filled[k])
+            f0 = o // frame_len
+            if packed:
+                _native.check(lib.ffs_vad_energy_bits(bufs[k].data_ptr(), m, frame_len, float(energy_threshold_db),
+                                                      out.data_ptr() + f0 // 8, main.cuda_stream))
+            else:
+                _native.check(lib.ffs_vad_energy(bufs[k].data_ptr(), m, frame_len, float(energy_threshold_db),
+                                                 float(non_speech_label), out[f0:].data_ptr(), main.cuda_stream))
+            drained[k] = torch.cuda.Event()
+            drained[k].record(main)
+    if packed:
+        from .subtitle_raster import DeviceRaster
+
+        return DeviceRaster(out, float(non_speech_label), 1.0, n_frames)
+    return out
 
 
 class ComputeSpeechFrameBoundariesMixin:
-    """speech_transformers.py:299-317."""
+    """speech_transformers.py:299-317 with the scan on the device: first / last frame above 0.5 (``start_frame_``,
+    ``end_frame_``; both stay None when nothing is) and their distance ``num_frames``."""
 
-    def __init__(self) -> None:
-        self.start_frame_: Optional[int] = None
-        self.end_frame_: Optional[int] = None
+    start_frame_: Optional[int] = None
+    end_frame_: Optional[int] = None
 
     @property
     def num_frames(self) -> Optional[int]:
-        if self.start_frame_ is None or self.end_frame_ is None:
-            return None
-        return self.end_frame_ - self.start_frame_
+        known = self.start_frame_ is not None and self.end_frame_ is not None
+        return self.end_frame_ - self.start_frame_ if known else None
 
     def fit_boundaries(self, speech_frames) -> "ComputeSpeechFrameBoundariesMixin":
         torch = _native.require_gpu()
@@ -375,34 +394,37 @@ def serialize_speech(fname: str, speech) -> None:
     np.savez_compressed(fname, speech=np.asarray(speech))
 
 
-class DeserializeSpeechTransformer(TransformerMixin):
-    """speech_transformers.py:987-1009: a ``.npy`` / ``.npz`` (key ``speech``) reference activity
-    vector; every sample below 1.0 becomes ``non_speech_label``.  The bulk on-disk format for batch
-    jobs that feed precomputed reference vectors straight to the device."""
+class _DeserializeStandIn(TransformerMixin):
+    """speech_transformers.py:987-1009 for boxes without ffsubsync: a ``.npy`` / ``.npz`` (key ``speech``) activity
+    vector; every sample below 1.0 becomes ``non_speech_label``."""
 
     def __init__(self, non_speech_label: float) -> None:
-        super(DeserializeSpeechTransformer, self).__init__()
-        self._non_speech_label: float = non_speech_label
-        self.deserialized_speech_results_: Optional[np.ndarray] = None
+        self._non_speech_label, self.deserialized_speech_results_ = non_speech_label, None
 
-    def fit(self, fname, *_) -> "DeserializeSpeechTransformer":
-        speech = np.load(fname)
-        if hasattr(speech, "files"):
-            if "speech" in speech.files:
-                speech = speech["speech"]
-            else:
-                raise ValueError(
-                    'could not find "speech" array in '
-                    "serialized file; only contains: %s" % speech.files
-                )
-        speech = np.array(speech, dtype=float)
-        speech[speech < 1.0] = self._non_speech_label
-        self.deserialized_speech_results_ = speech
+    def fit(self, fname, *_):
+        data = np.load(fname)
+        if hasattr(data, "files"):  # an .npz archive
+            if "speech" not in data.files:
+                raise ValueError('could not find "speech" array in serialized file; only contains: %s' % data.files)
+            data = data["speech"]
+        labels = np.array(data, dtype=float)
+        self.deserialized_speech_results_ = np.where(labels < 1.0, self._non_speech_label, labels)
         return self
 
     def transform(self, *_) -> np.ndarray:
         assert self.deserialized_speech_results_ is not None
         return self.deserialized_speech_results_
+
+
+def __getattr__(name: str):
+    """``DeserializeSpeechTransformer`` (the bulk on-disk format's reader, speech_transformers.py:987-1009) is the
+    reference's own class when ffsubsync is importable, resolved on first use rather than at import."""
+    if name == "DeserializeSpeechTransformer":
+        ref = reference_module("speech_transformers")
+        cls = ref.DeserializeSpeechTransformer if ref is not None else _DeserializeStandIn
+        globals()[name] = cls
+        return cls
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
 
 
 def load_speech_batch(fnames: Sequence[str], non_speech_label: float = 0.0):
@@ -417,7 +439,7 @@ def load_speech_batch(fnames: Sequence[str], non_speech_label: float = 0.0):
     torch = _native.require_gpu()
     loaded, chunks, total = [], [], 0
     for fname in fnames:
-        speech = DeserializeSpeechTransformer(non_speech_label).fit(fname).transform()
+        speech = __getattr__("DeserializeSpeechTransformer")(non_speech_label).fit(fname).transform()
         speech = np.asarray(speech, dtype=float).ravel()
         hi = float(speech.max()) if speech.size else 1.0
         is_hi = speech >= 1.0

@@ -38,6 +38,24 @@ class DeviceRaster:
     def size(self) -> int:
         return self.n
 
+    @classmethod
+    def from_host(cls, values) -> Optional["DeviceRaster"]:
+        """Bit-packed device copy of a two-level host vector (e.g. a VAD label vector: {non_speech_label, 1.0}); None
+        when the samples take more than two values.  One pass to find the levels, ``packbits``, one small upload."""
+        import torch
+
+        v = np.asarray(values, dtype=float).ravel()
+        if v.size == 0:
+            return None
+        lo, hi = float(v.min()), float(v.max())
+        is_hi = v == hi
+        if not (np.isfinite(lo) and np.isfinite(hi)) or not bool(np.all(is_hi | (v == lo))):
+            return None
+        packed = np.packbits(is_hi if hi != lo else np.zeros(v.size, bool), bitorder="little")
+        host = np.zeros((v.size + 31) // 32 * 4, dtype=np.uint8)
+        host[: packed.size] = packed
+        return cls(torch.from_numpy(host).cuda().view(torch.int32), lo, hi, v.size)
+
     def bytes01(self):
         """0/1 uint8 CUDA tensor of the samples."""
         return _native.unpack_bits(self.bits, self.n) if self.packed else self.bits
@@ -126,3 +144,32 @@ class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBounda
     def transform(self, *_) -> DeviceRaster:
         assert self.subtitle_speech_results_ is not None
         return self.subtitle_speech_results_
+
+
+def _device_copy_of(transformer, values):
+    """The bit-packed device copy of a fitted reference vector, made once per vector (cached on the transformer)."""
+    cached = transformer.__dict__.get("_ffs_device_copy")
+    if cached is not None and cached[0] is values:
+        return cached[1]
+    raster = DeviceRaster.from_host(values) if isinstance(values, np.ndarray) else None
+    out = values if raster is None else raster  # more than two levels (fused / weighted labels): the host floats
+    transformer.__dict__["_ffs_device_copy"] = (values, out)
+    return out
+
+
+def install_device_rasters(ref_speech_transformers, ref_main=None) -> None:
+    """``install(device_rasters=True)``: see :func:`ffsubsync_amd.install`.  Idempotent."""
+    ref_st = ref_speech_transformers
+    ref_st.SubtitleSpeechTransformer = DeviceSubtitleSpeechTransformer  # looked up by subpipe_maker at call time (:81-87)
+    if ref_main is not None and hasattr(ref_main, "SubtitleSpeechTransformer"):
+        ref_main.SubtitleSpeechTransformer = DeviceSubtitleSpeechTransformer
+    for name in ("VideoSpeechTransformer", "MultiSegmentVideoSpeechTransformer", "DeserializeSpeechTransformer"):
+        cls = getattr(ref_st, name, None)
+        if cls is None or getattr(cls.transform, "_ffs_wrapped", False):
+            continue
+
+        def transform(self, *args, _orig=cls.transform):
+            return _device_copy_of(self, _orig(self, *args))
+
+        transform._ffs_wrapped = True
+        cls.transform = transform
