@@ -50,14 +50,31 @@ def parse():
                     help="files in the end-to-end PCM -> VAD -> rasterise -> align figure (0 = skip)")
     ap.add_argument("--skip-secondary", action="store_true",
                     help="headline measurement only (used by the rocprofv3 / PMC runs)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="torch.distributed backend for N > 1.  nccl (= RCCL, the default): one rank per GPU.  gloo: the "
+                         "ranks may share GPUs (rank r runs on device r mod device_count) and the 24-byte records are "
+                         "gathered through host memory -- exercises the sharded N > 1 path on a one-GPU box (RCCL refuses "
+                         "two ranks on one device); not a scaling measurement")
     ap.add_argument("--reference-length", action="store_true",
                     help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
                          "alias-free length the lag window allows")
     return ap.parse_args()
 
 
+def fail_line(args, message, world=None):
+    """A bench run that cannot measure what was asked for says so in the JSON line (and exits non-zero) instead of
+    measuring something else."""
+    print(json.dumps({"metric": "alignments/sec (2 h@100 Hz, 7 framerate ratios)", "value": None, "unit": "7-ratio solves/s",
+                      "n_gpus": world or args.gpus, "steps": args.steps, "warmup": args.warmup, "error": message}), flush=True)
+    raise SystemExit(2)
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: run this script under torch.distributed.run, one process per GPU."""
+    import torch
+
+    if args.backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        fail_line(args, "--gpus %d asked for, %d HIP device(s) visible" % (args.gpus, torch.cuda.device_count()))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -231,16 +248,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
+    n_dev_visible = torch.cuda.device_count()
+    if n_dev_visible == 0:
+        fail_line(args, "no HIP device visible", world)
+    if args.backend == "nccl" and local_rank >= n_dev_visible:
+        fail_line(args, "rank %d (local rank %d) has no GPU: %d HIP device(s) visible; one rank per GPU with RCCL"
+                  % (rank, local_rank, n_dev_visible), world)
+    device = local_rank % n_dev_visible
+    torch.cuda.set_device(device)
     dist = None
     force_dist = os.environ.get("FFS_BENCH_FORCE_DIST") == "1"  # exercise the RCCL path with one rank
     use_dist = world > 1 or force_dist
+    host_coll = args.backend == "gloo"  # control collectives and the record gather go through host memory
     if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if host_coll:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    coll_dev = "cpu" if host_coll else "cuda"
 
     from ffsubsync_amd import _native, batch
     from workloads import synth
@@ -265,7 +294,14 @@ def main():
     profile = not args.no_profile and args.streams == 1
     gather_impl = None
     comm = None
+    ranks_seen = [0]
     if use_dist:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, device, socket.gethostname()))
+        ranks_seen = [list(x) for x in seen]
+    if use_dist and host_coll:
+        gather_impl = "torch.distributed (gloo) all_gather_into_tensor through host memory [--backend gloo: ranks may share a GPU]"
+    elif use_dist:
         # the library's own collective (ffs_gather_results, RCCL C API); checked once against torch's
         try:
             comm = batch.make_comm(rank, world)
@@ -281,7 +317,7 @@ def main():
             comm = None
             gather_impl = "torch.distributed.all_gather_into_tensor (ffs_comm_create failed: %s)" % repr(exc)[:120]
         # every rank must take the same branch
-        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=coll_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0 and comm is not None:
             comm.close()
@@ -305,6 +341,10 @@ def main():
             if use_dist and cands == n_cand:
                 if comm is not None:
                     comm.gather_pair_results(pair_out, gathered)
+                elif host_coll:
+                    host_all = torch.empty(world * per * 24, dtype=torch.uint8)
+                    dist.all_gather_into_tensor(host_all, pair_out.cpu())
+                    gathered.copy_(host_all)
                 else:
                     dist.all_gather_into_tensor(gathered, pair_out)
 
@@ -320,7 +360,7 @@ def main():
         ktimes = aligner.plan.profile_read() if profile else {}
         aligner.plan.profile(False)
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         seg = (n_fft % 3 == 0 and n_fft // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1"
@@ -425,6 +465,9 @@ def main():
             "arithmetic": "fp32 transforms nominate lags; integer (popcount) re-evaluation of the winners: offsets and "
                           "scores are exact",
             "parallelism": ("pairs sharded by rank, %s of 24 B/pair results" % gather_impl) if use_dist else "single GPU",
+            "gather_impl": gather_impl,
+            "ranks_seen": ranks_seen,  # [rank, device, host] of every rank, all-gathered
+            "devices_used": len({(x[2], x[1]) for x in ranks_seen}) if use_dist else 1,
         },
         "offset_match": {"pairs_matching_reference_golden": "%d/%d" % (g_ok, g_total),
                          "golden": "tests/golden/headline_golden.json (unmodified reference, bench seeds 0..255): winning index and "

@@ -194,13 +194,12 @@ def gather_pair_results(local, n_total: int, world: int, group=None, comm: "Opti
     return out[: n_total * 24]
 
 
-def make_comm(rank: int, world: int, store_key: str = "ffs_comm_id") -> "_native.Comm":
-    """``ffs_comm_create`` bootstrapped through torch.distributed's default store: rank 0 publishes the
-    128-byte RCCL unique id, everyone joins."""
+def make_comm(rank: int, world: int, group=None) -> "_native.Comm":
+    """``ffs_comm_create`` bootstrapped over an initialised torch.distributed group: rank 0 creates the 128-byte
+    RCCL unique id and broadcasts it (public API only; a fresh id per call, so communicators can be created
+    repeatedly in one process group), everyone joins."""
     import torch.distributed as dist
 
-    store = dist.distributed_c10d._get_default_store()
-    if rank == 0:
-        store.set(store_key, _native.Comm.unique_id())
-    uid = bytes(store.get(store_key))
-    return _native.Comm(rank, world, uid)
+    box = [_native.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return _native.Comm(rank, world, bytes(box[0]))

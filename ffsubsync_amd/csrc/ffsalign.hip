@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/ffsubsync_amd.h"
@@ -1447,9 +1448,9 @@ struct RcclApi {
 };
 RcclApi* rccl_api() {
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
+    static std::once_flag once;
+    static std::string load_error;
+    std::call_once(once, [] {
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names)
             if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // the copy this process already has
@@ -1460,9 +1461,16 @@ RcclApi* rccl_api() {
             api.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(api.handle, "ncclAllGather");
             api.CommDestroy = (int (*)(void*))dlsym(api.handle, "ncclCommDestroy");
             api.GetErrorString = (const char* (*)(int))dlsym(api.handle, "ncclGetErrorString");
+        } else {
+            const char* e = dlerror();  // may be null
+            load_error = e ? e : "no loader message";
         }
+    });
+    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) {
+        fail(FFS_E_RCCL, "librccl.so.1 could not be loaded or lacks the nccl* entry points: %s",
+             load_error.empty() ? "symbol missing" : load_error.c_str());
+        return nullptr;
     }
-    if (!api.handle || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) return nullptr;
     return &api;
 }
 int rccl_fail(RcclApi* a, const char* what, int code) {
@@ -1478,7 +1486,7 @@ struct ffs_comm {
 int ffs_comm_unique_id(ffs_comm_id* id_out) {
     if (!id_out) return fail(FFS_E_INVALID, "id_out is null");
     RcclApi* a = rccl_api();
-    if (!a) return fail(FFS_E_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+    if (!a) return FFS_E_RCCL;  // message set by rccl_api()
     const int rc = a->GetUniqueId(id_out);
     return rc ? rccl_fail(a, "ncclGetUniqueId", rc) : FFS_OK;
 }
@@ -1487,7 +1495,7 @@ int ffs_comm_create(int device, int rank, int world_size, const ffs_comm_id* id,
     if (!out || !id || world_size < 1 || rank < 0 || rank >= world_size) return fail(FFS_E_INVALID, "bad argument");
     *out = nullptr;
     RcclApi* a = rccl_api();
-    if (!a) return fail(FFS_E_RCCL, "librccl.so.1 could not be loaded: %s", dlerror());
+    if (!a) return FFS_E_RCCL;  // message set by rccl_api()
     HIP_TRY(hipSetDevice(device));
     ffs_comm* c = new ffs_comm();
     c->device = device;

@@ -81,3 +81,75 @@ def test_vad_bits_chunk_by_chunk_into_one_word_buffer(torch):
         _native.vad_energy_bits(dev[o:o + chunk], 480, 50.0, out=out, first_frame=o // 480)
     assert torch.equal(out, whole)
     assert np.array_equal(_native.unpack_bits(out, nf).cpu().numpy(), (vo.chunked_detect(pcm) > 0.5).astype(np.uint8))
+
+
+def _launch(nproc, argv, timeout=900):
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _golden():
+    import json
+
+    return {g["seed"]: g for g in json.load(open(os.path.join(HERE, "golden", "headline_golden.json")))["pairs"]}
+
+
+def test_two_ranks_on_one_gpu_sharded_solve_equals_single_process_and_goldens(torch, tmp_path):
+    """The N > 1 path with the HIP solver in every rank: two processes share cuda:0, each solves its
+    shard_bounds slice of five 2 h x 7-ratio bench pairs (5 is not divisible by 2) with BatchAligner, records gathered
+    over a gloo group == the single-process records == the unmodified reference's goldens."""
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
+
+    n_pairs = 5
+    out = tmp_path / "records.npy"
+    run = _launch(2, [os.path.join(HERE, "two_rank_worker.py"), str(out), str(n_pairs)])
+    assert run.returncode == 0 and "RANKS" in run.stdout, (run.stdout[-2000:], run.stderr[-3000:])
+    got = np.load(out).view(_native.PAIR_RESULT_DTYPE)
+    assert got.size == n_pairs
+    db = synth.build_device_batch([synth.make_pair_spec(s) for s in range(n_pairs)], packed=True)
+    al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=4)
+    _, single = al.solve(db)
+    al.close()
+    assert np.array_equal(got.view(np.uint8), single.view(np.uint8))  # bit-identical 24-byte records
+    gold = _golden()
+    for s in range(n_pairs):
+        g = gold[s]
+        assert (int(got[s]["best_cand"]), int(got[s]["offset"])) == (g["index"], g["offset"])
+        assert abs(float(got[s]["score"]) - float(g["score"])) <= 1e-5 * abs(float(g["score"]))
+
+
+def test_bench_main_with_two_ranks_on_one_gpu_and_loud_failure_without_devices(torch):
+    """bench.py's own N > 1 branch (sharding by rank, barrier + max-over-ranks timing, record gather, rank-0 JSON line)
+    executed with WORLD_SIZE=2 on one GPU (--backend gloo), and the JSON error line when RCCL's one-rank-per-GPU
+    cannot be had (--gpus 2 on a one-GPU box)."""
+    import json
+
+    run = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "32", "--steps", "2",
+                      "--warmup", "1", "--pairs-in-flight", "32", "--skip-secondary", "--cpu-pairs", "0"])
+    assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-3000:])
+    line = json.loads(run.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["scaling"] == "weak"
+    assert [r[0] for r in line["config"]["ranks_seen"]] == [0, 1] and "gloo" in line["config"]["gather_impl"]
+    assert line["gathered_records"] == 64 and line["gathered_best_cand_valid"] == 64
+    assert line["offset_match"]["pairs_matching_reference_golden"] == "32/32"  # rank 0's pairs, seeds 0..31
+    for scaling in ("strong",):
+        run = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--pairs", "33", "--steps", "1",
+                          "--warmup", "1", "--pairs-in-flight", "32", "--skip-secondary", "--cpu-pairs", "0",
+                          "--scaling", scaling])
+        assert run.returncode == 0, (run.stdout[-2000:], run.stderr[-3000:])
+        line = json.loads(run.stdout.strip().splitlines()[-1])
+        assert line["scaling"] == "strong" and line["config"]["pairs_per_gpu"] == 17 and line["gathered_best_cand_valid"] == 33
+    if torch.cuda.device_count() < 2:
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT,
+                             capture_output=True, text=True, timeout=300)
+        assert run.returncode == 2
+        line = json.loads(run.stdout.strip().splitlines()[-1])
+        assert line["value"] is None and "HIP device" in line["error"] and line["n_gpus"] == 2

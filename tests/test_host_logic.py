@@ -267,9 +267,12 @@ def test_bench_starts_itself_under_the_launcher(monkeypatch):
         seen["cmd"], seen["env"] = cmd, env
         return 7
 
+    import torch
+
     monkeypatch.setattr(bench.subprocess, "call", fake_call)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--scaling", "strong"])
     monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
@@ -279,6 +282,27 @@ def test_bench_starts_itself_under_the_launcher(monkeypatch):
     assert int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--scaling", "strong"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
+
+
+def test_bench_says_so_when_the_gpus_asked_for_are_not_there(monkeypatch, capsys):
+    """`--gpus N` with fewer than N visible devices: ONE JSON line with value null and an error text, exit code 2 --
+    never a silent measurement of something else."""
+    import importlib
+    import json
+    import sys
+
+    import torch
+
+    bench = importlib.import_module("bench")
+    monkeypatch.setattr(bench.subprocess, "call", lambda *a, **k: pytest.fail("must not launch"))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    monkeypatch.delenv("RANK", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 2
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert line["value"] is None and line["n_gpus"] == 8 and "8 asked for, 1 HIP device" in line["error"]
 
 
 def test_strong_and_weak_scaling_shards():
