@@ -499,8 +499,7 @@ def main():
         mm_launch = per_kernel[dom]["must_move_bytes_per_launch"]
         result["roofline"] = {
             "kernel": {"pass_a": "k_pass_a", "pass_c": "k_pass_c_pruned",
-                       "mid": ("k_mid_seg_one" if os.environ.get("FFS_MID_SEG_ONE", "1") != "0" and (n_cand + 1) // 2 <= 4
-                               else "k_mid_seg_pipe") if seg_mode else "k_mid"}[dom],
+                       "mid": ("k_mid_seg_one" if (n_cand + 1) // 2 <= 4 else "k_mid_seg_pipe") if seg_mode else "k_mid"}[dom],
             "bound": "hbm",
             "achieved": per_kernel[dom]["must_move_GBps"],
             "peak": HBM_PEAK / 1e9,

@@ -306,6 +306,10 @@ def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Op
     key = (dev, int(n_fft), int(pairs_in_flight), int(max_cand))
     cache = _plan_cache
     plan = cache.plans.get(key)
+    if plan is not None and getattr(plan, "handle", None) is None:  # closed behind the cache's back: forget it
+        del cache.plans[key]
+        cache.order.remove(key)
+        plan = None
     if plan is None:
         plan = Plan(n_fft, pairs_in_flight, max_cand, dev)  # hipMalloc + table upload: no lock held
         cache.plans[key] = plan

@@ -31,14 +31,22 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
-constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD (default; FFS_MID_SEG_PAIRMAP=0 turns it off)
-constexpr int DBG_NO_STORE = 32768;  // FFS_MID_DEBUG=4: the mid pass keeps its results (read-only kernel)
-constexpr int DBG_NO_FFT = 256, DBG_HOT_MEM = 512;  // section experiments of the mid pass (FFS_MID_DEBUG=1 / 2 / 3)
-// section experiments of pass A (FFS_PASS_A_DEBUG bit mask; WRONG RESULTS, timing only): no stores / no input loads /
-// unit twiddles instead of the table loads / every block stores into tile 0 of slot 0 (writes stay in L2)
+constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD
+// Section experiments (timing only, WRONG RESULTS): compiled in by `make lab` (-DFFS_LAB -> libffsalign_lab.so) and
+// selected there through FFS_MID_DEBUG / FFS_PASS_A_DEBUG; the product library contains none of it -- FFS_LABF() is a
+// constant false and the branches fold away.
+constexpr int DBG_NO_STORE = 32768;                 // mid pass keeps its results (read-only kernel)
+constexpr int DBG_NO_FFT = 256, DBG_HOT_MEM = 512;  // mid pass without row transforms / every pair on pair 0's buffers
+// pass A: no stores / no input loads / unit twiddles instead of the table loads / every block stores into tile 0 of
+// slot 0 (writes stay in L2) / every block reads transform 0's vectors (input reads become L2 hits)
 constexpr int DBG_PA_NO_STORE = 1024, DBG_PA_NO_INPUT = 2048, DBG_PA_NO_TW = 4096, DBG_PA_HOT_STORE = 8192;
-constexpr int DBG_PA_HOT_INPUT = 16384;  // every block reads transform 0's vectors (input reads become L2 hits)
-constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles (default; FFS_PASS_A_STORE8=0 turns it off)
+constexpr int DBG_PA_HOT_INPUT = 16384;
+#ifdef FFS_LAB
+#define FFS_LABF(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define FFS_LABF(flags, bit) (false)
+#endif
+constexpr int STORE_8B = 4;   // pass A: plain 8-byte stores for 64-column tiles
 
 struct XformDesc {  // one packed transform (slot 0 of a pair is the reference: b = a, len_b = 0)
     const void* a;
@@ -335,7 +343,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // tiles instead of every eighth one -- otherwise each input line is fetched by up to 8 L2s.
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int n2 = tile * C + c;
-    const XformDesc d = descs[(half_flags & DBG_PA_HOT_INPUT) ? 0 : blockIdx.y];
+    const XformDesc d = descs[FFS_LABF(half_flags, DBG_PA_HOT_INPUT) ? 0 : blockIdx.y];
     // every table value this thread needs is requested up front, together with the inputs
     // (tiles of 64+ columns: u is the wave's row phase, the stage twiddles are wave-uniform -> scalar registers)
     constexpr bool TWS = (C % 64 == 0) && !CS::R3 && (LT > 1) && (LT < 16);
@@ -352,7 +360,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // each, which trades eleven table loads per thread for eleven packed complex multiplies.
     cf wq[16];
     if constexpr (!CS::R3) {
-        if (half_flags & DBG_PA_NO_TW) {
+        if FFS_LABF(half_flags, DBG_PA_NO_TW) {
             wq[0] = wq[1] = wq[2] = wq[4] = wq[8] = mk(1.0f, 0.0f);
         } else {
             wq[0] = tb[u * N2 + n2];
@@ -428,7 +436,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             // only dwords that hold a valid sample (bits off+lead .. off+len-1) are touched
             const int w_lo = (off + lead) >> 5, w_hi = (off + len - 1) >> 5;
             unsigned d0 = 0, d1 = 0;
-            if (len > lead && !(half_flags & DBG_PA_NO_INPUT)) {
+            if (len > lead && !FFS_LABF(half_flags, DBG_PA_NO_INPUT)) {
                 if (w >= w_lo && w <= w_hi) d0 = src[w];
                 if (w + 1 >= w_lo && w + 1 <= w_hi) d1 = src[w + 1];
             }
@@ -461,7 +469,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
     cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
-    if (half_flags & DBG_PA_HOT_STORE) out = work;
+    if FFS_LABF(half_flags, DBG_PA_HOT_STORE) out = work;
     // HALF_REF: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
     // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all.
     // HALF_LAST: with an odd candidate count the last packed transform carries ONE real candidate; its
@@ -540,11 +548,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         // one add per store; the row guard only exists for the two half slots (block-uniform choice)
         // (byte offsets in 32-bit arithmetic -- 2^27 at most -- so that the stores can use the scalar base +
         // 32-bit lane offset addressing mode instead of 64-bit address pairs)
-        const unsigned o0 = ((unsigned)tile_base<L, C>((half_flags & DBG_PA_HOT_STORE) ? 0 : tile, c, log2CL) +
+        const unsigned o0 = ((unsigned)tile_base<L, C>(FFS_LABF(half_flags, DBG_PA_HOT_STORE) ? 0 : tile, c, log2CL) +
                              ((unsigned)ob << log2CL)) * (unsigned)sizeof(cf);
         const unsigned ostep = ((unsigned)CS::OSTEP << log2CL) * (unsigned)sizeof(cf);
         char* outb = reinterpret_cast<char*>(out);
-        if (half_flags & DBG_PA_NO_STORE) {
+        if FFS_LABF(half_flags, DBG_PA_NO_STORE) {
             // keep the values alive without memory traffic
 #pragma unroll
             for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(v[q]));
@@ -726,98 +734,15 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 // For every candidate slot the spectrum products of the blocks are ADDED, then one row transform goes
 // back:  acc = sum_k FFT(S_k row) * conj(FFT(R_k row)) / N.  The result replaces group 0's slot (its
 // own input row was consumed two blocks earlier), so mid writes and the last pass reads 1/n_blocks of
-// what the unsegmented pipeline moves.  The reference rows are transformed again for every slot
-// (keeping n_blocks spectra would not fit in registers); the row-transform count per pair is the same
-// as in k_mid at three times the transform length.
-template <int L>
-__global__ __launch_bounds__(256, 2) void k_mid_seg(cf* __restrict__ work, int N1, int log2C, long long N, int n_slots,
-                                                    int n_blocks, float inv_n, const cf* __restrict__ tw,
-                                                    const cf* __restrict__ tb, const cf* __restrict__ ts, int half_flags) {
-    static_assert(L == 4096, "one row per 256-thread block");
-    const int ref_half = half_flags & HALF_REF;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int LT = L / 16;
-    const int u = threadIdx.x;
-    // PAIR_ROWS: rows k1 and N1-k1 read the same stored reference rows (one of them mirrored).  Workgroup b
-    // runs on XCD b % 8, so give the two rows of a pair block indices 8 apart: same XCD (same L2), dispatched
-    // back to back -- the second read of every reference row can then be an L2 hit instead of HBM traffic.
-    // Pair j = (j, N1-j) for 0 < j < N1/2, pair 0 = the two self-mirrored rows (0, N1/2).
-    int k1 = blockIdx.x;
-    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {
-        const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
-        k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
-    }
-    RowAddr<L> addr(0, u);
-    const int C = 1 << log2C;
-    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
-    // HALF_LAST: rows above N1/2 of the single-candidate slot (the last one) are never needed
-    const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
-    if (s_end <= 1) return;
-    const bool mirrored = ref_half && k1 > N1 / 2;
-    const unsigned off0 = (unsigned)(((u >> log2C) * N1 + k1) * C + (u & (C - 1)));
-    const unsigned offr = mirrored ? (unsigned)(((u >> log2C) * N1 + (N1 - k1)) * C + (u & (C - 1))) : off0;
-    const size_t qstride = (size_t)LT * N1;
-    const float sgn = mirrored ? inv_n : -inv_n;
-    TwRegs<L> twr;
-    twr.load(tw, u);
-    const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
-    // Two candidate slots per sweep over the blocks: each reference row is then loaded and transformed
-    // for two slots instead of one (half the re-reads, 22 instead of 28 row transforms per row for seven
-    // candidates) at the price of a second accumulator row -- two blocks per CU instead of three, which
-    // costs this kind of kernel about 9 %.
-    for (int s = 1; s < s_end; s += 2) {
-        const bool two = s + 1 < s_end;
-        cf acc_a[16], acc_b[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc_a[q] = acc_b[q] = mk(0.f, 0.f);
-        for (int k = 0; k < n_blocks; ++k) {
-            cf* grp = base + (size_t)k * n_slots * N;
-            cf rr[16], v[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) rr[q] = (grp + q * qstride)[offr];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)s * N + q * qstride)[off0];
-            fft_regs<L>(rr, lds, u, addr, twr);
-            if (mirrored) {  // conj(R[k1][k2]) = R[N1-k1][N2-1-k2]: the mirror row, read backwards
-                __syncthreads();
-                mirror_store(rr, lds, addr, std::make_integer_sequence<int, 16>{});
-                __syncthreads();
-                mirror_load(rr, lds, addr, std::make_integer_sequence<int, 16>{});
-            }
-#pragma unroll
-            for (int q = 0; q < 16; ++q) rr[q] = mk(rr[q].x * inv_n, rr[q].y * sgn);  // conj(R_k)/N
-            fft_regs<L>(v, lds, u, addr, twr);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) acc_a[q] = cmac(acc_a[q], v[q], rr[q]);
-            if (two) {
-#pragma unroll
-                for (int q = 0; q < 16; ++q) v[q] = (grp + (size_t)(s + 1) * N + q * qstride)[off0];
-                fft_regs<L>(v, lds, u, addr, twr);
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc_b[q] = cmac(acc_b[q], v[q], rr[q]);
-            }
-        }
-        fft_regs<L>(acc_a, lds, u, addr, twr);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);  // W_N^(k1*(u + LT*q))
-            (base + (size_t)s * N + q * qstride)[off0] = cmul(acc_a[q], w);
-        }
-        if (two) {
-            fft_regs<L>(acc_b, lds, u, addr, twr);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
-                (base + (size_t)(s + 1) * N + q * qstride)[off0] = cmul(acc_b[q], w);
-            }
-        }
-    }
-}
-
-// --------------------------------------------------------------------------------------------
-// Block-segmented mid pass, software-pipelined: same arithmetic as k_mid_seg (two candidate slots per sweep),
-// but the sixteen loads of the NEXT row (reference row of the next block, or the next slot's row) are issued
+// what the unsegmented pipeline moves.
+// PAIR_ROWS: rows k1 and N1-k1 read the same stored reference rows (one of them mirrored).  Workgroup b
+// runs on XCD b % 8, so the two rows of a pair get block indices 8 apart: same XCD (same L2), dispatched
+// back to back -- the second read of every reference row can then be an L2 hit instead of HBM traffic.
+// Pair j = (j, N1-j) for 0 < j < N1/2, pair 0 = the two self-mirrored rows (0, N1/2).
+//
+// k_mid_seg_pipe (solves with more than four packed candidate slots): two candidate slots per sweep over the
+// blocks -- each reference row is loaded and transformed for two slots -- with two accumulator rows;
+// software-pipelined: the sixteen loads of the NEXT row (reference row of the next block, or the next slot's row) are issued
 // before the transform of the current one, so the HBM latency of every row hides behind a row transform
 // instead of stalling the block (two blocks per CU = two waves per SIMD leave little else to switch to).
 // Rows alternate between two register buffers; the item order of a sweep is R_0 A_0 B_0 R_1 A_1 B_1 ...
@@ -834,16 +759,14 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
     cf* s_rr = lds + RowAddr<L>::ROW_ELEMS;  // [16][LT]: conj(R_k)/N of the current block, thread-private columns
     const int u = threadIdx.x;
     int k1 = blockIdx.x;
-    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see k_mid_seg
+    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see above
         const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
         k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
     }
     RowAddr<L> addr(0, u);
     const int C = 1 << log2C;
-    // section experiments (profiles/mid_sections.py): DBG_HOT_MEM makes every pair use pair 0's buffers (all
-    // traffic becomes L2 hits: compute + LDS + issue only), DBG_NO_FFT drops the row transforms (memory only)
-    const bool no_fft = half_flags & DBG_NO_FFT;
-    cf* base = work + (size_t)((half_flags & DBG_HOT_MEM) ? 0 : blockIdx.y) * n_blocks * n_slots * N;
+    constexpr bool no_fft = false;
+    cf* base = work + (size_t)blockIdx.y * n_blocks * n_slots * N;
     const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
     if (s_end <= 1) return;
     const bool mirrored = ref_half && k1 > N1 / 2;
@@ -966,14 +889,16 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __rest
     cf rr[RR_REGS ? 16 : 1];
     const int u = threadIdx.x;
     int k1 = blockIdx.x;
-    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see k_mid_seg
+    if ((half_flags & PAIR_ROWS) && N1 % 16 == 0) {  // mirror-row pairs on one XCD, see above
         const int b = blockIdx.x, j = 8 * (b / 16) + (b % 8), second = (b / 8) & 1;
         k1 = j == 0 ? (second ? N1 / 2 : 0) : (second ? N1 - j : j);
     }
     RowAddr<L> addr(0, u);
     const int C = 1 << log2C;
-    const bool no_fft = half_flags & DBG_NO_FFT;  // section experiments, see k_mid_seg_pipe
-    cf* base = work + (size_t)((half_flags & DBG_HOT_MEM) ? 0 : blockIdx.y) * n_blocks * n_slots * N;
+    // section experiments (lab build only, profiles/mid_sections.py): DBG_HOT_MEM makes every pair use pair 0's buffers
+    // (all traffic becomes L2 hits: compute + LDS + issue only), DBG_NO_FFT drops the row transforms (memory only)
+    const bool no_fft = FFS_LABF(half_flags, DBG_NO_FFT);
+    cf* base = work + (size_t)(FFS_LABF(half_flags, DBG_HOT_MEM) ? 0 : blockIdx.y) * n_blocks * n_slots * N;
     const int s_end = ((half_flags & HALF_LAST) && k1 > N1 / 2) ? n_slots - 1 : n_slots;
     const int na = s_end - 1;  // candidate slots of this row: 1..4 (the host falls back to k_mid_seg_pipe beyond)
     if (na <= 0) return;
@@ -1047,7 +972,7 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __rest
     for (int a = 0; a < NA; ++a) {
         if (a >= na) break;
         if (!no_fft) fft_regs<L, RowAddr<L>, true>(acc[a], lds, u, addr, twr);
-        if (half_flags & DBG_NO_STORE) {
+        if FFS_LABF(half_flags, DBG_NO_STORE) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(acc[a][q]));
             continue;
@@ -1064,111 +989,11 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __rest
     }
 }
 
-// --------------------------------------------------------------------------------------------
-// mid pass, packed-reference layout (odd candidate counts, N2 = 4096).  The last candidate transform
-// is z = c_last + i*r, so after the row transform  Z[k] = C[k] + i*R[k]  with C, R Hermitian:
-//     R[k] = (Z[k] - conj(Z[N-k])) / 2i,   C[k] = (Z[k] + conj(Z[N-k])) / 2.
-// In the four-step layout k = k1 + N1*k2 mirrors to row N1-k1 (rows 0 and N1/2 mirror onto
-// themselves), element k2 -> N2-1-k2 (row 0: (N2-k2) mod N2).  One block therefore owns the row pair
-// (b, N1-b): for each of the two rows it transforms both rows of the last slot, mirrors the partner
-// through LDS, forms conj(R)/N (kept in registers, as in k_mid) and the product C*conj(R)/N of the
-// last slot itself, then runs the remaining slots exactly like k_mid.  The last slot's pass-A data is
-// left untouched (its result goes to the spare slot), so the second row can recompute from it.
-// Saves one of five pass-A transforms and one of five row reads per pair; same number of FFTs.
-// ROW0 = true: the block of row 0 (mirror index (N2-k2) mod N2, not separable into base + constant),
-// launched on its own so that its extra address registers do not size the main kernel.
-template <int L, bool ROW0>
-__global__ __launch_bounds__(256, 3) void k_mid_packed(cf* __restrict__ work, int N1, int log2CL, long long N,
-                                                       int n_packed, float inv_n, const cf* __restrict__ tw,
-                                                       const cf* __restrict__ tb, const cf* __restrict__ ts) {
-    static_assert(L == 4096, "one row per 256-thread block");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cf* lds = reinterpret_cast<cf*>(smem);
-    constexpr int LT = L / 16;
-    const int u = threadIdx.x;
-    RowAddr<L> addr(0, u);
-    const int CL = 1 << log2CL;
-    cf* base = work + (size_t)blockIdx.y * (n_packed + 1) * N;
-    const cf* zin = base + (size_t)(n_packed - 1) * N;  // last candidate transform (+ i * reference)
-    cf* zout = base + (size_t)n_packed * N;             // its result
-    const size_t qstride = (size_t)LT * N1;
-    auto off0 = [&](int k1) { return (unsigned)(((u >> log2CL) * N1 + k1) * CL + (u & (CL - 1))); };
+// Slot map: a pair owns n_slots = 1 + n_packed consecutive length-N buffers -- slot 0 = the reference transform,
+// slot 1 + k = packed candidate transform k (updated in place by the mid pass).
+FFS_DEV int slot_stride(int n_slots) { return n_slots; }
+FFS_DEV int cand_slot(int, int kp, int) { return 1 + kp; }
 
-    TwRegs<L> twr;
-    twr.load(tw, u);
-    const int ka = ROW0 ? 0 : (int)blockIdx.x + 1, kb = (N1 - ka) % N1;
-    const int halves = (ka == kb) ? 1 : 2;
-    const float h = 0.5f * inv_n;
-    for (int half = 0; half < halves; ++half) {
-        const int k1 = half ? kb : ka, kp = half ? ka : kb;
-        const unsigned o1 = off0(k1), op = off0(kp);
-        cf A[16], B[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) A[q] = (zin + q * qstride)[o1];
-        fft_regs<L>(A, lds, u, addr, twr);
-        if (kp != k1) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) B[q] = (zin + q * qstride)[op];
-            fft_regs<L>(B, lds, u, addr, twr);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) B[q] = A[q];
-        }
-        // mirror the partner row through LDS: B[q] <- Z_partner[mirror of (u + LT*q)]
-        __syncthreads();
-        mirror_store(B, lds, addr, std::make_integer_sequence<int, 16>{});
-        __syncthreads();
-        if constexpr (ROW0) {
-#pragma unroll
-            for (int q = 0; q < 16; ++q) B[q] = lds[addr.at((L - (u + LT * q)) & (L - 1))];
-        } else {
-            mirror_load(B, lds, addr, std::make_integer_sequence<int, 16>{});
-        }
-        // A = Z, B = Z mirrored.  conj(R)/N = ((A.y + B.y), (A.x - B.x)) / 2N;  C = ((A.x + B.x), (A.y - B.y)) / 2
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf rr = mk((A[q].y + B[q].y) * h, (A[q].x - B[q].x) * h);
-            const cf cc = mk((A[q].x + B[q].x) * 0.5f, (A[q].y - B[q].y) * 0.5f);
-            A[q] = cmul(cc, rr);
-            B[q] = rr;
-        }
-        const cf wb = tb[(size_t)k1 * LT + u];  // W_N^(k1*u)
-        fft_regs<L>(A, lds, u, addr, twr);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
-            (zout + q * qstride)[o1] = cmul(A[q], w);
-        }
-        for (int s = 0; s < n_packed - 1; ++s) {
-            cf* buf = base + (size_t)s * N;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) A[q] = (buf + q * qstride)[o1];
-            fft_regs<L>(A, lds, u, addr, twr);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) A[q] = cmul(A[q], B[q]);
-            fft_regs<L>(A, lds, u, addr, twr);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const cf w = (q == 0) ? wb : cmul(wb, ts[k1 * 16 + q]);
-                (buf + q * qstride)[o1] = cmul(A[q], w);
-            }
-        }
-    }
-}
-
-// Slot maps.  A pair owns n_packed + 1 consecutive length-N buffers.  The last-pass kernels receive
-// the map as one integer:  n_slots > 0: "separate reference" layout -- slot 0 = reference transform,
-// slot 1+k = candidate transform k (updated in place);  n_slots < 0: "packed reference" layout
-// (-n_slots = n_packed + 1) -- slot k = candidate transform k, except that the last one (which carries
-// the reference in its imaginary half) has its mid-pass result in slot n_packed.
-FFS_DEV int slot_stride(int n_slots) { return n_slots > 0 ? n_slots : -n_slots; }
-FFS_DEV int cand_slot(int n_slots, int kp, int n_packed) {
-    if (n_slots > 0) return 1 + kp;
-    return kp == n_packed - 1 ? n_packed : kp;
-}
-
-// --------------------------------------------------------------------------------------------
-// Lag-window bookkeeping shared by both pass-C variants.
 struct WinParams {
     int lo[2], hi[2];
     float marg[2];

@@ -140,25 +140,16 @@ struct ffs_plan {
     int pass_a_prefetch = 3;  // grid rows the input prefetch blocks of pass A run ahead, byte inputs (FFS_PASS_A_PREFETCH, 0 = off)
     int pass_a_prefetch_bits = 12;  // the same for bit-packed inputs, in rows of a 2^18-point transform (scaled by length)
     bool direct_only = false;
-    bool allow_pruned = true;  // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass (A/B testing)
-    bool allow_packed_ref = false;  // FFS_ENABLE_PACKED_REF=1: reference in the free half of the last transform
-    bool allow_ref_half = true;     // FFS_DISABLE_REF_HALF=1: store all rows of the reference transform
+    // the five run-time knobs; none of them can change a result
+    bool allow_pruned = true;       // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
-    int rescore_seg_bits = 4;       // blocks sharing one exact re-evaluation of bit-packed vectors (FFS_RESCORE_SEG)
-    int pass_a_debug = 0;           // FFS_PASS_A_DEBUG: DBG_PA_* bit mask >> 10 (WRONG RESULTS: timing only)
-    int mid_debug = 0;              // FFS_MID_DEBUG bits: 1 = no row transforms, 2 = L2-resident traffic, 4 = no stores (WRONG RESULTS: timing only)
-    bool mid_seg_one_na2 = true;    // FFS_MID_SEG_ONE_NA1=0: the four-accumulator kernel also for solves with one packed slot
-    int mid_seg_one = 1;            // FFS_MID_SEG_ONE=0|1|2: k_mid_seg_one (single sweep, four accumulator rows; 2 = no load-ahead, 0 = off)
-    bool mid_seg_pipe = true;       // FFS_MID_SEG_PIPE=0: plain k_mid_seg instead of k_mid_seg_pipe (row loads one item ahead)
-    bool mid_seg_pairmap = true;    // FFS_MID_SEG_PAIRMAP=0: rows in index order instead of mirror-row pairs on one XCD
-    bool pass_a_store8 = true;      // FFS_PASS_A_STORE8=0: 16-byte paired stores in pass A for 64-column tiles too
+    bool allow_radix3 = true;       // FFS_DISABLE_RADIX3=1 (read by ffs_plan_length): power-of-two lengths only
+    int lab_flags = 0;              // lab build only (make lab): DBG_* section switches, timing only
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
     cf *tbA = nullptr, *tsA = nullptr;        // pass A inter twiddles: [N1/16][N2], [16][N2]
     cf* tw1h = nullptr;                       // stage tables of the 256-row sub-transforms of a 512-row column
     cf *tbR = nullptr, *tsR = nullptr, *thR = nullptr;  // pass-A twiddles of the three-sub-transforms-per-thread columns (k_pass_a3)
-    bool mid_pf = true;             // FFS_MID_PF=0: k_mid without the load-ahead of the next candidate row (4096-point rows)
-    bool col3r = true;              // FFS_COL3R=0: radix-3 columns through LDS (k_pass_a / k_pass_c) instead of k_pass_a3 / k_pass_c3
     cf *tbM = nullptr, *tsM = nullptr;        // mid inter twiddles:    [N1][N2/16], [N1][16]
     cf* twn1 = nullptr;                       // W_N1^k, k < N1 (pruned pass C)
     cf* work = nullptr;                       // [pairs_in_flight][max_slots][N]
@@ -314,13 +305,13 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     dim3 grid(nt + pf, n_xf);
     hipLaunchKernelGGL((k_pass_a<L, C, DT>), grid, dim3((L / 16) * C), lds, st, descs, p->work, p->N2, (long long)p->N,
                        p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ahead,
-                       (unsigned*)p->bnom, ref_half | (p->pass_a_store8 ? STORE_8B : 0) | p->pass_a_debug);
+                       (unsigned*)p->bnom, ref_half | STORE_8B | (p->lab_flags & (31 << 10)));
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
 
 // columns of length 3*LI with three sub-transforms per thread (bit-packed inputs): tiles of C = 4096/LI columns
-bool col3r_ok(const ffs_plan* p) { return p->col3r && p->tbR && (p->N1 == 192 || p->N1 == 384 || p->N1 == 768 || p->N1 == 512); }
+bool col3r_ok(const ffs_plan* p) { return p->tbR && (p->N1 == 192 || p->N1 == 384 || p->N1 == 768 || p->N1 == 512); }
 int col3r_cols(const ffs_plan* p) { return p->N1 == 512 ? 16 : 4096 / (p->N1 / 3); }
 
 template <int NS, int LI, int C>
@@ -405,11 +396,11 @@ int launch_mid_inst(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, h
 }
 
 // the reference slot may hold only its rows 0..N1/2 (see k_mid) when one block handles one row
-bool ref_half_ok(const ffs_plan* p) { return p->allow_ref_half && p->N2 == 4096 && (p->N2 / 16) >= (1 << p->log2CL) && p->N1 % 2 == 0; }
+bool ref_half_ok(const ffs_plan* p) { return p->N2 == 4096 && (p->N2 / 16) >= (1 << p->log2CL) && p->N1 % 2 == 0; }
 
 int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStream_t st) {
     const bool sep = (p->N2 / 16) >= (1 << p->log2CL);
-    if (p->N2 == 4096 && sep && p->mid_pf) {  // one row per block: candidate rows requested one item ahead
+    if (p->N2 == 4096 && sep) {  // one row per block: candidate rows requested one item ahead
         const size_t lds = row_lds_bytes(4096);
         int rc_lds;
         if ((rc_lds = ensure_lds(p, (const void*)k_mid<4096, true, true>, lds))) return rc_lds;
@@ -434,41 +425,23 @@ int launch_mid(const ffs_plan* p, int n_pairs, int n_slots, int ref_half, hipStr
 int launch_mid_seg(const ffs_plan* sp, int n_pairs, int n_slots, int n_blocks, int ref_half, hipStream_t st) {
     int rc_lds;
     const size_t lds = row_lds_bytes(4096);
-    if (sp->mid_seg_one && n_slots - 1 <= 4) {  // single sweep: all (<= 4) candidate slots accumulate at once
-        const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
-        const int flags = ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0) | sp->mid_debug;
-        if (sp->mid_seg_one >= 1 && n_slots - 1 == 1 && sp->mid_seg_one_na2) {  // one accumulator row: 3 blocks per CU
-            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, false, 1>, lds))) return rc_lds;
-            hipLaunchKernelGGL((k_mid_seg_one<4096, false, 1>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1,
-                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
-                               sp->tbM, sp->tsM, flags);
-        } else if (sp->mid_seg_one == 1) {
-            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, true>, ldsp))) return rc_lds;
-            hipLaunchKernelGGL((k_mid_seg_one<4096, true>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
-                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
-                               sp->tbM, sp->tsM, flags);
-        } else {
-            if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, false>, ldsp))) return rc_lds;
-            hipLaunchKernelGGL((k_mid_seg_one<4096, false>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
-                               sp->log2CL, (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2,
-                               sp->tbM, sp->tsM, flags);
-        }
-        HIP_TRY(hipGetLastError());
-        return FFS_OK;
-    }
-    if (sp->mid_seg_pipe) {  // software-pipelined row loads (default)
-        const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);
+    const size_t ldsp = row_lds_bytes(4096) + 4096 * sizeof(cf);  // + conj(R_k)/N parked next to the row buffer
+    const float inv_n = (float)(1.0 / (double)sp->N);
+    const int flags = ref_half | PAIR_ROWS;
+    const int mid_lab = sp->lab_flags & (DBG_NO_FFT | DBG_HOT_MEM | DBG_NO_STORE);
+    if (n_slots - 1 == 1) {  // one packed slot (every FFTAligner.fit): one accumulator row, three blocks per CU
+        if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, false, 1>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_mid_seg_one<4096, false, 1>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1,
+                           sp->log2CL, (long long)sp->N, n_slots, n_blocks, inv_n, sp->tw2, sp->tbM, sp->tsM, flags | mid_lab);
+    } else if (n_slots - 1 <= 4) {  // single sweep: all (<= 4) candidate slots accumulate at once
+        if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_one<4096, true>, ldsp))) return rc_lds;
+        hipLaunchKernelGGL((k_mid_seg_one<4096, true>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1,
+                           sp->log2CL, (long long)sp->N, n_slots, n_blocks, inv_n, sp->tw2, sp->tbM, sp->tsM, flags | mid_lab);
+    } else {  // nine or more candidates: two slots per sweep
         if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg_pipe<4096>, ldsp))) return rc_lds;
         hipLaunchKernelGGL((k_mid_seg_pipe<4096>), dim3(sp->N1, n_pairs), dim3(256), ldsp, st, sp->work, sp->N1, sp->log2CL,
-                           (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                           ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0) | sp->mid_debug);
-        HIP_TRY(hipGetLastError());
-        return FFS_OK;
+                           (long long)sp->N, n_slots, n_blocks, inv_n, sp->tw2, sp->tbM, sp->tsM, flags);
     }
-    if ((rc_lds = ensure_lds(sp, (const void*)k_mid_seg<4096>, lds))) return rc_lds;
-    hipLaunchKernelGGL((k_mid_seg<4096>), dim3(sp->N1, n_pairs), dim3(256), lds, st, sp->work, sp->N1, sp->log2CL,
-                       (long long)sp->N, n_slots, n_blocks, (float)(1.0 / (double)sp->N), sp->tw2, sp->tbM, sp->tsM,
-                       ref_half | (sp->mid_seg_pairmap ? PAIR_ROWS : 0));
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -481,21 +454,6 @@ struct PoolArgs {
     int shares;  // sub-batches of the call that share the pool (each flagged candidate's quota is divided by it)
     int half_last = 0;  // HALF_LAST layout of the last candidate slot (see ffs_kernels.h)
 };
-
-int launch_mid_packed(const ffs_plan* p, int n_pairs, int n_packed, hipStream_t st) {
-    const size_t lds = row_lds_bytes(4096);
-    int rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_mid_packed<4096, false>, lds))) return rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_mid_packed<4096, true>, lds))) return rc_lds;
-    const float inv_n = (float)(1.0 / (double)p->N);
-    // row pairs (b, N1-b), b = 1 .. N1/2 (row N1/2 pairs with itself); row 0 (self-paired, different mirror)
-    hipLaunchKernelGGL((k_mid_packed<4096, false>), dim3(p->N1 / 2, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
-                       (long long)p->N, n_packed, inv_n, p->tw2, p->tbM, p->tsM);
-    hipLaunchKernelGGL((k_mid_packed<4096, true>), dim3(1, n_pairs), dim3(256), lds, st, p->work, p->N1, p->log2CL,
-                       (long long)p->N, n_packed, inv_n, p->tw2, p->tbM, p->tsM);
-    HIP_TRY(hipGetLastError());
-    return FFS_OK;
-}
 
 template <int L, int C, int MODE>
 int launch_pass_c_inst(const ffs_plan* p, const CandDesc* cands, int first_cand, int n_cand, int n_packed, int n_slots,
@@ -800,40 +758,25 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     HIP_TRY(hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
     {
-        const char* e = getenv("FFS_DISABLE_PRUNED_PASS_C");
-        p->allow_pruned = !(e && e[0] == '1');
-        // measured neutral (pass A -2.0 us/pair, mid +2.0 us/pair: the second row of every pair re-reads
-        // and re-transforms the last slot's rows), so the simpler separate-reference layout is the default
-        const char* e6 = getenv("FFS_DISABLE_SEGMENTED");
-        p->allow_seg = !(e6 && e6[0] == '1');
-        const char* e4 = getenv("FFS_DISABLE_REF_HALF");
-        p->allow_ref_half = !(e4 && e4[0] == '1');
-        const char* e9 = getenv("FFS_PASS_A_STORE8");
-        p->pass_a_store8 = !(e9 && e9[0] == '0');
-        const char* e12 = getenv("FFS_MID_SEG_PAIRMAP");
-        p->mid_seg_pairmap = !(e12 && e12[0] == '0');
-        const char* e20 = getenv("FFS_PASS_A_DEBUG");
-        if (e20) p->pass_a_debug = (atoi(e20) & 31) << 10;
-        const char* e15 = getenv("FFS_MID_DEBUG");
-        if (e15) p->mid_debug = ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0) | ((atoi(e15) & 4) ? DBG_NO_STORE : 0);
-        const char* e23 = getenv("FFS_MID_SEG_ONE_NA1");
-        p->mid_seg_one_na2 = !(e23 && e23[0] == '0');
-        const char* e16 = getenv("FFS_MID_SEG_ONE");
-        if (e16 && atoi(e16) >= 0 && atoi(e16) <= 2) p->mid_seg_one = atoi(e16);
-        const char* e19 = getenv("FFS_MID_PF");
-        if (e19) p->mid_pf = e19[0] == '1';
-        const char* e17 = getenv("FFS_COL3R");
-        p->col3r = !(e17 && e17[0] == '0');
-        const char* e10 = getenv("FFS_MID_SEG_PIPE");
-        p->mid_seg_pipe = !(e10 && e10[0] == '0');
-        const char* e13 = getenv("FFS_RESCORE_SEG");
-        if (e13 && atoi(e13) >= 1 && atoi(e13) <= RSEG) p->rescore_seg_bits = atoi(e13);
-        const char* e7 = getenv("FFS_DISABLE_HALF_LAST");
-        p->allow_half_last = !(e7 && e7[0] == '1');
+        // Run-time knobs: five, all listed in INTEGRATION.md section 6, each selecting between code paths that
+        // return identical records (every pairing has an "identical records" GPU test).
+        auto on = [](const char* name) {
+            const char* e = getenv(name);
+            return e && e[0] == '1';
+        };
+        p->allow_pruned = !on("FFS_DISABLE_PRUNED_PASS_C");
+        p->allow_seg = !on("FFS_DISABLE_SEGMENTED");
+        p->allow_half_last = !on("FFS_DISABLE_HALF_LAST");
+        p->allow_radix3 = !on("FFS_DISABLE_RADIX3");
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
-        const char* e2 = getenv("FFS_ENABLE_PACKED_REF");
-        p->allow_packed_ref = (e2 && e2[0] == '1');
+#ifdef FFS_LAB
+        // section experiments of the lab build (timing only: these switches produce WRONG RESULTS)
+        const char* e20 = getenv("FFS_PASS_A_DEBUG");
+        if (e20) p->lab_flags |= (atoi(e20) & 31) << 10;
+        const char* e15 = getenv("FFS_MID_DEBUG");
+        if (e15) p->lab_flags |= ((atoi(e15) & 1) ? DBG_NO_FFT : 0) | ((atoi(e15) & 2) ? DBG_HOT_MEM : 0) | ((atoi(e15) & 4) ? DBG_NO_STORE : 0);
+#endif
     }
     if (n_fft < kMinFftN) {
         p->direct_only = true;
@@ -973,20 +916,16 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
 
     const int n_packed = (n_cand + 1) / 2;
     const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
-    // Odd candidate counts leave the imaginary half of the last packed transform free: put the reference
-    // there (k_mid_packed) instead of spending a fifth transform on it.
-    const bool packed_ref = !p->direct_only && p->allow_packed_ref && (n_cand % 2 == 1) && p->N2 == 4096 && p->N1 % 3 != 0 &&
-                            (p->N2 / 16) >= (1 << p->log2CL) && p->N1 >= 2;
-    const int xf_per_pair = packed_ref ? n_packed : n_slots;
-    const bool ref_half = !packed_ref && !p->direct_only && ref_half_ok(p);
+    const int xf_per_pair = n_slots;
+    const bool ref_half = !p->direct_only && ref_half_ok(p);
     // odd candidate count: the last packed transform carries one real candidate -> half of its rows suffice
     // (needs the one-row-per-block mid kernels, like ref_half; the plan that runs the kernels decides)
     auto half_flags_of = [&](const ffs_plan* q, bool rh) {
-        const bool hl = !packed_ref && (n_cand % 2 == 1) && q->allow_half_last && ref_half_ok(q) && q->N1 >= 4;
+        const bool hl = (n_cand % 2 == 1) && q->allow_half_last && ref_half_ok(q) && q->N1 >= 4;
         return (rh ? HALF_REF : 0) | (hl ? HALF_LAST : 0);
     };
     const int hflags = p->direct_only ? 0 : half_flags_of(p, ref_half);
-    const int slot_map = packed_ref ? -n_slots : n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
+    const int slot_map = n_slots;  // see slot_stride()/cand_slot() in ffs_kernels.h
     const size_t n_cands = (size_t)n_pairs * n_cand;
     size_t n_xf = (size_t)n_pairs * xf_per_pair;
     const size_t n_xf_alloc = p->seg ? (size_t)n_pairs * kSegBlocks * n_slots : n_xf;  // block-segmented mode needs more
@@ -1037,14 +976,9 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
         ref.len = ref_used;
         views[b] = ref;
         for (int j = 0; j < n_cand; ++j) views[b + 1 + j] = subs[j];
-        if (packed_ref) {
-            for (int k = 0; k < n_packed; ++k)
-                fill_xform(&hx[(size_t)pi * xf_per_pair + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : &ref);
-        } else {
-            fill_xform(&hx[(size_t)pi * n_slots], &ref, nullptr);
-            for (int k = 0; k < n_packed; ++k)
-                fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
-        }
+        fill_xform(&hx[(size_t)pi * n_slots], &ref, nullptr);
+        for (int k = 0; k < n_packed; ++k)
+            fill_xform(&hx[(size_t)pi * n_slots + 1 + k], &subs[2 * k], (2 * k + 1 < n_cand) ? &subs[2 * k + 1] : nullptr);
     }
     // last-pass bins reachable by any lag window of this call (pruned pass C when there are few)
     std::vector<int> bin_set;
@@ -1062,7 +996,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     bool seg = false;
     int seg_blocks = 0;
     int64_t seg_lo = 0;
-    if (p->seg && p->allow_seg && p->allow_pruned && !p->direct_only && !packed_ref && max_offset_samples >= 0 && p->seg->N2 == 4096 &&
+    if (p->seg && p->allow_seg && p->allow_pruned && !p->direct_only && max_offset_samples >= 0 && p->seg->N2 == 4096 &&
         ref_half_ok(p->seg)) {
         const ffs_plan* sp = p->seg;
         int64_t d_lo = INT64_MAX, d_hi = INT64_MIN, s_max = 1;
@@ -1180,7 +1114,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 return rc;
             {
                 ProfSpan span(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? p->rescore_seg_bits : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
                                                        first_cand));
             }
             HIP_TRY(hipGetLastError());
@@ -1196,7 +1130,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_MID);
-                rc = packed_ref ? launch_mid_packed(p, np, n_packed, st) : launch_mid(p, np, n_slots, hflags, st);
+                rc = launch_mid(p, np, n_slots, hflags, st);
             }
             if (rc) return rc;
             {
@@ -1220,7 +1154,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? p->rescore_seg_bits : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
+                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
                                                        first_cand));
             }
             HIP_TRY(hipGetLastError());
@@ -1595,8 +1529,7 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
     if ((rc_dev = guard.enter(labels_dev))) return rc_dev;
     const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     const long long longest = chunk_frames < n_frames ? chunk_frames : n_frames;
-    const char* serial = getenv("FFS_VAD_TOKENIZE_SERIAL");
-    if (longest <= TOK_SCAN_MAX && max_length >= min_length && min_length >= 0 && !(serial && serial[0] == '1')) {
+    if (longest <= TOK_SCAN_MAX && max_length >= min_length && min_length >= 0) {
         // one workgroup per chunk, every step a scan (three 16-bit index arrays of the chunk in LDS)
         const int lds_frames = (int)((longest + 7) / 8 * 8);
         const size_t lds = (size_t)lds_frames * 3 * sizeof(short);

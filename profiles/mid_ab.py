@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Same-box A/B of mid-pass variants: per-kernel us/pair (plan profile) + throughput + golden check.
 
-    python profiles/mid_ab.py '{"FFS_MID_SEG_E8": "2"}' '{}' ...      (one JSON env dict per variant)
+    python profiles/mid_ab.py '{"FFS_DISABLE_HALF_LAST": "1"}' '{}' ...      (one JSON env dict per variant)
+
+A variant is an environment: one of the five run-time knobs, `FFS_LIBRARY_PATH` pointing at another build
+(`make variant NAME=x DEFS=-D...`), or -- with the lab build, `make lab` -- the timing-only section switches.
 """
 import json
 import os

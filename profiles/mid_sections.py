@@ -6,7 +6,9 @@
     FFS_MID_DEBUG=2  every pair works on pair 0's buffers: all traffic is L2 hits (compute + LDS + issue alone)
     FFS_MID_DEBUG=3  both (launch + instruction overhead floor)
 
-Run once per mode:  FFS_MID_DEBUG=k python profiles/mid_sections.py
+The switches exist in the LAB build only (`make -C ffsubsync_amd/csrc lab` -> libffsalign_lab.so; the product library
+ignores them).  Run once per mode:
+    FFS_LIBRARY_PATH=$PWD/ffsubsync_amd/libffsalign_lab.so FFS_MID_DEBUG=k python profiles/mid_sections.py
 """
 import json
 import os

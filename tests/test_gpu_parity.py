@@ -96,7 +96,7 @@ def test_raw_correlation_three_times_power_of_two(torch, n):
         assert torch.equal(bit_a, out_a) and torch.equal(bit_b, out_b)
     else:  # N1 >= 192: bit-packed inputs take k_pass_a3 (radix-3 step in registers) -- same values, other rounding
         assert np.abs(bit_a.cpu().numpy() - ea).max() < tol / 8 and np.abs(bit_b.cpu().numpy() - eb).max() < tol / 8
-        assert not torch.equal(bit_a, out_a) or os.environ.get("FFS_COL3R") == "0"  # i.e. the new kernel did run
+        assert not torch.equal(bit_a, out_a)  # i.e. the three-sub-transforms-per-thread kernel did run
     if n <= 3 << 16:
         fa = rng.rand(Sa).astype(np.float32)
         out_f, _ = plan.correlate_full(_native.FFS_DTYPE_F32, d(ref.astype(np.float32)), (0, 1), d(fa), (0, 1))
@@ -374,26 +374,6 @@ def test_pruned_last_pass_equals_full_last_pass(torch, monkeypatch):
         assert pruned[1][p]["best_cand"] == sp.true_ratio_index
 
 
-def test_reference_half_rows_equal_all_rows(torch, monkeypatch):
-    """The reference transform's rows k1 > N1/2 are rebuilt from the Hermitian mirror rows in the mid
-    pass instead of being stored; storing all rows must give the same records."""
-    from ffsubsync_amd import batch
-    from workloads import synth
-
-    specs = [synth.make_pair_spec(700 + i, duration_s=d) for i, d in enumerate((7200.0, 5400.0, 2500.0))]
-    db = synth.build_device_batch(specs)
-    for mo in (6000, None):
-        n_fft = db.required_fft_length(mo)
-        half = batch.BatchAligner(n_fft, 7, max_offset_samples=mo, pairs_in_flight=2).solve(db)
-        monkeypatch.setenv("FFS_DISABLE_REF_HALF", "1")
-        full = batch.BatchAligner(n_fft, 7, max_offset_samples=mo, pairs_in_flight=2).solve(db)
-        monkeypatch.delenv("FFS_DISABLE_REF_HALF")
-        assert np.array_equal(half[0]["offset"], full[0]["offset"]) and np.array_equal(half[0]["score"], full[0]["score"])
-        assert np.array_equal(half[1], full[1])
-        assert np.abs(half[0]["score_f32"] - full[0]["score_f32"]).max() < 0.25
-        assert np.abs(half[0]["score_f32"].astype(np.float64) - half[0]["score"]).max() < 0.5
-
-
 def test_block_segmented_mode_equals_single_transform(torch, monkeypatch):
     """With a narrow lag window a 3*2^k plan cuts every candidate into three blocks, correlates each
     with its stretch of the reference by a transform of a third of the length and adds the spectrum
@@ -480,38 +460,6 @@ def test_flat_topped_peak_uses_exhaustive_fallback(torch):
             assert cres[0, 0]["score"] == pytest.approx(top, rel=1e-9)
             assert not (int(cres[0, 0]["flags"]) & _native.FLAG_AMBIGUOUS)
             assert int(pres[0]["best_cand"]) == 0
-
-
-def test_packed_reference_layout_equals_separate_reference(torch, monkeypatch):
-    """Optional layout (FFS_ENABLE_PACKED_REF=1): odd candidate counts put the reference into the
-    imaginary half of the last candidate transform (k_mid_packed, Hermitian split across row pairs);
-    results must match the default separate-reference path on a 7-ratio batch, a 1-candidate problem
-    and a window-less problem."""
-    from ffsubsync_amd import _native, batch
-    from workloads import synth
-    from ffsubsync_amd.aligners import _Vec, solve_pairs
-
-    specs = [synth.make_pair_spec(400 + i, duration_s=3000.0) for i in range(3)]
-    db = synth.build_device_batch(specs)
-    n = db.required_fft_length(6000)
-    c = SMALL["config1_none"]
-    one = [(_Vec(c["ref"]), [_Vec(c["cands"][0])])]
-
-    def run():
-        _native.clear_plan_cache()  # the layout switch is read when a plan is created
-        out = (batch.BatchAligner(n, 7, 6000, pairs_in_flight=2).solve(db), solve_pairs(one, None), solve_pairs(one, 6000))
-        _native.clear_plan_cache()
-        return out
-
-    separate = run()
-    monkeypatch.setenv("FFS_ENABLE_PACKED_REF", "1")
-    packed = run()
-    for a, b in zip(packed, separate):
-        assert np.array_equal(a[0]["offset"], b[0]["offset"]) and np.array_equal(a[0]["score"], b[0]["score"])
-        assert np.array_equal(a[1], b[1])
-        assert np.abs(a[0]["score_f32"] - b[0]["score_f32"]).max() < 0.25
-    for p, sp in enumerate(specs):
-        assert packed[0][1][p]["best_cand"] == sp.true_ratio_index
 
 
 def test_maximum_length_solve(torch):

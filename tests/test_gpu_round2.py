@@ -334,18 +334,15 @@ def test_mid_pass_variants_give_identical_records(torch, monkeypatch, n_cand):
             monkeypatch.delenv(k)
         return out
 
-    base = solve({"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0"})  # plain two-slot k_mid_seg, rows in order
-    for env in ({}, {"FFS_DISABLE_HALF_LAST": "1"},  # defaults: pipelined loads + mirror-row pairs per XCD
-                {"FFS_MID_SEG_PIPE": "0"}, {"FFS_MID_SEG_PAIRMAP": "0"},
-                {"FFS_MID_SEG_PIPE": "0", "FFS_MID_SEG_PAIRMAP": "0", "FFS_DISABLE_HALF_LAST": "1"},
-                # single sweep (four accumulator rows), with and without load-ahead
-                {"FFS_MID_SEG_ONE": "1"}, {"FFS_MID_SEG_ONE": "2"},
-                {"FFS_MID_SEG_ONE": "1", "FFS_DISABLE_HALF_LAST": "1", "FFS_MID_SEG_PAIRMAP": "0"}):
+    base = solve({"FFS_DISABLE_SEGMENTED": "1"})  # one transform of the full length: k_mid instead of the segmented kernels
+    for env in ({}, {"FFS_DISABLE_HALF_LAST": "1"}):  # k_mid_seg_one (<= 4 packed slots) / k_mid_seg_pipe (more)
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
         assert np.array_equal(base[1], got[1])
         assert np.abs(got[0]["score_f32"].astype(np.float64) - got[0]["score"]).max() < 0.5
+    for i, sp in enumerate(specs):  # and they are the right answers (when the true ratio is among the candidates)
+        assert sp.true_ratio_index >= n_cand or int(base[1][i]["best_cand"]) == sp.true_ratio_index
 
 
 def test_float64_inputs_are_rescored_from_the_callers_samples(torch):
@@ -388,9 +385,9 @@ def test_float64_inputs_are_rescored_from_the_callers_samples(torch):
 @pytest.mark.parametrize("case", ["n192_window", "n384_none", "n768_none", "n512_none", "n512_reference_length"])
 def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, case):
     """Plans with 3*2^k columns (N1 = 192 / 384 / 768) and with 512-row columns (N = 2^21): k_pass_a3 / k_pass_c3
-    keep the three (two) sub-transforms of a column in one thread (last radix step in registers); FFS_COL3R=0
-    selects k_pass_a / k_pass_c (radix-3 combine through LDS; three-stage 512-row columns).  Same records either
-    way, with and without the half slots."""
+    keep the three (two) sub-transforms of a column in one thread (last radix step in registers).  Same records as
+    the power-of-two plan of the next length up (FFS_DISABLE_RADIX3=1; none for the 2^21 cases, which are compared
+    with the CPU oracle), with and without the half slot and the pruned last pass."""
     from ffsubsync_amd import batch
     from workloads import synth
 
@@ -414,9 +411,24 @@ def test_radix3_columns_in_registers_give_identical_records(torch, monkeypatch, 
         return out
 
     seg_off = {"FFS_DISABLE_SEGMENTED": "1"}  # the windowed case would otherwise run block-segmented (power-of-two columns)
-    base = solve(dict(seg_off, FFS_COL3R="0"))
-    for env in (dict(seg_off), dict(seg_off, FFS_DISABLE_HALF_LAST="1", FFS_DISABLE_REF_HALF="1"),
-                dict(seg_off, FFS_DISABLE_PRUNED_PASS_C="1"), dict(seg_off, FFS_MID_PF="0")):  # k_mid without load-ahead
+    if n_fft % 3 == 0:  # baseline: the power-of-two plan of the same problem
+        monkeypatch.setenv("FFS_DISABLE_RADIX3", "1")
+        n_pow2 = db.required_fft_length(max_offset)
+        monkeypatch.delenv("FFS_DISABLE_RADIX3")
+        assert n_pow2 & (n_pow2 - 1) == 0 and n_pow2 > n_fft
+        al = batch.BatchAligner(n_pow2, 7, max_offset, pairs_in_flight=2)
+        base = al.solve(db)
+        al.plan.close()
+    else:
+        base = solve(dict(seg_off))
+        from oracle import aligners_oracle as orc
+
+        for i, sp in enumerate(specs):
+            ref, cands = synth.pair_float_arrays(sp)
+            (score, offset), idx = orc.max_score_align(ref, cands, max_offset)
+            assert (int(base[1][i]["best_cand"]), int(base[1][i]["offset"])) == (idx, offset)
+            assert abs(float(base[1][i]["score"]) - score) <= 1e-5 * abs(score)
+    for env in (dict(seg_off), dict(seg_off, FFS_DISABLE_HALF_LAST="1"), dict(seg_off, FFS_DISABLE_PRUNED_PASS_C="1")):
         got = solve(env)
         for f in ("score", "offset", "flags"):
             assert np.array_equal(base[0][f], got[0][f]), (env, f)
@@ -452,8 +464,8 @@ def test_pass_a_prefetch_blocks_change_nothing_but_time(torch, monkeypatch):
 
 def test_scan_tokenizer_equals_serial_kernel_and_restatement(torch, monkeypatch):
     """ffs_vad_tokenize runs one workgroup per chunk with every step a scan (k_vad_tokenize_scan) for chunks of up to
-    20480 frames and max_length >= min_length, the one-thread-per-chunk state machine (k_vad_tokenize) otherwise
-    (FFS_VAD_TOKENIZE_SERIAL=1: always).  Both against the Python restatement: reference parameters and degenerate
+    20480 frames and max_length >= min_length, the one-thread-per-chunk state machine (k_vad_tokenize) otherwise (the
+    25000-frame chunks below, and the max_length < min_length case).  Both against the Python restatement: reference parameters and degenerate
     ones, several labels, chunk lengths around the segment size of the scans, chunks too long for the scan kernel."""
     from ffsubsync_amd import _native
 
@@ -479,18 +491,14 @@ def test_scan_tokenizer_equals_serial_kernel_and_restatement(torch, monkeypatch)
                     want.append(np.clip(np.cumsum(marks)[:-1], 0.0, 1.0))
                 want = np.concatenate(want)
                 got = _native.vad_tokenize(dev, chunk, mn, mx, msil, label).cpu().numpy().astype(float)
-                assert np.array_equal(got, want), ("scan", trial, n, (mn, mx, msil), label, chunk)
-                monkeypatch.setenv("FFS_VAD_TOKENIZE_SERIAL", "1")
-                got = _native.vad_tokenize(dev, chunk, mn, mx, msil, label).cpu().numpy().astype(float)
-                monkeypatch.delenv("FFS_VAD_TOKENIZE_SERIAL")
-                assert np.array_equal(got, want), ("serial", trial, n, (mn, mx, msil), label, chunk)
+                assert np.array_equal(got, want), (trial, n, (mn, mx, msil), label, chunk)
 
 
 @pytest.mark.parametrize("n_cand", [1, 2])
 def test_one_slot_mid_kernel_gives_identical_records(torch, monkeypatch, n_cand):
     """Solves with one packed slot (every FFTAligner.fit: one or two candidates) run the block-segmented mid pass with
-    ONE accumulator row and conj(R)/N in registers (k_mid_seg_one<.., 1>: three blocks per CU); FFS_MID_SEG_ONE_NA1=0
-    keeps the four-row kernel.  Identical records, fp32 values included."""
+    ONE accumulator row and conj(R)/N in registers (k_mid_seg_one<.., 1>: three blocks per CU).  Records identical to
+    the single-transform pipeline's."""
     from ffsubsync_amd import batch
     from workloads import synth
 
@@ -499,17 +507,18 @@ def test_one_slot_mid_kernel_gives_identical_records(torch, monkeypatch, n_cand)
     pick = lambda a: np.ascontiguousarray(a[:, : 1 + n_cand])
     db = batch.DeviceBatch(db8.data, pick(db8.offs), pick(db8.lens), pick(db8.lo), pick(db8.hi), db8.dtype)
     out = []
-    for env in ("0", None):
+    for env in ("1", None):  # single-transform pipeline (k_mid) vs the block-segmented one-slot kernel
         if env is not None:
-            monkeypatch.setenv("FFS_MID_SEG_ONE_NA1", env)
+            monkeypatch.setenv("FFS_DISABLE_SEGMENTED", env)
         al = batch.BatchAligner(db.required_fft_length(6000), n_cand, 6000, pairs_in_flight=2)
         out.append(al.solve(db))
         al.plan.close()
         if env is not None:
-            monkeypatch.delenv("FFS_MID_SEG_ONE_NA1")
-    for f in ("score", "offset", "flags", "score_f32"):
+            monkeypatch.delenv("FFS_DISABLE_SEGMENTED")
+    for f in ("score", "offset", "flags"):
         assert np.array_equal(out[0][0][f], out[1][0][f]), f
     assert np.array_equal(out[0][1], out[1][1])
+    assert np.abs(out[1][0]["score_f32"].astype(np.float64) - out[1][0]["score"]).max() < 0.5
 
 
 def test_two_streams_give_identical_records(torch):
