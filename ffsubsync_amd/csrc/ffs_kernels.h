@@ -1088,9 +1088,11 @@ FFS_DEV WinParams load_window(const CandDesc* __restrict__ cands, int cand0, int
 // real-part candidate, v[q].y to the imaginary-part one, at output index m_of(q) (< 0: no value).
 // The window test of every value is done once (a bit per value); lags are only worked out for the few
 // values that reach the tie margin.
+// dm_b: added to m_of(q) for the imaginary half (0 normally; k_pass_c3's paired columns: the imaginary half is the
+// SAME candidate's column C columns further on).
 template <int NV, int NW, class MOf>
 FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, unsigned char* smem, int tid,
-                            BlockNom* __restrict__ out_a, BlockNom* __restrict__ out_b) {
+                            BlockNom* __restrict__ out_a, BlockNom* __restrict__ out_b, int dm_b = 0) {
     // callers with a whole column per thread (NV >= 16) only ever pass valid output indices
     constexpr bool ALLM = NV >= 16;
     float bv[2] = {-INFINITY, -INFINITY};
@@ -1099,7 +1101,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
         const int m = m_of(q);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const bool ok = in_window_t<ALLM>(wp, h, m);
+            const bool ok = in_window_t<ALLM>(wp, h, h ? m + dm_b : m);
             const float val = h ? v[q].y : v[q].x;
             bv[h] = fmaxf(bv[h], ok ? val : -INFINITY);
         }
@@ -1140,7 +1142,7 @@ FFS_DEV void block_nominees(const cf* v, MOf m_of, const WinParams& wp, int nN, 
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             const float val = h ? v[q].y : v[q].x;
-            int m = m_of(q);
+            int m = m_of(q) + (h ? dm_b : 0);
             asm volatile("" : "+v"(m));  // opaque: a fresh test here, not the first loop's results kept alive
             if (val >= thr && in_window_t<ALLM>(wp, h, m)) {
                 const int slot = atomicAdd(&s_cnt[h], 1);
@@ -1312,6 +1314,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------
+#ifndef FFS_C3P_CHUNK
+#define FFS_C3P_CHUNK 16
+#endif
+#ifndef FFS_C3P_WAVES
+#define FFS_C3P_WAVES 2  // paired-column instantiation with three sub-transforms: 205 VGPRs (37 spilled at three waves)
+#endif
 #ifndef FFS_C3_WAVES
 #define FFS_C3_WAVES 3
 #endif
@@ -1319,35 +1327,61 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
 // one thread (colnr_fft): nominees only (MODE 0 of
 // k_pass_c; the diagnostic and exhaustive modes stay with k_pass_c, the work layout is the same).
 // grid = (N2/C, n_candidate_transforms); block = (LI/16)*C = 256 threads.
-template <int NS, int LI, int C>
-__global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restrict__ work, int N2, long long N,
+// PAIRED = the instantiation for a HALF_LAST slot (ONE real candidate; launched on its own: grid = (N2/C/2, n_pairs)):
+// every column of that slot's product spectrum is Hermitian (rows above L/2 are the conjugates of stored rows, see
+// k_pass_c), i.e. every output column is REAL -- so two columns share one complex transform, z = A + i*B -> Re = column
+// A's correlation values, Im = column B's.  A block covers the tile pair (2t, 2t+1) (one whole 512-byte row chunk per
+// row when C = 32): half the column transforms for this slot.  The other slots run the plain instantiation
+// (grid.y = n_pairs * slots_here, slots_here = n_packed minus the half-last slot).
+template <int NS, int LI, int C, bool PAIRED>
+__global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_C3P_WAVES : FFS_C3_WAVES) void k_pass_c3(const cf* __restrict__ work, int N2, long long N,
                                                  const cf* __restrict__ tw, const CandDesc* __restrict__ cands,
                                                  int first_cand, int n_cand, int n_packed, int n_slots,
                                                  BlockNom* __restrict__ bnom, int log2CL, const cf* __restrict__ tw3,
-                                                 int half_last) {
+                                                 int slots_here) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, NW = NT / 64;
     static_assert(NT == 256, "256 threads per block");
     const int tid = threadIdx.x;
     const int c = tid % C, u = tid / C;
-    const int tile = blockIdx.x, ly = blockIdx.y;
-    const int lp = ly / n_packed, kp = ly % n_packed;
+    const int tiles = N2 / C;  // block records per (transform, half)
+    const int tile = PAIRED ? 2 * (int)blockIdx.x : (int)blockIdx.x;
+    const int lp = PAIRED ? (int)blockIdx.y : (int)blockIdx.y / slots_here;
+    const int kp = PAIRED ? n_packed - 1 : (int)blockIdx.y % slots_here;
+    const int ly = lp * n_packed + kp;
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     TwRegs<LI> twr;
     twr.load(tw, u);
     const cf wu = tw3[u], wu2 = tw3[2 * u];  // W_L^u, W_L^2u
     cf v[NS][16];
-    const cf* col = in + tile_base<L, C>(tile, c, log2CL);
-    if (half_last && kp == n_packed - 1) {  // HALF_LAST: rows above L/2 are the conjugates of stored rows (k_pass_c)
+    if constexpr (PAIRED) {
+        const unsigned oa = (unsigned)tile_base<L, C>(tile, c, log2CL) * (unsigned)sizeof(cf);
+        const unsigned ob = (unsigned)tile_base<L, C>(tile + 1, c, log2CL) * (unsigned)sizeof(cf);
+        const unsigned row_bytes = (unsigned)sizeof(cf) << log2CL;
+        const gcptr pin = (gcptr)in;  // scalar base + one 32-bit byte offset per load
 #pragma unroll
-        for (int g = 0; g < NS; ++g)
+        for (int g = 0; g < NS; ++g) {
+            constexpr int CH = FFS_C3P_CHUNK;  // rows of A and of B requested together
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = NS * (u + LTI * q) + g;
-                const cf y = col[(size_t)(row <= L / 2 ? row : L - row) << log2CL];
-                v[g][q] = row <= L / 2 ? y : mk(y.x, -y.y);
+            for (int q0 = 0; q0 < 16; q0 += CH) {
+                cf a[CH], b[CH];
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int row = NS * (u + LTI * (q0 + j)) + g;
+                    const unsigned ro = (unsigned)(row <= L / 2 ? row : L - row) * row_bytes;
+                    a[j] = gload(pin, oa + ro);
+                    b[j] = gload(pin, ob + ro);
+                }
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const int row = NS * (u + LTI * (q0 + j)) + g;
+                    const float sg = row <= L / 2 ? 1.0f : -1.0f;  // conjugate the mirrored rows
+                    v[g][q0 + j] = mk(a[j].x - sg * b[j].y, sg * a[j].y + b[j].x);  // A' + i*B'
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
     } else {
         // scalar row pointer stepping by the (opaque) stride of 3*LTI rows + one 32-bit lane offset per sub-transform
         size_t stride = ((size_t)(NS * LTI) << log2CL) * sizeof(cf);
@@ -1367,10 +1401,18 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_c3(const cf* __restr
     colnr_fft<NS, LI, C>(v, lds, u, c, twr, wu, wu2);
     // v[r][q] = out[m], m = m1 + N2*m2, m1 = tile*C + c, m2 = u + LTI*q + LI*r
     const int m1 = tile * C + c;
-    const WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, (int)N);
+    WinParams wp = load_window(cands, first_cand + lp * n_cand, kp, n_cand, (int)N);
+    if constexpr (PAIRED) {  // the imaginary half carries the same candidate (columns m1 + C): same window, same margin
+        wp.lo[1] = wp.lo[0], wp.hi[1] = wp.hi[0], wp.marg[1] = wp.marg[0];
+        wp.g0[1] = wp.g0[0], wp.gw[1] = wp.gw[0], wp.ginv[1] = wp.ginv[0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wp.ra[1][i] = wp.ra[0][i], wp.rw[1][i] = wp.rw[0][i];
+    }
+    // PAIRED: both halves are block records of part 0 of this transform (tiles `tile` and `tile + 1`)
     block_nominees<16 * NS, NW>(
         &v[0][0], [&](int i) { return m1 + N2 * (u + LTI * (i % 16) + LI * (i / 16)); }, wp, (int)N, smem, tid,
-        &bnom[((size_t)ly * 2 + 0) * gridDim.x + tile], &bnom[((size_t)ly * 2 + 1) * gridDim.x + tile]);
+        &bnom[((size_t)ly * 2 + 0) * tiles + tile],
+        PAIRED ? &bnom[((size_t)ly * 2 + 0) * tiles + tile + 1] : &bnom[((size_t)ly * 2 + 1) * tiles + tile], PAIRED ? C : 0);
 }
 
 // --------------------------------------------------------------------------------------------

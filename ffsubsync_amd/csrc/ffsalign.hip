@@ -334,10 +334,19 @@ int launch_pass_c3_inst(const ffs_plan* p, const CandDesc* cands, int first_cand
                         int n_pairs, int half_last, hipStream_t st) {
     const size_t lds = (size_t)LI * C * sizeof(cf);
     int rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<NS, LI, C>, lds))) return rc_lds;
-    hipLaunchKernelGGL((k_pass_c3<NS, LI, C>), dim3(p->N2 / C, n_pairs * n_packed), dim3(256), lds, st, p->work, p->N2,
-                       (long long)p->N, NS == 2 ? p->tw1h : p->tw1, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1,
-                       half_last);
+    const cf* tw = NS == 2 ? p->tw1h : p->tw1;
+    const int tiles = p->N2 / C;
+    const int plain = n_packed - (half_last ? 1 : 0);  // slots with two candidates (or all of them without HALF_LAST)
+    if (plain > 0) {
+        if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<NS, LI, C, false>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_pass_c3<NS, LI, C, false>), dim3(tiles, n_pairs * plain), dim3(256), lds, st, p->work, p->N2,
+                           (long long)p->N, tw, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1, plain);
+    }
+    if (half_last) {  // the single-candidate slot: two real output columns per complex column transform
+        if ((rc_lds = ensure_lds(p, (const void*)k_pass_c3<NS, LI, C, true>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_pass_c3<NS, LI, C, true>), dim3(tiles / 2, n_pairs), dim3(256), lds, st, p->work, p->N2,
+                           (long long)p->N, tw, cands, first_cand, n_cand, n_packed, n_slots, p->bnom, p->log2CL, p->twn1, 1);
+    }
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
