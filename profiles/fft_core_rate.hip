@@ -254,6 +254,68 @@ __global__ __launch_bounds__(512, 1) void k_core_duo(const cf* __restrict__ tw, 
     for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 512 + threadIdx.x) * 16 + q] = acc[q] + v[q];
 }
 
+// ---- wave-local 1024-point rows: ONE wave per row transform (64 lanes x 16 values, 16*16*4), both exchanges inside
+// the wave's own LDS region, no workgroup barrier at all (LDS operations of a wave execute in order).  The question:
+// what would the row pass cost per POINT if rows were 1024 instead of 4096 points long (N = 256 x 1024 instead of
+// 64 x 4096), i.e. with every wave of the CU an independent unit of overlap?
+template <int L, class Addr>
+FFS_DEV void fft_wave(cf (&v)[16], cf* lds, int u, Addr& addr, const TwRegs<L>& tw) {
+    typedef Shape<L> S;
+    stage_first(v);
+    stage_scatter<L, 16, 1>(v, lds, u, addr);
+    stage_gather<L>(v, lds, u, addr);
+    stage_compute<L, S::R1, 16, false>(v, tw.s1);
+    if constexpr (S::R2 > 1) {
+        stage_scatter<L, S::R1, 16>(v, lds, u, addr);
+        stage_gather<L>(v, lds, u, addr);
+        stage_compute<L, S::R2, 256, false>(v, tw.s2);
+    }
+}
+__global__ __launch_bounds__(256) void k_core_wave1024(const cf* __restrict__ tw, cf* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int L = 1024;
+    const int wave = threadIdx.x >> 6, u = threadIdx.x & 63;
+    cf* lds = reinterpret_cast<cf*>(smem) + wave * RowAddr<L>::ROW_ELEMS;
+    RowAddr<L> addr(0, u);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf v[16], acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
+        acc[q] = mk(0.f, 0.f);
+    }
+    for (int it = 0; it < iters; ++it) {
+        fft_wave<L>(v, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], twr.s1.w[q % 6]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(v[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 256 + threadIdx.x) * 16 + q] = acc[q] + v[q];
+}
+static void run_wave1024(const cf* tw, cf* out, int n_cu, bool last) {
+    const size_t lds = 4 * (size_t)RowAddr<1024>::ROW_ELEMS * sizeof(cf);
+    printf("  \"wave_local_1024\": {");
+    const int iters = 1600;
+    for (int bpc = 1; bpc <= 4; ++bpc) {
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_core_wave1024, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_core_wave1024, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        // ns per 1024-point transform per wave, and ns per 4096 POINTS per CU (comparable with the other rows)
+        printf("\"%d_blocks_per_cu\": [%.0f, %.0f]%s", bpc, ms * 1e6 / iters, ms * 1e6 / iters / (4 * bpc) * 4, bpc < 4 ? ", " : "");
+    }
+    printf("}%s\n", last ? "" : ",");
+}
+
 template <bool OFFSET>
 static void run_duo(const char* name, const cf* tw, cf* out, int n_cu, bool last) {
     const size_t lds = 2 * (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf);
@@ -316,7 +378,8 @@ int main() {
     run<PLANAR>("planar_addtid_full", tw, out, n_cu, false);
     run<PLANAR_NO_VALU>("planar_addtid_no_valu", tw, out, n_cu, false);
     run_duo<true>("duo_staggered", tw, out, n_cu, false);
-    run_duo<false>("duo_lockstep", tw, out, n_cu, true);
+    run_duo<false>("duo_lockstep", tw, out, n_cu, false);
+    run_wave1024(tw, out, n_cu, true);
     printf("}\n");
     return 0;
 }
