@@ -316,6 +316,178 @@ static void run_wave1024(const cf* tw, cf* out, int n_cu, bool last) {
     printf("}%s\n", last ? "" : ",");
 }
 
+// ---- the product transform + the mid pass's load pattern: sixteen 8-byte global loads per thread per item, requested
+// one item ahead into a staging buffer (copied when its turn comes), from a buffer small enough to stay in L2 (MODE 1)
+// or striding through 2 GB (MODE 2: HBM); MODE 0 = no loads.  66.8 KB of LDS per block: exactly two resident blocks.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_core_loads(const cf* __restrict__ tw, const cf* __restrict__ src, size_t src_elems,
+                                                        cf* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int L = 4096;
+    const int u = threadIdx.x;
+    RowAddr<L> addr(0, u);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf v[16], xl[16], acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
+        xl[q] = v[q];
+        acc[q] = mk(0.f, 0.f);
+    }
+    // a row = sixteen 2 KB pieces (one per q) at a stride of 128 KB, as in the tile layout of the 64-row plan
+    const size_t row_elems = 16 * 16384;
+    size_t row = ((size_t)blockIdx.x * 977) % (src_elems / row_elems);
+    auto request = [&]() {
+        if constexpr (MODE != 0) {
+            const cf* p = src + row * row_elems + u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) xl[q] = p[(size_t)q * 16384];
+            row = (row + (MODE == 2 ? 1031 : 1)) % (MODE == 2 ? (src_elems / row_elems) : 8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    request();
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE != 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = cadd(v[q], xl[q]);
+            request();
+        }
+        fft_regs<L, RowAddr<L>, true>(v, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], twr.s1.w[q % 6]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(v[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 256 + u) * 16 + q] = acc[q] + v[q];
+}
+template <int MODE>
+static void run_loads(const char* name, const cf* tw, const cf* src, size_t src_elems, cf* out, int n_cu, bool last) {
+    const size_t lds = (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf) + 32768;
+    CHECK(hipFuncSetAttribute((const void*)k_core_loads<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int iters = 100, bpc = 16;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_core_loads<MODE>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, src, src_elems, out, iters);
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_core_loads<MODE>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, src, src_elems, out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  \"%s\": {\"ns_per_transform_per_block\": %.0f, \"ns_per_transform_per_cu\": %.0f, \"load_TBps\": %.2f}%s\n", name,
+           ms * 1e6 / iters / (bpc / 2), ms * 1e6 / iters / bpc,
+           MODE ? (double)n_cu * bpc * iters * 32768.0 / (ms * 1e-3) / 1e12 : 0.0, last ? "" : ",");
+}
+
+// ---- the same transform under the mid pass's REGISTER pressure: four live accumulator rows (128 VGPRs) next to the
+// row being transformed, as in k_mid_seg_one (250 VGPRs there).  Does the compiler still schedule the exchanges as
+// "sixteen reads, one wait, butterflies", or does it trickle them through the few free registers?
+__global__ __launch_bounds__(256, 2) void k_core_pressure(const cf* __restrict__ tw, cf* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int L = 4096;
+    const int u = threadIdx.x;
+    RowAddr<L> addr(0, u);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf v[16], acc[4][16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[a][q] = mk(0.f, (float)a);
+    }
+    for (int it = 0; it < iters; it += 4) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            fft_regs<L, RowAddr<L>, true>(v, lds, u, addr, twr);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][q] = cmac(acc[a][q], v[q], twr.s1.w[q % 6]);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(v[q]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+        out[((size_t)blockIdx.x * 256 + u) * 16 + q] = cadd(cadd(acc[0][q], acc[1][q]), cadd(cadd(acc[2][q], acc[3][q]), v[q]));
+}
+
+// ---- the same loads through LDS-DMA (global_load_lds_dwordx4: global -> LDS without touching a VGPR), read back with
+// ds_read_b64 when the item's turn comes: does the transform keep its pace next to loads that bypass the register file?
+// LDS: row buffer + 32 KB of staging (8 KB per wave: sixteen 512-byte pieces), two resident blocks.
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_core_dma(const cf* __restrict__ tw, const cf* __restrict__ src, size_t src_elems,
+                                                      cf* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cf* lds = reinterpret_cast<cf*>(smem);
+    constexpr int L = 4096;
+    const int u = threadIdx.x, lane = u & 63, wv = u >> 6;
+    cf* stage = lds + RowAddr<L>::ROW_ELEMS + wv * 1024;  // this wave's 8 KB
+    RowAddr<L> addr(0, u);
+    TwRegs<L> twr;
+    twr.load(tw, u);
+    cf v[16], acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        v[q] = mk(1e-3f * (float)(u + q), 1e-3f * (float)(u - q));
+        acc[q] = mk(0.f, 0.f);
+    }
+    const size_t row_elems = 16 * 16384;
+    size_t row = ((size_t)blockIdx.x * 977) % (src_elems / row_elems);
+    auto request = [&]() {
+        // one instruction = 1 KB = two 512-byte pieces (q, q + 1): lanes 0..31 piece q, lanes 32..63 piece q + 1, 16 B each
+        const char* p = reinterpret_cast<const char*>(src + row * row_elems + wv * 64) + (lane & 31) * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const char* g = p + (size_t)(2 * j + (lane >> 5)) * 16384 * sizeof(cf);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(stage + j * 128), 16, 0, 0);
+        }
+        row = (row + (MODE == 2 ? 1031 : 1)) % (MODE == 2 ? (src_elems / row_elems) : 8);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    request();
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed (it reads only its own pieces)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = cadd(v[q], stage[q * 64 + lane]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        request();
+        fft_regs<L, RowAddr<L>, true>(v, lds, u, addr, twr);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = cmac(acc[q], v[q], twr.s1.w[q % 6]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(v[q]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 16; ++q) out[((size_t)blockIdx.x * 256 + u) * 16 + q] = acc[q] + v[q];
+}
+template <int MODE>
+static void run_dma(const char* name, const cf* tw, const cf* src, size_t src_elems, cf* out, int n_cu, bool last) {
+    const size_t lds = (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf) + 32768;
+    CHECK(hipFuncSetAttribute((const void*)k_core_dma<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int iters = 100, bpc = 16;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_core_dma<MODE>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, src, src_elems, out, iters);
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_core_dma<MODE>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, src, src_elems, out, iters);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  \"%s\": {\"ns_per_transform_per_block\": %.0f, \"ns_per_transform_per_cu\": %.0f, \"load_TBps\": %.2f}%s\n", name,
+           ms * 1e6 / iters / (bpc / 2), ms * 1e6 / iters / bpc, (double)n_cu * bpc * iters * 32768.0 / (ms * 1e-3) / 1e12,
+           last ? "" : ",");
+}
+
 template <bool OFFSET>
 static void run_duo(const char* name, const cf* tw, cf* out, int n_cu, bool last) {
     const size_t lds = 2 * (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf);
@@ -369,7 +541,7 @@ int main() {
     cf *tw, *out;
     CHECK(hipMalloc(&tw, 1 << 20));
     CHECK(hipMemset(tw, 0x3c, 1 << 20));  // small finite floats: timing only
-    CHECK(hipMalloc(&out, (size_t)n_cu * 4 * 512 * 16 * sizeof(cf)));
+    CHECK(hipMalloc(&out, (size_t)n_cu * 16 * 512 * 16 * sizeof(cf)));
     printf("{\"cus\": %d, \"unit\": \"[ns per transform per block, ns per transform per CU] for one 4096-point row transform + 16 cmacs\",\n", n_cu);
     run<FULL>("full", tw, out, n_cu, false);
     run<NO_LDS>("no_lds", tw, out, n_cu, false);
@@ -379,7 +551,54 @@ int main() {
     run<PLANAR_NO_VALU>("planar_addtid_no_valu", tw, out, n_cu, false);
     run_duo<true>("duo_staggered", tw, out, n_cu, false);
     run_duo<false>("duo_lockstep", tw, out, n_cu, false);
-    run_wave1024(tw, out, n_cu, true);
+    run_wave1024(tw, out, n_cu, false);
+    {   // the product transform with the mid pass's footprint: 66.8 KB of LDS per block caps the CU at two resident
+        // blocks whatever the dispatcher does; 16 blocks per CU in the grid keep both slots filled
+        const size_t lds = (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf) + 32768;
+        CHECK(hipFuncSetAttribute((const void*)k_core<FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const int iters = 100, bpc = 16;
+        hipEvent_t e0, e1;
+        CHECK(hipEventCreate(&e0));
+        CHECK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(k_core<FULL>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_core<FULL>, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        // bpc blocks per CU run two at a time: bpc/2 rounds of `iters` transforms each
+        printf("  \"full_exactly_two_resident_blocks\": {\"ns_per_transform_per_block\": %.0f, \"ns_per_transform_per_cu\": %.0f},\n",
+               ms * 1e6 / iters / (bpc / 2), ms * 1e6 / iters / bpc);
+    }
+    {
+        cf* src;
+        const size_t src_elems = (size_t)1 << 28;  // 2 GB
+        CHECK(hipMalloc(&src, src_elems * sizeof(cf)));
+        CHECK(hipMemset(src, 0, src_elems * sizeof(cf)));
+        {
+            const size_t lds = (size_t)RowAddr<4096>::ROW_ELEMS * sizeof(cf) + 32768;
+            CHECK(hipFuncSetAttribute((const void*)k_core_pressure, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int iters = 100, bpc = 16;
+            hipEvent_t e0, e1;
+            CHECK(hipEventCreate(&e0));
+            CHECK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(k_core_pressure, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+            CHECK(hipEventRecord(e0));
+            hipLaunchKernelGGL(k_core_pressure, dim3(n_cu * bpc), dim3(256), lds, 0, tw, out, iters);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("  \"four_live_accumulator_rows\": {\"ns_per_transform_per_block\": %.0f, \"ns_per_transform_per_cu\": %.0f},\n",
+                   ms * 1e6 / iters / (bpc / 2), ms * 1e6 / iters / bpc);
+        }
+        run_loads<0>("with_loads_none", tw, src, src_elems, out, n_cu, false);
+        run_loads<1>("with_loads_l2_resident", tw, src, src_elems, out, n_cu, false);
+        run_loads<2>("with_loads_hbm", tw, src, src_elems, out, n_cu, false);
+        run_dma<1>("with_lds_dma_l2_resident", tw, src, src_elems, out, n_cu, false);
+        run_dma<2>("with_lds_dma_hbm", tw, src, src_elems, out, n_cu, true);
+    }
     printf("}\n");
     return 0;
 }
