@@ -32,6 +32,7 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
 constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD
+constexpr int PAIR_REF_LAST = 16;  // k_pass_a3: slot 0 and the last slot come from the PAIRED launch (two real vectors, one transform)
 // Section experiments (timing only, WRONG RESULTS): compiled in by `make lab` (-DFFS_LAB -> libffsalign_lab.so) and
 // selected there through FFS_MID_DEBUG / FFS_PASS_A_DEBUG; the product library contains none of it -- FFS_LABF() is a
 // constant false and the branches fold away.
@@ -1314,6 +1315,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c(const cf* __restrict__ 
 }
 
 // --------------------------------------------------------------------------------------------
+#ifndef FFS_A3P_WAVES
+#define FFS_A3P_WAVES 3
+#endif
 #ifndef FFS_C3P_CHUNK
 #define FFS_C3P_CHUNK 16
 #endif
@@ -1419,8 +1423,14 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_C3P_WAVES : FFS_C3_W
 // pass A for columns of length L = NS*LI, bit-packed inputs, all sub-transforms of a column in one thread (colnr_fft).
 // grid = (N2/C, n_transforms); block = (LI/16)*C = 256 threads; same outputs as k_pass_a<L, ., 2>.
 // tbR[u][n2] = W_N^(n2*u) (u < LTI), tsR[i][n2] = W_N^(n2*LTI*2^i) (i < 4), thR[r-1][n2] = W_N^(n2*LI*r) (0 < r < NS).
-template <int NS, int LI, int C>
-__global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* __restrict__ descs, cf* __restrict__ work, int N2,
+// PAIRED (round 3; launched on its own over grid = (N2/C, n_pairs) when the reference slot AND the last candidate slot
+// are half slots): both hold ONE real vector, so their columns share one complex column transform -- z = ref + i*cand,
+// Z = R + i*S with R, S Hermitian, hence  R[k] = (Z[k] + conj(Z[L-k]))/2,  S[k] = (Z[k] - conj(Z[L-k]))/(2i)  for the
+// stored rows k <= L/2.  The mirror rows Z[L-k] sit in other threads of the same column: they go through the LDS tile
+// once (rows >= L/2 only, one LI-row block at a time).  One column transform + one exchange instead of two column
+// transforms; the plain instantiation then skips slot 0 and the last slot (PAIR_REF_LAST).
+template <int NS, int LI, int C, bool PAIRED>
+__global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_WAVES) void k_pass_a3(const XformDesc* __restrict__ descs, cf* __restrict__ work, int N2,
                                                  long long N, const cf* __restrict__ tw, const cf* __restrict__ tbR,
                                                  const cf* __restrict__ tsR, const cf* __restrict__ thR,
                                                  const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
@@ -1433,10 +1443,18 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
         prefetch_bit_inputs(descs, (int)blockIdx.y + ((half_flags >> 16) & 255), (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
         return;
     }
+    if (!PAIRED && (half_flags & PAIR_REF_LAST)) {  // slot 0 and the last slot are produced by the PAIRED launch
+        const int xi0 = blockIdx.y % xf_per_pair;
+        if (xi0 == 0 || xi0 == xf_per_pair - 1) return;
+    }
     const int c = threadIdx.x % C, u = threadIdx.x / C;
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;  // see k_pass_a
     const int n2 = tile * C + c;
-    const XformDesc d = descs[blockIdx.y];
+    XformDesc d = descs[PAIRED ? blockIdx.y * xf_per_pair : blockIdx.y];
+    if constexpr (PAIRED) {  // the imaginary half = the single candidate of the pair's last transform
+        const XformDesc dl = descs[blockIdx.y * xf_per_pair + xf_per_pair - 1];
+        d.b = dl.a, d.off_b = dl.off_a, d.len_b = dl.len_a, d.lead_b = dl.lead_a, d.b0 = dl.a0, d.b1 = dl.a1;
+    }
     TwRegs<LI> twr;
     twr.load(tw, u);
     const cf wu = tw3[u], wu2 = tw3[2 * u];
@@ -1513,23 +1531,56 @@ __global__ __launch_bounds__(256, FFS_C3_WAVES) void k_pass_a3(const XformDesc* 
     for (int q = 0; q < 4; ++q) wq[4 + q] = cmul(wq[q], g4);
 #pragma unroll
     for (int q = 0; q < 8; ++q) wq[8 + q] = cmul(wq[q], g8);
-    cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
-    const int xi = blockIdx.y % xf_per_pair;
-    const int k1_end = (((half_flags & HALF_REF) && xi == 0) || ((half_flags & HALF_LAST) && xi == xf_per_pair - 1))
-                           ? L / 2 + 1 : L;
-    char* outb = reinterpret_cast<char*>(out);
     const unsigned o0 = ((unsigned)tile_base<L, C>(tile, c, log2CL) + ((unsigned)u << log2CL)) * (unsigned)sizeof(cf);
     const unsigned ostep = ((unsigned)LTI << log2CL) * (unsigned)sizeof(cf);
+    auto row_off = [&](int r, int q) { return o0 + ostep * q + (((unsigned)(LI * r)) << log2CL) * (unsigned)sizeof(cf); };
+    auto tw_of = [&](int r, int q) { return r == 0 ? wq[q] : cmul(wq[q], r == 1 ? h1 : h2); };
+    if constexpr (PAIRED) {
+        char* out_r = reinterpret_cast<char*>(work + ((size_t)blockIdx.y * slots_per_pair) * N);
+        char* out_s = reinterpret_cast<char*>(work + ((size_t)blockIdx.y * slots_per_pair + slots_per_pair - 1) * N);
+        // row k1 <= L/2 from Z[k1] = z and its mirror Z[L-k1] = m
+        auto emit = [&](int r, int q, cf z, cf m) {
+            const cf w = tw_of(r, q);
+            const cf a = mk(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));   // (z + conj(m)) / 2
+            const cf b = mk(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));  // (z - conj(m)) / (2i)
+            *reinterpret_cast<cf*>(out_r + row_off(r, q)) = cmul(a, w);
+            *reinterpret_cast<cf*>(out_s + row_off(r, q)) = cmul(b, w);
+        };
+        if (u == 0) emit(0, 0, v[0][0], v[0][0]);  // row 0 mirrors onto itself
 #pragma unroll
-    for (int r = 0; r < NS; ++r) {
-        if (LI * r >= k1_end) break;  // block-uniform: the whole third of the rows is beyond the stored half
+        for (int rr = NS - 1; rr >= 1; --rr) {
+            // rows [LI*rr, LI*(rr+1)) through the tile; they are the mirrors of rows (L - LI*(rr+1), L - LI*rr]
+            __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf w = r == 0 ? wq[q] : cmul(wq[q], r == 1 ? h1 : h2);
-            const int k1 = u + LTI * q + LI * r;
-            if (k1 < k1_end)
-                *reinterpret_cast<cf*>(outb + (o0 + ostep * q + (((unsigned)(LI * r)) << log2CL) * (unsigned)sizeof(cf))) =
-                    cmul(v[r][q], w);
+            for (int q = 0; q < 16; ++q) lds[(u + LTI * q) * C + c] = v[rr][q];
+            __syncthreads();
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int lo = L - LI * (rr + 1), hi = L - LI * rr;  // compile-time after unrolling
+#pragma unroll
+            for (int r = 0; r < NS; ++r)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k_min = LTI * q + LI * r, k_max = k_min + LTI - 1;
+                    if (k_max <= lo || k_min > hi || k_min > L / 2) continue;  // no lane of this (r, q) is in range
+                    const int k1 = u + k_min;
+                    if (k1 > lo && k1 <= hi && k1 <= L / 2) emit(r, q, v[r][q], lds[(L - k1 - LI * rr) * C + c]);
+                }
+        }
+    } else {
+        cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+        const int xi = blockIdx.y % xf_per_pair;
+        const int k1_end = (((half_flags & HALF_REF) && xi == 0) || ((half_flags & HALF_LAST) && xi == xf_per_pair - 1))
+                               ? L / 2 + 1 : L;
+        char* outb = reinterpret_cast<char*>(out);
+#pragma unroll
+        for (int r = 0; r < NS; ++r) {
+            if (LI * r >= k1_end) break;  // block-uniform: the whole third of the rows is beyond the stored half
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int k1 = u + LTI * q + LI * r;
+                if (k1 < k1_end) *reinterpret_cast<cf*>(outb + row_off(r, q)) = cmul(v[r][q], tw_of(r, q));
+            }
         }
     }
 }

@@ -319,12 +319,24 @@ int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int
                         int ref_half, hipStream_t st) {
     const size_t lds = (size_t)LI * C * sizeof(cf);
     int rc_lds;
-    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C>, lds))) return rc_lds;
     const int nt = p->N2 / C;
     const int ahead = nt % 8 == 0 ? bit_prefetch_rows(p) : 0;  // eight prefetch blocks per grid row, one per XCD
-    hipLaunchKernelGGL((k_pass_a3<NS, LI, C>), dim3(nt + (ahead ? 8 : 0), n_xf), dim3(256), lds, st, descs, p->work, p->N2,
-                       (long long)p->N, NS == 2 ? p->tw1h : p->tw1,
-                       p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ref_half | (ahead << 16));
+    const cf* tw = NS == 2 ? p->tw1h : p->tw1;
+    // reference slot and last candidate slot both half slots (one real vector each): one paired column transform
+    const bool paired = (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 && xf_per_pair == slots_per_pair;
+    const int flags = ref_half | (ahead << 16) | (paired ? PAIR_REF_LAST : 0);
+    if (!paired || xf_per_pair > 2) {
+        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, false>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_pass_a3<NS, LI, C, false>), dim3(nt + (ahead ? 8 : 0), n_xf), dim3(256), lds, st, descs, p->work,
+                           p->N2, (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair,
+                           nt, flags);
+    }
+    if (paired) {
+        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, true>, lds))) return rc_lds;
+        hipLaunchKernelGGL((k_pass_a3<NS, LI, C, true>), dim3(nt, n_xf / xf_per_pair), dim3(256), lds, st, descs, p->work, p->N2,
+                           (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt,
+                           ref_half);
+    }
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
