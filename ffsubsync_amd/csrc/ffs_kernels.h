@@ -299,7 +299,11 @@ FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int
 // --------------------------------------------------------------------------------------------
 // pass A.  grid = (N2/C column tiles [+ input prefetch blocks: N2/128 for byte inputs, 8 (one per XCD) for bit-packed
 // ones], n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
-template <int L, int C, int DT>
+// PAIRED (bit-packed inputs, power-of-two columns; grid.y = transform GROUPS): a group's reference and its single last
+// candidate are both real vectors with half slots, so ONE column transform of z = ref + i*last serves both -- per column
+// ref^[k1] = (Z[k1] + conj Z[L-k1])/2 and last^[k1] = (Z[k1] - conj Z[L-k1])/(2i), the mirror rows fetched through the
+// column tile in LDS -- and the plain launch (flag PAIR_REF_LAST) leaves those two transforms out.
+template <int L, int C, int DT, bool PAIRED = false>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
@@ -337,6 +341,10 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         prefetch_bit_inputs(descs, (int)blockIdx.y + pf_ahead, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, LT * C);
         return;
     }
+    if constexpr (!PAIRED) {
+        const int xi0 = blockIdx.y % xf_per_pair;
+        if ((half_flags & PAIR_REF_LAST) && (xi0 == 0 || xi0 == xf_per_pair - 1)) return;
+    }
     const int c = threadIdx.x % C;
     const int u = threadIdx.x / C;
     // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), and the input
@@ -344,7 +352,12 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // tiles instead of every eighth one -- otherwise each input line is fetched by up to 8 L2s.
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int n2 = tile * C + c;
-    const XformDesc d = descs[FFS_LABF(half_flags, DBG_PA_HOT_INPUT) ? 0 : blockIdx.y];
+    XformDesc d = descs[PAIRED ? blockIdx.y * xf_per_pair : (FFS_LABF(half_flags, DBG_PA_HOT_INPUT) ? 0 : blockIdx.y)];
+    if constexpr (PAIRED) {
+        static_assert(DT == 2 && !CS::R3, "paired first pass: bit-packed inputs, power-of-two columns");
+        const XformDesc dl = descs[blockIdx.y * xf_per_pair + xf_per_pair - 1];
+        d.b = dl.a, d.len_b = dl.len_a, d.b0 = dl.a0, d.b1 = dl.a1, d.lead_b = dl.lead_a, d.off_b = dl.off_a;
+    }
     // every table value this thread needs is requested up front, together with the inputs
     // (tiles of 64+ columns: u is the wave's row phase, the stage twiddles are wave-uniform -> scalar registers)
     constexpr bool TWS = (C % 64 == 0) && !CS::R3 && (LT > 1) && (LT < 16);
@@ -469,7 +482,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     }
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
-    cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+    cf* out = PAIRED ? work + (size_t)blockIdx.y * slots_per_pair * N
+                     : work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
     if FFS_LABF(half_flags, DBG_PA_HOT_STORE) out = work;
     // HALF_REF: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
     // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all.
@@ -533,6 +547,29 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     wq[9] = cmul(wq[3], wq[4]);   // h_5
     wq[10] = cmul(wq[5], wq[4]);  // h_6
     wq[11] = cmul(wq[6], wq[4]);  // h_7
+    if constexpr (PAIRED) {
+        // v[q] = Z[k1 = u + LT*q] of z = ref + i*last (no twiddle yet: the mirror row has its own).  The raw column goes
+        // through the tile in LDS, every thread picks up Z[L - k1] for its rows k1 <= L/2 and writes the two separated
+        // spectra, times W_N^(n2*k1), to the reference slot and the last slot (half slots: rows 0..L/2).
+        const cf h[9] = {wq[0], wq[3], wq[5], wq[6], wq[7], wq[9], wq[10], wq[11], cmul(wq[0], wq[8])};
+        __syncthreads();  // the transform's last exchange has been read
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lds[(u + LT * q) * C + c] = v[q];
+        __syncthreads();
+        cf* out_l = out + (size_t)(xf_per_pair - 1) * N;
+        const size_t o0 = tile_base<L, C>(tile, c, log2CL);
+#pragma unroll
+        for (int q = 0; q <= 8; ++q) {
+            const int k1 = u + LT * q;
+            if (k1 > L / 2) continue;
+            const cf m = lds[((L - k1) & (L - 1)) * C + c];
+            const cf a = mk(0.5f * (v[q].x + m.x), 0.5f * (v[q].y - m.y));
+            const cf b = mk(0.5f * (v[q].y + m.y), 0.5f * (m.x - v[q].x));
+            out[o0 + ((size_t)k1 << log2CL)] = cmul(a, h[q]);
+            out_l[o0 + ((size_t)k1 << log2CL)] = cmul(b, h[q]);
+        }
+        return;
+    }
     {
         const cf h[8] = {wq[0], wq[3], wq[5], wq[6], wq[7], wq[9], wq[10], wq[11]};
 #pragma unroll
