@@ -51,6 +51,8 @@ EXPORTED_SYMBOLS = (
     "ffs_raster_intervals",
     "ffs_rasterize_subtitles",
     "ffs_rasterize_subtitles_bits",
+    "ffs_raster_lengths",
+    "ffs_rasterize_batch_bits",
     "ffs_pack_bits",
     "ffs_scatter_segments",
     "ffs_comm_unique_id",
@@ -145,6 +147,12 @@ def load():
                                                 c.c_double, c.c_void_p, c.c_int64, c.c_void_p]
         lib.ffs_rasterize_subtitles_bits.restype = c.c_int
         lib.ffs_rasterize_subtitles_bits.argtypes = lib.ffs_rasterize_subtitles.argtypes
+        lib.ffs_raster_lengths.restype = c.c_int
+        lib.ffs_raster_lengths.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_void_p]
+        lib.ffs_rasterize_batch_bits.restype = c.c_int
+        lib.ffs_rasterize_batch_bits.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p,
+                                                 c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_double,
+                                                 c.c_void_p, c.c_int64, c.c_void_p]
         lib.ffs_pack_bits.restype = c.c_int
         lib.ffs_pack_bits.argtypes = [c.c_void_p, c.c_int, c.c_int64, c.c_double, c.c_void_p, c.c_void_p]
         lib.ffs_scatter_segments.restype = c.c_int
@@ -423,6 +431,39 @@ def rasterize_subtitles(start_us, end_us, is_metadata, ratio, sample_rate=100.0,
     check(fn(start_us.ctypes.data, end_us.ctypes.data, None if meta is None else meta.ctypes.data, start_us.size,
              float(ratio), float(sample_rate), float(start_seconds), out.data_ptr(), n, current_stream_ptr(torch)))
     return (out, n) if packed else out
+
+
+def raster_lengths(track_end_us_max, ratio, sample_rate=100.0) -> np.ndarray:
+    """Host-only: raster lengths of many vectors at once (``ffs_raster_lengths``): vector v is a track whose largest
+    end time is ``track_end_us_max[v]`` microseconds, scaled by ``ratio[v]``."""
+    ends = np.ascontiguousarray(track_end_us_max, dtype=np.int64)
+    ratio = np.ascontiguousarray(ratio, dtype=np.float64)
+    if ends.shape != ratio.shape:
+        raise ValueError("one ratio per vector")
+    out = np.zeros(ends.size, dtype=np.int64)
+    check(load().ffs_raster_lengths(ends.ctypes.data, ratio.ctypes.data, ends.size, float(sample_rate), out.ctypes.data))
+    return out
+
+
+def rasterize_batch_bits(start_us, end_us, is_metadata, vec_sub_first, vec_sub_count, vec_ratio, vec_out_word, vec_len,
+                         out, sample_rate=100.0, start_seconds=0.0) -> None:
+    """``ffs_rasterize_batch_bits``: every vector of a batch from ONE call, interval arithmetic on the device.  The
+    tracks are concatenated in ``start_us`` / ``end_us`` / ``is_metadata``; vector v covers subtitles
+    [vec_sub_first[v], +vec_sub_count[v]) scaled by vec_ratio[v] and lands as vec_len[v] bits at word vec_out_word[v]
+    of ``out`` (int32 / uint8 CUDA tensor, zeroed by the call)."""
+    torch = require_gpu()
+    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    first, count, word, length = i64(vec_sub_first), i64(vec_sub_count), i64(vec_out_word), i64(vec_len)
+    ratio = np.ascontiguousarray(vec_ratio, dtype=np.float64)
+    n_vec = first.size
+    if not (count.size == word.size == length.size == ratio.size == n_vec):
+        raise ValueError("the vector tables must have the same length")
+    out_words = out.numel() * out.element_size() // 4
+    check(load().ffs_rasterize_batch_bits(start_us.ctypes.data, end_us.ctypes.data, None if meta is None else meta.ctypes.data,
+                                          start_us.size, first.ctypes.data, count.ctypes.data, ratio.ctypes.data,
+                                          word.ctypes.data, length.ctypes.data, n_vec, float(sample_rate),
+                                          float(start_seconds), out.data_ptr(), out_words, current_stream_ptr(torch)))
 
 
 def packed_words(n: int) -> int:

@@ -96,6 +96,35 @@ def pack_pairs(pairs, packed: bool = True) -> DeviceBatch:
     return DeviceBatch(data, offs, lens, lo, hi, _native.FFS_DTYPE_U1 if packed else _native.FFS_DTYPE_U8)
 
 
+def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 100, start_seconds: float = 0) -> DeviceBatch:
+    """Bit-packed DeviceBatch straight from subtitle interval lists: ``records`` is a list of
+    (reference_track, candidate_track), a track being (start_us, end_us, is_metadata) arrays
+    (``subtitle_raster.subtitle_records``).  The reference track is rasterised as it is, the candidate track once per
+    framerate ratio (``SubtitleScaler`` + ``SubtitleSpeechTransformer``: times scaled by the ratio, amplitude
+    min(1/ratio, 1)) -- all of it by ONE ``ffs_rasterize_batch_bits`` call that writes into the batch buffer (interval
+    arithmetic on the device; no per-vector tensors, no pack copy).  Same vectors as ``pack_pairs`` over
+    ``subtitle_raster.rasterize_candidates``."""
+    torch = _native.require_gpu()
+    ratios = [float(r) for r in ratios]
+    n_pairs, n_vec = len(records), 1 + len(ratios)
+    tracks = [t for rec in records for t in rec]  # track 2p: pair p's reference, 2p + 1: its candidates
+    counts = np.array([len(t[0]) for t in tracks], dtype=np.int64)
+    firsts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64) if len(tracks) else np.zeros(0, np.int64)
+    cat = lambda k, dt: (np.concatenate([np.asarray(t[k], dtype=dt) for t in tracks]) if len(tracks) else np.zeros(0, dt))
+    start_us, end_us = cat(0, np.int64), cat(1, np.int64)
+    meta = None if any(t[2] is None for t in tracks) else cat(2, np.uint8)
+    end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64).reshape(n_pairs, 2)
+    track_of = np.tile(np.array([0] + [1] * len(ratios)), (n_pairs, 1)) + 2 * np.arange(n_pairs)[:, None]
+    ratio = np.tile(np.array([1.0] + ratios), (n_pairs, 1))
+    lens = _native.raster_lengths(end_max.ravel()[track_of.ravel()], ratio.ravel(), sample_rate).reshape(n_pairs, n_vec)
+    offs, total = _layout(lens, (lens + 31) // 32 * 4)
+    data = torch.empty(total, dtype=torch.uint8, device="cuda")
+    _native.rasterize_batch_bits(start_us, end_us, meta, firsts[track_of.ravel()], counts[track_of.ravel()], ratio.ravel(),
+                                 offs.ravel() // 4, lens.ravel(), data, sample_rate, start_seconds)
+    hi = np.minimum(1.0 / ratio, 1.0)
+    return DeviceBatch(data, offs, lens, np.zeros_like(hi), hi, _native.FFS_DTYPE_U1)
+
+
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous block of ceil(n/world) items per rank: [lo, hi)."""
     per = (n_items + world - 1) // world

@@ -2533,6 +2533,92 @@ __global__ __launch_bounds__(256) void k_vad_tokenize_scan(const float* __restri
     }
 }
 
+// ---- subtitle rasteriser arithmetic, shared by the host entry points and the batched kernel --------------------
+// (fp64 IEEE operations only -- division, multiplication, modf, round, rint -- so host and device agree bit for bit;
+// contraction is off inside them: nothing here may turn into an fma)
+// Python slice semantics of  x[:stop] = v  /  x[start:] = v  on a length-n array
+FFS_HD long long slice_clamp(long long i, long long n) {
+    if (i < 0) i += n;
+    if (i < 0) i = 0;
+    if (i > n) i = n;
+    return i;
+}
+// datetime.timedelta(seconds=x).total_seconds() for a float x >= 0, i.e. x rounded to whole
+// microseconds the way CPython's delta_new/accum does it (integer part exact, fractional part
+// times 1e6 split again, leftover rounded half-to-even on the accumulated parity).
+FFS_HD long long timedelta_us(double x) {
+#pragma clang fp contract(off)
+    double ip;
+    const double fr = modf(x, &ip);
+    long long us = (long long)ip * 1000000;
+    if (fr != 0.0) {
+        double ip2;
+        const double fr2 = modf(1e6 * fr, &ip2);
+        us += (long long)ip2;
+        if (fr2 != 0.0) {
+            double whole = round(fr2);
+            if (fabs(whole - fr2) == 0.5) {
+                const int is_odd = (int)(us & 1);
+                whole = 2.0 * round((fr2 + is_odd) * 0.5) - is_odd;
+            }
+            us += (long long)whole;
+        }
+    }
+    return us;
+}
+FFS_HD double scaled_seconds(long long us, double ratio) {
+#pragma clang fp contract(off)
+    const double t = (double)us / 1e6;                  // timedelta.total_seconds()
+    return (double)timedelta_us(t * ratio) / 1e6;       // SubtitleScaler: timedelta(seconds=t*ratio)
+}
+// one subtitle's clamped [a, b) sample interval of a raster of out_len samples (speech_transformers.py:968-975)
+FFS_HD bool raster_interval(long long start_us, long long end_us, double ratio, double sample_rate, double start_seconds,
+                            long long out_len, long long* a, long long* b) {
+#pragma clang fp contract(off)
+    const double ts = scaled_seconds(start_us, ratio), te = scaled_seconds(end_us, ratio);
+    const long long start = (long long)rint((ts - start_seconds) * sample_rate);   // :968-972 (round half even)
+    const long long end = start + (long long)rint((te - ts) * sample_rate);        // :974-975
+    *a = slice_clamp(start, out_len);                                              // samples[start:end] = ...
+    *b = slice_clamp(end, out_len);
+    return *a < *b;
+}
+
+// OR the bits [a, b) of a word array (edge words masked); `lane` of `lanes` cooperating threads
+FFS_DEV void or_bit_range(unsigned* __restrict__ out, long long a, long long b, int lane, int lanes) {
+    const long long w_first = a >> 5, w_last = (b - 1) >> 5;
+    for (long long w = w_first + lane; w <= w_last; w += lanes) {
+        unsigned m = 0xffffffffu;
+        if (w == w_first) m &= 0xffffffffu << (a & 31);
+        if (w == w_last) m &= 0xffffffffu >> (31 - ((b - 1) & 31));
+        atomicOr(&out[w], m);
+    }
+}
+
+// Batched rasteriser (ffs_rasterize_batch_bits): vector v = the subtitles [sub_first, sub_first + sub_count) of the
+// concatenated tracks, times scaled by `ratio`, as `len` bits starting at word `out_word` of the batch buffer.
+struct RasterVec {
+    long long sub_first, out_word;
+    double ratio;
+    int sub_count, len;
+};
+// grid = (blocks over the longest track, vectors); one thread per (vector, subtitle): the interval arithmetic above,
+// then the subtitle's 5-20 words (a 2-6 s line at 100 Hz).
+__global__ __launch_bounds__(256) void k_rasterize_batch(const long long* __restrict__ start_us, const long long* __restrict__ end_us,
+                                                         const unsigned char* __restrict__ meta, const RasterVec* __restrict__ vecs,
+                                                         int n_vec, double sample_rate, double start_seconds,
+                                                         unsigned* __restrict__ out) {
+    for (int v = blockIdx.y; v < n_vec; v += gridDim.y) {
+        const RasterVec rv = vecs[v];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rv.sub_count; i += gridDim.x * blockDim.x) {
+            const long long k = rv.sub_first + i;
+            if (meta && meta[k]) continue;  // speech_transformers.py:966-967
+            long long a, b;
+            if (raster_interval(start_us[k], end_us[k], rv.ratio, sample_rate, start_seconds, rv.len, &a, &b))
+                or_bit_range(out + rv.out_word, a, b, 0, 1);
+        }
+    }
+}
+
 // subtitle rasteriser: one wave per [start, end) interval, byte stores of 1 (overlaps are unions)
 __global__ __launch_bounds__(256) void k_fill_intervals(const int2* __restrict__ iv, int n, unsigned char* __restrict__ out) {
     const int lane = threadIdx.x & 63;

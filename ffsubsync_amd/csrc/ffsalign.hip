@@ -1239,33 +1239,6 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     return leave_stream(p, st);
 }
 
-// datetime.timedelta(seconds=x).total_seconds() for a float x >= 0, i.e. x rounded to whole
-// microseconds the way CPython's delta_new/accum does it (integer part exact, fractional part
-// times 1e6 split again, leftover rounded half-to-even on the accumulated parity).
-static int64_t timedelta_us(double x) {
-    double ip;
-    const double fr = modf(x, &ip);
-    int64_t us = (int64_t)ip * 1000000;
-    if (fr != 0.0) {
-        double ip2;
-        const double fr2 = modf(1e6 * fr, &ip2);
-        us += (int64_t)ip2;
-        if (fr2 != 0.0) {
-            double whole = round(fr2);
-            if (fabs(whole - fr2) == 0.5) {
-                const int is_odd = (int)(us & 1);
-                whole = 2.0 * round((fr2 + is_odd) * 0.5) - is_odd;
-            }
-            us += (int64_t)whole;
-        }
-    }
-    return us;
-}
-static double scaled_seconds(int64_t us, double ratio) {
-    const double t = (double)us / 1e6;                  // timedelta.total_seconds()
-    return (double)timedelta_us(t * ratio) / 1e6;       // SubtitleScaler: timedelta(seconds=t*ratio)
-}
-
 int64_t ffs_raster_length(const int64_t* end_us, int64_t n_subs, double ratio, double sample_rate) {
     double max_time = 0.0;  // speech_transformers.py:958-960
     for (int64_t i = 0; i < n_subs; ++i) {
@@ -1275,16 +1248,21 @@ int64_t ffs_raster_length(const int64_t* end_us, int64_t n_subs, double ratio, d
     return (int64_t)(max_time * sample_rate) + 2;       // :962
 }
 
+int ffs_raster_lengths(const int64_t* track_end_us_max, const double* ratio, int64_t n_vec, double sample_rate, int64_t* len_out) {
+    if (n_vec < 0 || (n_vec > 0 && (!track_end_us_max || !ratio || !len_out))) return fail(FFS_E_INVALID, "bad argument");
+    // the scaling is monotone (division, multiplication and the microsecond rounding all are), so a track's largest
+    // scaled end is the scaled largest end
+    for (int64_t v = 0; v < n_vec; ++v) len_out[v] = ffs_raster_length(&track_end_us_max[v], 1, ratio[v], sample_rate);
+    return FFS_OK;
+}
+
 int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs,
                              double ratio, double sample_rate, double start_seconds, int64_t out_len, int32_t* iv_out) {
     int64_t n = 0;
     for (int64_t i = 0; i < n_subs; ++i) {
         if (is_metadata && is_metadata[i]) continue;    // speech_transformers.py:966-967
-        const double ts = scaled_seconds(start_us[i], ratio), te = scaled_seconds(end_us[i], ratio);
-        const int64_t start = (int64_t)rint((ts - start_seconds) * sample_rate);   // :968-972 (round half even)
-        const int64_t end = start + (int64_t)rint((te - ts) * sample_rate);        // :974-975
-        const int64_t a = py_clamp(start, out_len), b = py_clamp(end, out_len);    // samples[start:end] = ...
-        if (a < b) {
+        long long a, b;
+        if (raster_interval(start_us[i], end_us[i], ratio, sample_rate, start_seconds, out_len, &a, &b)) {
             iv_out[2 * n] = (int32_t)a;
             iv_out[2 * n + 1] = (int32_t)b;
             ++n;
@@ -1350,6 +1328,63 @@ int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us,
                                  int64_t out_len, void* hip_stream) {
     return rasterize_impl(start_us, end_us, is_metadata, n_subs, ratio, sample_rate, start_seconds, out_dev, out_len, true,
                           hip_stream);
+}
+
+int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs_total,
+                             const int64_t* vec_sub_first, const int64_t* vec_sub_count, const double* vec_ratio,
+                             const int64_t* vec_out_word, const int64_t* vec_len, int64_t n_vec, double sample_rate,
+                             double start_seconds, uint32_t* out_dev, int64_t out_words, void* hip_stream) {
+    if (n_vec < 0 || n_subs_total < 0 || out_words < 0) return fail(FFS_E_INVALID, "bad argument");
+    if (n_vec > 0 && (!vec_sub_first || !vec_sub_count || !vec_ratio || !vec_out_word || !vec_len))
+        return fail(FFS_E_INVALID, "null vector table");
+    if (n_subs_total > 0 && (!start_us || !end_us)) return fail(FFS_E_INVALID, "null subtitle arrays");
+    if (out_words > 0 && (!out_dev || ((uintptr_t)out_dev & 3))) return fail(FFS_E_INVALID, "null or misaligned output");
+    if (n_vec >= (int64_t(1) << 31)) return fail(FFS_E_INVALID, "too many vectors");
+    std::vector<RasterVec> vecs((size_t)n_vec);
+    int64_t longest = 0;
+    for (int64_t v = 0; v < n_vec; ++v) {
+        if (vec_sub_first[v] < 0 || vec_sub_count[v] < 0 || vec_sub_first[v] + vec_sub_count[v] > n_subs_total)
+            return fail(FFS_E_INVALID, "vector %lld: subtitle range outside the arrays", (long long)v);
+        if (vec_len[v] < 0 || vec_len[v] >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
+        if (vec_out_word[v] < 0 || vec_out_word[v] + (vec_len[v] + 31) / 32 > out_words)
+            return fail(FFS_E_INVALID, "vector %lld: output range outside the buffer", (long long)v);
+        vecs[(size_t)v] = RasterVec{(long long)vec_sub_first[v], (long long)vec_out_word[v], vec_ratio[v], (int)vec_sub_count[v],
+                                    (int)vec_len[v]};
+        if (vec_sub_count[v] > longest) longest = vec_sub_count[v];
+    }
+    if (out_words == 0) return FFS_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
+    int rc_dev;
+    if ((rc_dev = guard.enter(out_dev))) return rc_dev;
+    HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_words * 4, st));
+    if (n_vec == 0 || longest == 0) return FFS_OK;
+    // one staging allocation: start | end | vector table | metadata flags
+    const size_t nsub = (size_t)n_subs_total, off_end = nsub * 8, off_vec = 2 * nsub * 8;
+    const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterVec), total = off_meta + (is_metadata ? nsub : 0);
+    char* d = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d, total, st));
+    int rc = FFS_OK;
+    auto put = [&](size_t off, const void* src, size_t bytes) {
+        if (rc == FFS_OK && bytes && hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
+            rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    };
+    put(0, start_us, nsub * 8);
+    put(off_end, end_us, nsub * 8);
+    put(off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterVec));
+    if (is_metadata) put(off_meta, is_metadata, nsub);
+    // the tables are the caller's (and this function's) pageable memory: they must have been read before we return
+    if (rc == FFS_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(FFS_E_HIP, "stream synchronisation failed");
+    if (rc == FFS_OK) {
+        const unsigned bx = (unsigned)((longest + 255) / 256);
+        hipLaunchKernelGGL(k_rasterize_batch, dim3(bx < 64 ? bx : 64, (unsigned)(n_vec < 65535 ? n_vec : 65535)), dim3(256), 0, st,
+                           (const long long*)d, (const long long*)(d + off_end),
+                           is_metadata ? (const unsigned char*)(d + off_meta) : nullptr, (const RasterVec*)(d + off_vec),
+                           (int)n_vec, sample_rate, start_seconds, out_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_rasterize_batch launch failed");
+    }
+    (void)hipFreeAsync(d, st);
+    return rc;
 }
 
 int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshold, uint32_t* dst_dev, void* hip_stream) {

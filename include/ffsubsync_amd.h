@@ -190,6 +190,10 @@ int ffs_speech_bounds(const float* frames_dev, int64_t n_frames, int64_t* bounds
  * The sample value min(1/ratio, 1) (speech_transformers.py:977) is passed to ffs_align_batch as the
  * vector's `hi` level; out_dev holds 0/1 bytes. */
 int64_t ffs_raster_length(const int64_t* end_us, int64_t n_subs, double ratio, double sample_rate);
+/* Host-only, many vectors at once: len_out[v] = ffs_raster_length of a track whose largest end time is
+ * track_end_us_max[v], scaled by ratio[v] (the scaling is monotone, so the largest end decides). */
+int ffs_raster_lengths(const int64_t* track_end_us_max, const double* ratio, int64_t n_vec, double sample_rate,
+                       int64_t* len_out);
 /* Host-only: the clamped [start, end) sample intervals ffs_rasterize_subtitles fills, written as
  * pairs into iv_out[2*n_subs]; returns how many intervals were produced. */
 int64_t ffs_raster_intervals(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
@@ -203,6 +207,20 @@ int ffs_rasterize_subtitles(const int64_t* start_us, const int64_t* end_us, cons
 int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
                                  int64_t n_subs, double ratio, double sample_rate, double start_seconds,
                                  uint32_t* out_dev, int64_t out_len, void* hip_stream);
+
+/* Batched form, interval arithmetic on the device: n_vec bit-packed rasters from one call -- a file's seven framerate
+ * ratios, or every vector of a batch of files, written straight into the buffer ffs_align_batch reads.  The subtitle
+ * tracks are concatenated in start_us / end_us / is_metadata (host arrays of n_subs_total entries; is_metadata may be
+ * NULL); vector v rasterises the subtitles [vec_sub_first[v], vec_sub_first[v] + vec_sub_count[v]) -- several vectors
+ * may name the same track -- with times scaled by vec_ratio[v], as vec_len[v] samples (ffs_raster_length) whose bit 0
+ * is bit 0 of word out_dev[vec_out_word[v]].  out_dev[0, out_words) is zeroed first.  Same results, bit for bit, as
+ * one ffs_rasterize_subtitles_bits call per vector (the arithmetic is IEEE fp64 on both sides).  The call returns
+ * after the tables have been read (one stream synchronisation); the rasterisation itself is enqueued on hip_stream. */
+int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
+                             int64_t n_subs_total, const int64_t* vec_sub_first, const int64_t* vec_sub_count,
+                             const double* vec_ratio, const int64_t* vec_out_word, const int64_t* vec_len, int64_t n_vec,
+                             double sample_rate, double start_seconds, uint32_t* out_dev, int64_t out_words,
+                             void* hip_stream);
 
 /* Two-level vector -> FFS_DTYPE_U1 on the device.  src_dtype FFS_DTYPE_U8: bit = (byte != 0);
  * FFS_DTYPE_F32: bit = (x > threshold), e.g. VAD labels against 0.5 or (lo+hi)/2.  Writes

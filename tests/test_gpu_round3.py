@@ -153,3 +153,84 @@ def test_bench_main_with_two_ranks_on_one_gpu_and_loud_failure_without_devices(t
         assert run.returncode == 2
         line = json.loads(run.stdout.strip().splitlines()[-1])
         assert line["value"] is None and "HIP device" in line["error"] and line["n_gpus"] == 2
+
+
+def _tracks(n_tracks, seed, odd=False):
+    from oracle import raster_oracle as ro
+
+    rng = np.random.RandomState(seed)
+    out = []
+    for t in range(n_tracks):
+        s, e, m = ro.synth_subtitles(seed * 100 + t, n=int(rng.randint(1, 60)), minutes=float(rng.uniform(0.5, 30.0)))
+        if odd:
+            s, e = s // 2 * 2 + 1, e // 2 * 2 + 1
+        out.append((s, e, m))
+    return out
+
+
+@pytest.mark.parametrize("start_seconds", [0.0, 17.0])
+def test_batched_rasteriser_equals_one_call_per_vector(torch, start_seconds):
+    """ffs_rasterize_batch_bits does the interval arithmetic (timedelta microsecond rounding, round-half-even, slice
+    clamping) on the device: every vector bit-identical to ffs_rasterize_subtitles_bits, whose host arithmetic the CPU
+    suite pins to the reference's rasters -- ratios on half microseconds, metadata lines, an empty track, overlapping
+    subtitles, vectors packed back to back (neighbours must not bleed into each other)."""
+    from ffsubsync_amd import _native
+
+    ratios = [0.5, 1.5, 2.5, 1.0, 1.001, 0.999, 25.0 / 23.976, 23.976 / 25.0, 0.93137, 1.0874]
+    for seed, odd in ((1, False), (2, True)):
+        tracks = _tracks(9, seed, odd) + [(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.uint8))]
+        counts = np.array([len(t[0]) for t in tracks])
+        firsts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        s = np.concatenate([t[0] for t in tracks])
+        e = np.concatenate([t[1] for t in tracks])
+        m = np.concatenate([t[2] for t in tracks])
+        vec_track = np.repeat(np.arange(len(tracks)), len(ratios))
+        vec_ratio = np.tile(ratios, len(tracks))
+        end_max = np.array([int(t[1].max()) if len(t[1]) else 0 for t in tracks])
+        lens = _native.raster_lengths(end_max[vec_track], vec_ratio, 100.0)
+        words = (lens + 31) // 32
+        word_off = np.concatenate([[0], np.cumsum(words)[:-1]])
+        out = torch.full((int(words.sum()) + 3,), -1, dtype=torch.int32, device="cuda")
+        for use_meta in (True, False):
+            _native.rasterize_batch_bits(s, e, m if use_meta else None, firsts[vec_track], counts[vec_track], vec_ratio,
+                                         word_off, lens, out, 100.0, start_seconds)
+            got = out.cpu().numpy()
+            assert not got[int(words.sum()):].any()  # the whole buffer is zeroed first
+            for v in range(len(vec_track)):
+                ts, te, tm = tracks[vec_track[v]]
+                want, n = _native.rasterize_subtitles(ts, te, tm if use_meta else None, float(vec_ratio[v]), 100.0,
+                                                      start_seconds, packed=True)
+                assert n == lens[v]
+                assert np.array_equal(got[word_off[v]: word_off[v] + words[v]], want.cpu().numpy()), (seed, v, use_meta)
+
+
+def test_batch_from_interval_lists_equals_packing_the_per_vector_rasters(torch):
+    """batch.pairs_from_intervals (one rasteriser call for the whole batch) builds the very DeviceBatch that
+    pack_pairs builds from rasterize_candidates, and the solve recovers ratio and shift."""
+    from ffsubsync_amd import batch
+    from ffsubsync_amd.constants import candidate_ratios
+    from ffsubsync_amd.subtitle_raster import rasterize_candidates
+    from workloads import synth
+
+    ratios = candidate_ratios()
+    recs, truth = [], []
+    for f in range(6):
+        rng = np.random.RandomState(400 + f)
+        s_us, e_us, meta = synth.make_subtitle_records(400 + f, duration_s=20 * 60)
+        idx, shift_us = int(rng.randint(7)), int(rng.randint(-30, 30)) * 1_000_000
+        r_s = np.maximum(np.rint(s_us * ratios[idx]).astype(np.int64) + shift_us, 0)
+        r_e = np.maximum(np.rint(e_us * ratios[idx]).astype(np.int64) + shift_us, 0)
+        recs.append(((r_s, r_e, meta), (s_us, e_us, meta)))
+        truth.append((idx, shift_us // 10_000))
+    db = batch.pairs_from_intervals(recs, ratios)
+    ref = batch.pack_pairs([(rasterize_candidates(*r, [1.0])[0], rasterize_candidates(*c, ratios)) for r, c in recs])
+    assert db.dtype == ref.dtype and np.array_equal(db.offs, ref.offs) and np.array_equal(db.lens, ref.lens)
+    assert np.array_equal(db.lo, ref.lo) and np.array_equal(db.hi, ref.hi)
+    assert torch.equal(db.data, ref.data)
+    al = batch.BatchAligner(db.required_fft_length(6000), 7, 6000, pairs_in_flight=4)
+    try:
+        _, pres = al.solve(db)
+    finally:
+        al.close()
+    for i, (idx, off) in enumerate(truth):
+        assert int(pres[i]["best_cand"]) == idx and abs(int(pres[i]["offset"]) - off) <= 2

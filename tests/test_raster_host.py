@@ -64,3 +64,23 @@ def test_empty_and_all_metadata():
     s, e, m = ro.synth_subtitles(5, n=10, minutes=1.0)
     n = _native.raster_length(e, 1.0, 100.0)
     assert _native.raster_intervals(s, e, np.ones_like(m), 1.0, 100.0, 0.0, n).shape == (0, 2)
+
+
+def test_raster_lengths_of_many_vectors_equal_the_per_track_scan():
+    """ffs_raster_lengths takes each track's largest end time only: the scaling (division, multiplication, microsecond
+    rounding) is monotone, so that is the track's largest scaled end -- checked against the scan over every subtitle,
+    with ratios that land on half microseconds."""
+    rng = np.random.RandomState(3)
+    ends, ratios, want = [], [], []
+    for trial in range(300):
+        s, e, m = ro.synth_subtitles(700 + trial, n=int(rng.randint(1, 30)), minutes=float(rng.uniform(0.2, 200.0)))
+        if trial % 7 == 0:
+            e = e // 2 * 2 + 1  # odd microsecond counts: x 0.5 / 1.5 / 2.5 hits the half-even branch
+        ratio = float(rng.choice([0.5, 1.5, 2.5, 1.0, 1.001, 0.999, 25.0 / 23.976, rng.uniform(0.9, 1.1)]))
+        ends.append(int(e.max()))
+        ratios.append(ratio)
+        want.append(_native.raster_length(e, ratio, 100.0))
+    got = _native.raster_lengths(np.array(ends), np.array(ratios), 100.0)
+    assert got.tolist() == want
+    assert _native.raster_lengths(np.zeros(2, np.int64), np.array([1.0, 1.1]), 100.0).tolist() == [2, 2]
+    assert _native.raster_lengths(np.zeros(0, np.int64), np.zeros(0), 100.0).size == 0
