@@ -172,6 +172,35 @@ typedef const __attribute__((address_space(1))) char* gcptr;
 typedef __attribute__((address_space(1))) char* gptr;
 FFS_DEV cf gload(gcptr p, unsigned off) { return *(const __attribute__((address_space(1))) cf*)(p + off); }
 FFS_DEV void gstore(gptr p, unsigned off, cf v) { *(__attribute__((address_space(1))) cf*)(p + off) = v; }
+// Streaming variants (`nt`): the intermediates are written once and read once, a whole launch (13 GB) later, so they
+// need not displace anything in L2 / the Infinity Cache.  FFS_NT is a compile-time mask (A/B builds: -DFFS_NT=0):
+// 1 = first-pass stores, 2 = mid-pass loads, 4 = mid-pass stores, 8 = last-pass loads.  All four on, measured against
+// none (profiles/nt_ab.sh, r03_ab_experiments.json::run3l): first pass 4.83 -> 4.78 us/pair (windowless 11.2 -> 10.5),
+// mid 7.63 -> 7.53, pruned last pass 1.21 -> 1.16; seven-ratio solves/s +1.4 % (+2 % on the windowless and
+// reference-length plans, +2.5-3 % single-ratio).
+#ifndef FFS_NT
+#define FFS_NT 15
+#endif
+template <int BIT>
+FFS_DEV cf gload_s(gcptr p, unsigned off) {
+    if constexpr ((FFS_NT & BIT) != 0)
+        return __builtin_nontemporal_load((const __attribute__((address_space(1))) cf*)(p + off));
+    else
+        return gload(p, off);
+}
+template <int BIT>
+FFS_DEV void gstore_s(gptr p, unsigned off, cf v) {
+    if constexpr ((FFS_NT & BIT) != 0)
+        __builtin_nontemporal_store(v, (__attribute__((address_space(1))) cf*)(p + off));
+    else
+        gstore(p, off, v);
+}
+// first-pass stores: generic byte pointer + 32-bit offset (-DFFS_NT=0 keeps the plain stores it was tuned with)
+#if FFS_NT & 1
+#define FFS_PA_STORE(base, off, val) gstore_s<1>((gptr)(base), (off), (val))
+#else
+#define FFS_PA_STORE(base, off, val) (*reinterpret_cast<cf*>((base) + (off)) = (val))
+#endif
 FFS_DEV void gstep(gcptr& p, size_t stride) {
     p += stride;
     asm volatile("" : "+s"(p));
@@ -565,8 +594,9 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             const cf m = lds[((L - k1) & (L - 1)) * C + c];
             const cf a = mk(0.5f * (v[q].x + m.x), 0.5f * (v[q].y - m.y));
             const cf b = mk(0.5f * (v[q].y + m.y), 0.5f * (m.x - v[q].x));
-            out[o0 + ((size_t)k1 << log2CL)] = cmul(a, h[q]);
-            out_l[o0 + ((size_t)k1 << log2CL)] = cmul(b, h[q]);
+            const unsigned ob8 = (unsigned)((o0 + ((size_t)k1 << log2CL)) * sizeof(cf));
+            FFS_PA_STORE(reinterpret_cast<char*>(out), ob8, cmul(a, h[q]));
+            FFS_PA_STORE(reinterpret_cast<char*>(out_l), ob8, cmul(b, h[q]));
         }
         return;
     }
@@ -596,11 +626,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
             for (int q = 0; q < 16; ++q) asm volatile("" ::"v"(v[q]));
         } else if (k1_end == L) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) *reinterpret_cast<cf*>(outb + (o0 + ostep * q)) = v[q];
+            for (int q = 0; q < 16; ++q) FFS_PA_STORE(outb, o0 + ostep * q, v[q]);
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-                if (ob + CS::OSTEP * q < k1_end) *reinterpret_cast<cf*>(outb + (o0 + ostep * q)) = v[q];
+                if (ob + CS::OSTEP * q < k1_end) FFS_PA_STORE(outb, o0 + ostep * q, v[q]);
         }
     } else if constexpr (C >= 2) {
         // Pair up neighbouring columns so every lane issues 8 x 16-byte stores instead of 16 x 8-byte:
@@ -679,7 +709,7 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
             asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                x[q] = gload(p, off);
+                x[q] = gload_s<2>(p, off);
                 gstep(p, stride);
             }
         } else {
@@ -752,7 +782,7 @@ __global__ __launch_bounds__(256, 3) void k_mid(cf* __restrict__ work, int N1, i
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const cf w = ONE_ROW ? stw.times(wbl, q) : ((q == 0) ? wbl : cmul(wbl, ts[k1 * 16 + q]));  // W_N^(k1*(u + LT*q))
-                gstore(p, off, cmul(v[q], w));
+                gstore_s<4>(p, off, cmul(v[q], w));
                 gstep(p, stride);
             }
         } else {
@@ -833,7 +863,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
             asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                x[q] = gload(src, off);
+                x[q] = gload_s<2>(src, off);
                 gstep(src, stride);
             }
             __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
@@ -887,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void k_mid_seg_pipe(cf* __restrict__ work, 
             asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                gstore(dst, off, cmul(acc[q], stw.times(wb, q)));  // W_N^(k1*(u + LT*q))
+                gstore_s<4>(dst, off, cmul(acc[q], stw.times(wb, q)));  // W_N^(k1*(u + LT*q))
                 gstep(dst, stride);
             }
         };
@@ -961,7 +991,7 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __rest
         asm volatile("" : "+s"(stride), "+v"(off));
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            dst[q] = gload(p, off);
+            dst[q] = gload_s<2>(p, off);
             gstep(p, stride);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads go out HERE, ahead of the transform that follows
@@ -1021,7 +1051,7 @@ __global__ __launch_bounds__(256, NA == 1 ? 3 : 2) void k_mid_seg_one(cf* __rest
         asm volatile("" : "+s"(stride), "+v"(off), "+v"(wbl));  // opaque: the sixteen products wb*ts[q] are not hoisted
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            gstore(dst, off, cmul(acc[a][q], stw.times(wbl, q)));  // W_N^(k1*(u + LT*q))
+            gstore_s<4>(dst, off, cmul(acc[a][q], stw.times(wbl, q)));  // W_N^(k1*(u + LT*q))
             gstep(dst, stride);
         }
     }
@@ -1411,7 +1441,7 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_C3P_WAVES : FFS_C3_W
                 for (int j = 0; j < CH; ++j) {
                     const int row = NS * (u + LTI * (q0 + j)) + g;
                     const unsigned ro = (unsigned)(row <= L / 2 ? row : L - row) * row_bytes;
-                    a[j] = gload(pin, oa + ro);
+                    a[j] = gload(pin, oa + ro);  // (plain loads: streaming ones measured 1.9 -> 2.0 us/pair here)
                     b[j] = gload(pin, ob + ro);
                 }
 #pragma unroll
@@ -1434,7 +1464,7 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_C3P_WAVES : FFS_C3_W
             gcptr p = (gcptr)in;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                v[g][q] = gload(p, off + g * row_bytes);
+                v[g][q] = gload_s<8>(p, off + g * row_bytes);
                 gstep(p, stride);
             }
         }
@@ -1580,8 +1610,8 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
             const cf w = tw_of(r, q);
             const cf a = mk(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));   // (z + conj(m)) / 2
             const cf b = mk(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));  // (z - conj(m)) / (2i)
-            *reinterpret_cast<cf*>(out_r + row_off(r, q)) = cmul(a, w);
-            *reinterpret_cast<cf*>(out_s + row_off(r, q)) = cmul(b, w);
+            FFS_PA_STORE(out_r, row_off(r, q), cmul(a, w));
+            FFS_PA_STORE(out_s, row_off(r, q), cmul(b, w));
         };
         if (u == 0) emit(0, 0, v[0][0], v[0][0]);  // row 0 mirrors onto itself
 #pragma unroll
@@ -1616,7 +1646,7 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int k1 = u + LTI * q + LI * r;
-                if (k1 < k1_end) *reinterpret_cast<cf*>(outb + row_off(r, q)) = cmul(v[r][q], tw_of(r, q));
+                if (k1 < k1_end) FFS_PA_STORE(outb, row_off(r, q), cmul(v[r][q], tw_of(r, q)));
             }
         }
     }
@@ -1680,6 +1710,11 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
     if (EXH) {
         if (!exhaustive_wanted(noms, cands, first_cand + lp * n_cand, kp, n_cand, only_half, xci, xwant, xthr)) continue;
     }
+#if FFS_NT & 8
+#define FFS_PC_LOAD(base, ...) gload_s<8>((gcptr)(base), (unsigned)((__VA_ARGS__) * sizeof(cf)))
+#else
+#define FFS_PC_LOAD(base, ...) ((base)[(__VA_ARGS__)])
+#endif
     const cf* in = work + (size_t)(lp * slot_stride(n_slots) + cand_slot(n_slots, kp, n_packed)) * N;
     cf v[16];
     if (half_last && kp == n_packed - 1) {
@@ -1692,13 +1727,14 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_c_pruned(const cf* __rest
             const float wgt = (row == 0 || row == L / 2) ? 1.0f : 2.0f;
             v[q] = mk(0.f, 0.f);
             if (row <= L / 2) {
-                const cf y = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)row << log2CL)];
+                const cf y = FFS_PC_LOAD(in, tile_base<L, C>(tile, c, log2CL) + ((size_t)row << log2CL));
                 v[q] = mk(wgt * y.x, wgt * y.y);
             }
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) v[q] = in[tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL)];
+        for (int q = 0; q < 16; ++q)
+            v[q] = FFS_PC_LOAD(in, tile_base<L, C>(tile, c, log2CL) + ((size_t)(u + LT * q) << log2CL));
     }
     for (int i = tid; i < L; i += NT) s_tw[i] = twn1[i];
     __syncthreads();

@@ -1,0 +1,20 @@
+#!/bin/bash
+# A/B of streaming (`nt`) stores / loads on the intermediates: libffsalign_nt<mask>.so are builds with -DFFS_NT=<mask>
+# (1 = first-pass stores, 2 = mid-pass loads, 4 = mid-pass stores, 8 = last-pass loads); full bench line, every leg.
+#   for m in 15; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DFFS_NT=$m -shared \
+#       -o ffsubsync_amd/libffsalign_nt$m.so ffsubsync_amd/csrc/ffsalign.hip; done;  bash profiles/nt_ab.sh 0 15 0 15
+cd "$GRAFT_REPO_ROOT"
+for m in "$@"; do
+  lib=ffsubsync_amd/libffsalign_nt$m.so; [ $m = 0 ] && lib=ffsubsync_amd/libffsalign.so
+  [ -f $lib ] || continue
+  echo "FFS_NT=$m"
+  FFS_LIBRARY_PATH=$PWD/$lib timeout 300 python bench.py --steps 6 --warmup 2 --cpu-pairs 0 --no-vad --e2e-files 0 2>/dev/null | python -c "
+import sys,json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+us=lambda k:{n:round(v['us_per_pair'],2) for n,v in k.items()}
+print(' headline', round(d['value']), us(d['kernels']), d['offset_match']['pairs_matching_reference_golden'])
+print(' reflen', round(d['reference_length']['value']), us(d['reference_length']['kernels']), d['reference_length']['identical_pair_results'])
+print(' windowless', round(d['windowless']['value']), us(d['windowless']['kernels']))
+for k,v in d['single_ratio'].items(): print(' single', k, round(v['solves_per_s']), us(v['kernels']), v['pairs_matching_reference_golden'])
+print(' bytes', round(d['byte_inputs']['value']), d['byte_inputs']['identical_pair_results'])"
+done
