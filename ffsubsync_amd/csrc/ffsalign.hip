@@ -836,6 +836,12 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->log2C = ilog2(p->C);
     p->log2CL = p->log2C < 6 ? 6 : p->log2C;
     if ((1 << p->log2CL) > p->N2) p->log2CL = ilog2(p->N2);
+#ifdef FFS_LAB
+    if (const char* ecl = getenv("FFS_LOG2CL")) {  // wider row chunks (timing experiments of the lab build)
+        const int v = atoi(ecl);
+        if (v >= p->log2C && (1 << v) <= p->N2 / 16) p->log2CL = v;
+    }
+#endif
     const int64_t N = n_fft;
     const int N1 = p->N1, N2 = p->N2, LT1 = N1 / 16, LT2 = N2 / 16;
     int rc;
