@@ -1,13 +1,14 @@
 #!/bin/bash
 # A/B of streaming (`nt`) stores / loads on the intermediates: libffsalign_nt<mask>.so are builds with -DFFS_NT=<mask>
-# (1 = first-pass stores, 2 = mid-pass loads, 4 = mid-pass stores, 8 = last-pass loads); full bench line, every leg.
-#   for m in 15; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -DFFS_NT=$m -shared \
-#       -o ffsubsync_amd/libffsalign_nt$m.so ffsubsync_amd/csrc/ffsalign.hip; done;  bash profiles/nt_ab.sh 0 15 0 15
+# (1 = first-pass stores, 2 = mid-pass loads, 4 = mid-pass stores, 8 = last-pass loads; the product library is built
+# with 15); full bench line, every leg.  `default` = libffsalign.so.
+#   make -C ffsubsync_amd/csrc variant NAME=nt0 DEFS=-DFFS_NT=0;  bash profiles/nt_ab.sh nt0 default nt0 default
+# (run3l was taken when the product default was still 0: `0 15 0 15` with a -DFFS_NT=15 variant)
 cd "$GRAFT_REPO_ROOT"
 for m in "$@"; do
-  lib=ffsubsync_amd/libffsalign_nt$m.so; [ $m = 0 ] && lib=ffsubsync_amd/libffsalign.so
+  lib=ffsubsync_amd/libffsalign_$m.so; [ $m = default ] && lib=ffsubsync_amd/libffsalign.so
   [ -f $lib ] || continue
-  echo "FFS_NT=$m"
+  echo "build=$m"
   FFS_LIBRARY_PATH=$PWD/$lib timeout 300 python bench.py --steps 6 --warmup 2 --cpu-pairs 0 --no-vad --e2e-files 0 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
