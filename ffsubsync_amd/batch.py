@@ -112,7 +112,11 @@ def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 10
     firsts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64) if len(tracks) else np.zeros(0, np.int64)
     cat = lambda k, dt: (np.concatenate([np.asarray(t[k], dtype=dt) for t in tracks]) if len(tracks) else np.zeros(0, dt))
     start_us, end_us = cat(0, np.int64), cat(1, np.int64)
-    meta = None if any(t[2] is None for t in tracks) else cat(2, np.uint8)
+    if all(t[2] is None for t in tracks):
+        meta = None
+    else:  # a track without flags has no metadata lines
+        meta = np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else np.asarray(t[2], dtype=np.uint8)
+                               for t in tracks])
     end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64).reshape(n_pairs, 2)
     track_of = np.tile(np.array([0] + [1] * len(ratios)), (n_pairs, 1)) + 2 * np.arange(n_pairs)[:, None]
     ratio = np.tile(np.array([1.0] + ratios), (n_pairs, 1))

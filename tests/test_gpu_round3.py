@@ -217,10 +217,11 @@ def test_batch_from_interval_lists_equals_packing_the_per_vector_rasters(torch):
     for f in range(6):
         rng = np.random.RandomState(400 + f)
         s_us, e_us, meta = synth.make_subtitle_records(400 + f, duration_s=20 * 60)
+        meta[::17] = 1  # some metadata lines (skipped by the rasteriser, still counted for the length)
         idx, shift_us = int(rng.randint(7)), int(rng.randint(-30, 30)) * 1_000_000
         r_s = np.maximum(np.rint(s_us * ratios[idx]).astype(np.int64) + shift_us, 0)
         r_e = np.maximum(np.rint(e_us * ratios[idx]).astype(np.int64) + shift_us, 0)
-        recs.append(((r_s, r_e, meta), (s_us, e_us, meta)))
+        recs.append(((r_s, r_e, None if f % 2 else meta), (s_us, e_us, meta)))  # tracks with and without flags mix
         truth.append((idx, shift_us // 10_000))
     db = batch.pairs_from_intervals(recs, ratios)
     ref = batch.pack_pairs([(rasterize_candidates(*r, [1.0])[0], rasterize_candidates(*c, ratios)) for r, c in recs])
