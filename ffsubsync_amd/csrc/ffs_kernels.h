@@ -305,8 +305,8 @@ FFS_DEV size_t tile_base(int tile, int c, int log2CL) {
 // eight workgroups of a grid row (gridDim.x = nt + 8 = 0 mod 8, so workgroup x runs on XCD x % 8, which also runs
 // the tiles (x % 8) * nt/8 ...) each touch the lines under their XCD's `ncols` columns, all L rows of both vectors;
 // the consumers find them in their L2 a few microseconds later (6.1 -> 5.0 us/pair at twelve rows ahead).
-FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int xcd, int L, int N2, int ncols, int nthreads) {
-    if (y >= (int)gridDim.y) return;
+FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int n_desc, int xcd, int L, int N2, int ncols, int nthreads) {
+    if (y >= n_desc) return;
     const XformDesc dn = descs[y];
     const int colA = xcd * ncols;
     unsigned acc = 0;
@@ -328,11 +328,13 @@ FFS_DEV void prefetch_bit_inputs(const XformDesc* __restrict__ descs, int y, int
 // --------------------------------------------------------------------------------------------
 // pass A.  grid = (N2/C column tiles [+ input prefetch blocks: N2/128 for byte inputs, 8 (one per XCD) for bit-packed
 // ones], n_transforms); block = (L/16)*C threads; thread (c = tid % C, u = tid / C).
-// PAIRED (bit-packed inputs, power-of-two columns; grid.y = transform GROUPS): a group's reference and its single last
-// candidate are both real vectors with half slots, so ONE column transform of z = ref + i*last serves both -- per column
+// Paired transforms (bit-packed inputs, power-of-two columns): a group's reference and its single last candidate are
+// both real vectors with half slots, so ONE column transform of z = ref + i*last serves both -- per column
 // ref^[k1] = (Z[k1] + conj Z[L-k1])/2 and last^[k1] = (Z[k1] - conj Z[L-k1])/(2i), the mirror rows fetched through the
-// column tile in LDS -- and the plain launch (flag PAIR_REF_LAST) leaves those two transforms out.
-template <int L, int C, int DT, bool PAIRED = false>
+// column tile in LDS.  PM = 0: one grid row per transform, no pairing.  PM = 1: grid rows = transform GROUPS, every
+// block a paired one (groups of two transforms).  PM = 2: xf_per_pair - 1 grid rows per group -- row 0 the paired
+// transform, row j the plain transform j -- in one launch.
+template <int L, int C, int DT, int PM = 0>
 __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __restrict__ descs, cf* __restrict__ work,
                                                          int N2, long long N, const cf* __restrict__ tw,
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
@@ -366,14 +368,27 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         if (acc == 0xdeadbeefu && pf_sink) *pf_sink = acc;  // keeps the loads alive (pf_sink is scratch)
         return;
     }
+    // grid row -> (transform group, transform within the group, paired or not)
+    constexpr bool CAN_PAIR = PM != 0;
+    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : xf_per_pair);
+    auto desc_of = [&](int y, bool* is_paired) {
+        const int g = y / rows_per_group, j = y % rows_per_group;
+        *is_paired = CAN_PAIR && j == 0;
+        return g * xf_per_pair + j;
+    };
     if (DT == 2 && blockIdx.x >= (unsigned)nt) {
-        prefetch_bit_inputs(descs, (int)blockIdx.y + pf_ahead, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, LT * C);
+        const int y = (int)blockIdx.y + pf_ahead;
+        if (y >= (int)gridDim.y) return;
+        bool pp;
+        const int di = desc_of(y, &pp);
+        const int n_desc = ((int)gridDim.y / rows_per_group) * xf_per_pair;
+        prefetch_bit_inputs(descs, di, n_desc, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, LT * C);
+        if (pp) prefetch_bit_inputs(descs, di + xf_per_pair - 1, n_desc, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, LT * C);
         return;
     }
-    if constexpr (!PAIRED) {
-        const int xi0 = blockIdx.y % xf_per_pair;
-        if ((half_flags & PAIR_REF_LAST) && (xi0 == 0 || xi0 == xf_per_pair - 1)) return;
-    }
+    bool paired;
+    const int desc_index = desc_of((int)blockIdx.y, &paired);
+    const int group = (int)blockIdx.y / rows_per_group;
     const int c = threadIdx.x % C;
     const int u = threadIdx.x / C;
     // XCD-aware tile mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2), and the input
@@ -381,11 +396,13 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     // tiles instead of every eighth one -- otherwise each input line is fetched by up to 8 L2s.
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
     const int n2 = tile * C + c;
-    XformDesc d = descs[PAIRED ? blockIdx.y * xf_per_pair : (FFS_LABF(half_flags, DBG_PA_HOT_INPUT) ? 0 : blockIdx.y)];
-    if constexpr (PAIRED) {
+    XformDesc d = descs[FFS_LABF(half_flags, DBG_PA_HOT_INPUT) ? 0 : desc_index];
+    if constexpr (CAN_PAIR) {
         static_assert(DT == 2 && !CS::R3, "paired first pass: bit-packed inputs, power-of-two columns");
-        const XformDesc dl = descs[blockIdx.y * xf_per_pair + xf_per_pair - 1];
-        d.b = dl.a, d.len_b = dl.len_a, d.b0 = dl.a0, d.b1 = dl.a1, d.lead_b = dl.lead_a, d.off_b = dl.off_a;
+        if (paired) {  // block-uniform
+            const XformDesc dl = descs[desc_index + xf_per_pair - 1];
+            d.b = dl.a, d.len_b = dl.len_a, d.b0 = dl.a0, d.b1 = dl.a1, d.lead_b = dl.lead_a, d.off_b = dl.off_a;
+        }
     }
     // every table value this thread needs is requested up front, together with the inputs
     // (tiles of 64+ columns: u is the wave's row phase, the stage twiddles are wave-uniform -> scalar registers)
@@ -511,15 +528,14 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     }
     // transform blockIdx.y of the launch is transform (y % xf_per_pair) of pair (y / xf_per_pair); a pair
     // owns slots_per_pair consecutive length-N buffers
-    cf* out = PAIRED ? work + (size_t)blockIdx.y * slots_per_pair * N
-                     : work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
+    const int xi = desc_index - group * xf_per_pair;
+    cf* out = work + ((size_t)group * slots_per_pair + xi) * N;
     if FFS_LABF(half_flags, DBG_PA_HOT_STORE) out = work;
     // HALF_REF: the reference transform (slot 0) is of a real signal, so its rows k1 > L/2 mirror the
     // rows L - k1 (X[N-k] = conj X[k]); k_mid rebuilds them and they are not stored at all.
     // HALF_LAST: with an odd candidate count the last packed transform carries ONE real candidate; its
     // product with the reference spectrum stays Hermitian, so neither its rows k1 > L/2 nor their
     // results are ever needed (the last pass rebuilds them by conjugation, see k_pass_c*).
-    const int xi = blockIdx.y % xf_per_pair;
     const int k1_end = (((half_flags & HALF_REF) && xi == 0) || ((half_flags & HALF_LAST) && xi == xf_per_pair - 1))
                            ? L / 2 + 1 : L;
     if constexpr (CS::R3) {
@@ -576,7 +592,7 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
     wq[9] = cmul(wq[3], wq[4]);   // h_5
     wq[10] = cmul(wq[5], wq[4]);  // h_6
     wq[11] = cmul(wq[6], wq[4]);  // h_7
-    if constexpr (PAIRED) {
+    if (CAN_PAIR && paired) {
         // v[q] = Z[k1 = u + LT*q] of z = ref + i*last (no twiddle yet: the mirror row has its own).  The raw column goes
         // through the tile in LDS, every thread picks up Z[L - k1] for its rows k1 <= L/2 and writes the two separated
         // spectra, times W_N^(n2*k1), to the reference slot and the last slot (half slots: rows 0..L/2).
@@ -1517,7 +1533,7 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
     constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
     static_assert(NT == 256, "256 threads per block");
     if (blockIdx.x >= (unsigned)nt) {  // input prefetch block (see prefetch_bit_inputs); distance in bits 16..23 of half_flags
-        prefetch_bit_inputs(descs, (int)blockIdx.y + ((half_flags >> 16) & 255), (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
+        prefetch_bit_inputs(descs, (int)blockIdx.y + ((half_flags >> 16) & 255), (int)gridDim.y, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
         return;
     }
     if (!PAIRED && (half_flags & PAIR_REF_LAST)) {  // slot 0 and the last slot are produced by the PAIRED launch

@@ -302,28 +302,34 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     const int pf = (DT == 0 && ahead > 0 && nt % 8 == 0 && groups % 8 == 0) ? groups
                    : (DT == 2 && ahead > 0 && nt % 8 == 0) ? 8 : 0;
     // bit-packed inputs, reference slot and last candidate slot both half slots (one real vector each): one paired
-    // column transform per group instead of two.  Pays where the transforms, not the stores, set the pace: one
-    // candidate 1.72 -> 1.41 us/pair (two transforms -> one); seven candidates (five -> four, the same four slots' worth
-    // of stores at 5.2 TB/s) 4.90 -> 5.01, so only groups of up to three transforms take it.
+    // column transform per group instead of two, in the same launch as the group's other transforms
     constexpr bool CAN_PAIR = DT == 2 && L % 3 != 0;
     const bool paired = CAN_PAIR && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
-                        xf_per_pair <= 3 && xf_per_pair == slots_per_pair;
-    const int flags = ref_half | STORE_8B | (p->lab_flags & (31 << 10)) | (paired ? PAIR_REF_LAST : 0);
-    if (!paired || xf_per_pair > 2) {
-        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
-        hipLaunchKernelGGL((k_pass_a<L, C, DT>), dim3(nt + pf, n_xf), dim3((L / 16) * C), lds, st, descs, p->work, p->N2,
-                           (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ahead,
-                           (unsigned*)p->bnom, flags);
-    }
+                        xf_per_pair == slots_per_pair;
+    const int flags = ref_half | STORE_8B | (p->lab_flags & (31 << 10));
     if constexpr (CAN_PAIR) {
         if (paired) {
             const size_t lds_p = lds > (size_t)L * C * sizeof(cf) ? lds : (size_t)L * C * sizeof(cf);  // the whole column tile
-            if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT, true>, lds_p))) return rc_lds;
-            hipLaunchKernelGGL((k_pass_a<L, C, DT, true>), dim3(nt, n_xf / xf_per_pair), dim3((L / 16) * C), lds_p, st, descs,
-                               p->work, p->N2, (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair,
-                               slots_per_pair, nt, 0, (unsigned*)p->bnom, ref_half);
+            const int groups_y = n_xf / xf_per_pair;
+            if (xf_per_pair == 2) {
+                if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT, 1>, lds_p))) return rc_lds;
+                hipLaunchKernelGGL((k_pass_a<L, C, DT, 1>), dim3(nt + pf, groups_y), dim3((L / 16) * C), lds_p, st, descs, p->work,
+                                   p->N2, (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair,
+                                   slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags);
+            } else {
+                if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT, 2>, lds_p))) return rc_lds;
+                hipLaunchKernelGGL((k_pass_a<L, C, DT, 2>), dim3(nt + pf, groups_y * (xf_per_pair - 1)), dim3((L / 16) * C), lds_p,
+                                   st, descs, p->work, p->N2, (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL,
+                                   xf_per_pair, slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags);
+            }
+            HIP_TRY(hipGetLastError());
+            return FFS_OK;
         }
     }
+    if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
+    hipLaunchKernelGGL((k_pass_a<L, C, DT>), dim3(nt + pf, n_xf), dim3((L / 16) * C), lds, st, descs, p->work, p->N2,
+                       (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ahead,
+                       (unsigned*)p->bnom, flags);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
