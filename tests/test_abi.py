@@ -5,6 +5,7 @@ import math
 import os
 import re
 
+import numpy as np
 import pytest
 
 from ffsubsync_amd import _native
@@ -72,6 +73,32 @@ def test_bad_arguments_are_reported_not_thrown():
     assert rc == -1 and b"power of two" in lib.ffs_last_error()
     with pytest.raises(_native.NativeError):
         _native.check(rc)
+
+
+def test_batched_rasteriser_validates_its_tables_before_touching_the_gpu():
+    lib = _native.load()
+    i64 = lambda *v: np.array(v, dtype=np.int64)
+    s, e = i64(0, 1_000_000), i64(500_000, 2_000_000)
+    first, count, word, length = i64(0), i64(2), i64(0), i64(202)
+    ratio = np.array([1.0])
+    out = ctypes.c_void_p(0x1000)  # never dereferenced: every case below fails validation first
+
+    def call(n_subs=2, first=first, count=count, word=word, length=length, n_vec=1, out_words=7, out=out, vec_first=None):
+        return lib.ffs_rasterize_batch_bits(s.ctypes.data, e.ctypes.data, None, n_subs,
+                                            first.ctypes.data if vec_first is None else vec_first, count.ctypes.data,
+                                            ratio.ctypes.data, word.ctypes.data, length.ctypes.data, n_vec, 100.0, 0.0, out,
+                                            out_words, None)
+
+    assert call(n_vec=-1) == -1
+    assert call(vec_first=0) == -1 and b"null vector table" in lib.ffs_last_error()
+    assert call(count=i64(3)) == -1 and b"subtitle range" in lib.ffs_last_error()
+    assert call(first=i64(-1)) == -1
+    assert call(word=i64(1)) == -1 and b"output range" in lib.ffs_last_error()  # 7 words needed from word 1 of 7
+    assert call(length=i64(1 << 31)) != 0
+    assert call(out=ctypes.c_void_p(0x1002)) == -1 and b"misaligned" in lib.ffs_last_error()
+    assert call(n_vec=0, out_words=0) == 0  # nothing to do is not an error
+    assert lib.ffs_raster_lengths(None, None, 1, 100.0, None) == -1
+    assert lib.ffs_raster_lengths(None, None, 0, 100.0, None) == 0
 
 
 def test_result_struct_layouts():
