@@ -304,8 +304,11 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     // bit-packed inputs, reference slot and last candidate slot both half slots (one real vector each): one paired
     // column transform per group instead of two, in the same launch as the group's other transforms
     constexpr bool CAN_PAIR = DT == 2 && L % 3 != 0;
+#ifndef FFS_PAIR_MAX_XF
+#define FFS_PAIR_MAX_XF 64  // A/B builds: largest transform group that takes the paired transform
+#endif
     const bool paired = CAN_PAIR && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
-                        xf_per_pair == slots_per_pair;
+                        xf_per_pair <= FFS_PAIR_MAX_XF && xf_per_pair == slots_per_pair;
     const int flags = ref_half | STORE_8B | (p->lab_flags & (31 << 10));
     if constexpr (CAN_PAIR) {
         if (paired) {
