@@ -32,7 +32,6 @@ constexpr int RSEG = 16;  // blocks sharing each exact re-evaluation
 constexpr int HALF_REF = 1;   // reference slot holds rows 0..N1/2 only
 constexpr int HALF_LAST = 2;  // so does the last candidate slot (single real candidate)
 constexpr int PAIR_ROWS = 8;  // block-segmented mid pass: mirror-row pairs on one XCD
-constexpr int PAIR_REF_LAST = 16;  // k_pass_a3: slot 0 and the last slot come from the PAIRED launch (two real vectors, one transform)
 // Section experiments (timing only, WRONG RESULTS): compiled in by `make lab` (-DFFS_LAB -> libffsalign_lab.so) and
 // selected there through FFS_MID_DEBUG / FFS_PASS_A_DEBUG; the product library contains none of it -- FFS_LABF() is a
 // constant false and the branches fold away.
@@ -1516,14 +1515,15 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_C3P_WAVES : FFS_C3_W
 // pass A for columns of length L = NS*LI, bit-packed inputs, all sub-transforms of a column in one thread (colnr_fft).
 // grid = (N2/C, n_transforms); block = (LI/16)*C = 256 threads; same outputs as k_pass_a<L, ., 2>.
 // tbR[u][n2] = W_N^(n2*u) (u < LTI), tsR[i][n2] = W_N^(n2*LTI*2^i) (i < 4), thR[r-1][n2] = W_N^(n2*LI*r) (0 < r < NS).
-// PAIRED (round 3; launched on its own over grid = (N2/C, n_pairs) when the reference slot AND the last candidate slot
-// are half slots): both hold ONE real vector, so their columns share one complex column transform -- z = ref + i*cand,
+// Paired transforms (round 3; when the reference slot AND the last candidate slot are half slots; PM as in k_pass_a:
+// 0 = none, 1 = every grid row a paired group of two transforms, 2 = xf_per_pair - 1 grid rows per group, row 0 the
+// paired one): both hold ONE real vector, so their columns share one complex column transform -- z = ref + i*cand,
 // Z = R + i*S with R, S Hermitian, hence  R[k] = (Z[k] + conj(Z[L-k]))/2,  S[k] = (Z[k] - conj(Z[L-k]))/(2i)  for the
 // stored rows k <= L/2.  The mirror rows Z[L-k] sit in other threads of the same column: they go through the LDS tile
 // once (rows >= L/2 only, one LI-row block at a time).  One column transform + one exchange instead of two column
-// transforms; the plain instantiation then skips slot 0 and the last slot (PAIR_REF_LAST).
-template <int NS, int LI, int C, bool PAIRED>
-__global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_WAVES) void k_pass_a3(const XformDesc* __restrict__ descs, cf* __restrict__ work, int N2,
+// transforms.
+template <int NS, int LI, int C, int PM>
+__global__ __launch_bounds__(256, (PM != 0 && NS == 3) ? FFS_A3P_WAVES : FFS_C3_WAVES) void k_pass_a3(const XformDesc* __restrict__ descs, cf* __restrict__ work, int N2,
                                                  long long N, const cf* __restrict__ tw, const cf* __restrict__ tbR,
                                                  const cf* __restrict__ tsR, const cf* __restrict__ thR,
                                                  const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
@@ -1532,20 +1532,32 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
     static_assert(NT == 256, "256 threads per block");
+    // grid row -> (transform group, transform within the group, paired or not)
+    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : xf_per_pair);
+    auto desc_of = [&](int y, bool* is_paired) {
+        const int g = y / rows_per_group, j = y % rows_per_group;
+        *is_paired = PM != 0 && j == 0;
+        return g * xf_per_pair + j;
+    };
     if (blockIdx.x >= (unsigned)nt) {  // input prefetch block (see prefetch_bit_inputs); distance in bits 16..23 of half_flags
-        prefetch_bit_inputs(descs, (int)blockIdx.y + ((half_flags >> 16) & 255), (int)gridDim.y, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
+        const int y = (int)blockIdx.y + ((half_flags >> 16) & 255);
+        if (y >= (int)gridDim.y) return;
+        bool pp;
+        const int di = desc_of(y, &pp);
+        const int n_desc = ((int)gridDim.y / rows_per_group) * xf_per_pair;
+        prefetch_bit_inputs(descs, di, n_desc, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
+        if (pp) prefetch_bit_inputs(descs, di + xf_per_pair - 1, n_desc, (int)blockIdx.x - nt, L, N2, (nt / 8) * C, NT);
         return;
     }
-    if (!PAIRED && (half_flags & PAIR_REF_LAST)) {  // slot 0 and the last slot are produced by the PAIRED launch
-        const int xi0 = blockIdx.y % xf_per_pair;
-        if (xi0 == 0 || xi0 == xf_per_pair - 1) return;
-    }
+    bool paired;
+    const int desc_index = desc_of((int)blockIdx.y, &paired);
+    const int group = (int)blockIdx.y / rows_per_group;
     const int c = threadIdx.x % C, u = threadIdx.x / C;
     const int tile = (nt % 8 == 0) ? (int)(blockIdx.x % 8) * (nt / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;  // see k_pass_a
     const int n2 = tile * C + c;
-    XformDesc d = descs[PAIRED ? blockIdx.y * xf_per_pair : blockIdx.y];
-    if constexpr (PAIRED) {  // the imaginary half = the single candidate of the pair's last transform
-        const XformDesc dl = descs[blockIdx.y * xf_per_pair + xf_per_pair - 1];
+    XformDesc d = descs[desc_index];
+    if (PM != 0 && paired) {  // block-uniform: the imaginary half = the single candidate of the group's last transform
+        const XformDesc dl = descs[desc_index + xf_per_pair - 1];
         d.b = dl.a, d.off_b = dl.off_a, d.len_b = dl.len_a, d.lead_b = dl.lead_a, d.b0 = dl.a0, d.b1 = dl.a1;
     }
     TwRegs<LI> twr;
@@ -1628,9 +1640,9 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
     const unsigned ostep = ((unsigned)LTI << log2CL) * (unsigned)sizeof(cf);
     auto row_off = [&](int r, int q) { return o0 + ostep * q + (((unsigned)(LI * r)) << log2CL) * (unsigned)sizeof(cf); };
     auto tw_of = [&](int r, int q) { return r == 0 ? wq[q] : cmul(wq[q], r == 1 ? h1 : h2); };
-    if constexpr (PAIRED) {
-        char* out_r = reinterpret_cast<char*>(work + ((size_t)blockIdx.y * slots_per_pair) * N);
-        char* out_s = reinterpret_cast<char*>(work + ((size_t)blockIdx.y * slots_per_pair + slots_per_pair - 1) * N);
+    if (PM != 0 && paired) {
+        char* out_r = reinterpret_cast<char*>(work + ((size_t)group * slots_per_pair) * N);
+        char* out_s = reinterpret_cast<char*>(work + ((size_t)group * slots_per_pair + slots_per_pair - 1) * N);
         // row k1 <= L/2 from Z[k1] = z and its mirror Z[L-k1] = m
         auto emit = [&](int r, int q, cf z, cf m) {
             const cf w = tw_of(r, q);
@@ -1661,8 +1673,8 @@ __global__ __launch_bounds__(256, (PAIRED && NS == 3) ? FFS_A3P_WAVES : FFS_C3_W
                 }
         }
     } else {
-        cf* out = work + ((size_t)(blockIdx.y / xf_per_pair) * slots_per_pair + (blockIdx.y % xf_per_pair)) * N;
-        const int xi = blockIdx.y % xf_per_pair;
+        const int xi = desc_index - group * xf_per_pair;
+        cf* out = work + ((size_t)group * slots_per_pair + xi) * N;
         const int k1_end = (((half_flags & HALF_REF) && xi == 0) || ((half_flags & HALF_LAST) && xi == xf_per_pair - 1))
                                ? L / 2 + 1 : L;
         char* outb = reinterpret_cast<char*>(out);

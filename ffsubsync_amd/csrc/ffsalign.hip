@@ -289,6 +289,9 @@ int bit_prefetch_rows(const ffs_plan* p) {
     return (int)(rows < 4 ? 4 : (rows > 255 ? 255 : rows));
 }
 
+#ifndef FFS_PAIR_MAX_XF
+#define FFS_PAIR_MAX_XF 64  // A/B builds: largest transform group that takes the paired transform
+#endif
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
                        int ref_half, hipStream_t st) {
@@ -304,9 +307,6 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     // bit-packed inputs, reference slot and last candidate slot both half slots (one real vector each): one paired
     // column transform per group instead of two, in the same launch as the group's other transforms
     constexpr bool CAN_PAIR = DT == 2 && L % 3 != 0;
-#ifndef FFS_PAIR_MAX_XF
-#define FFS_PAIR_MAX_XF 64  // A/B builds: largest transform group that takes the paired transform
-#endif
     const bool paired = CAN_PAIR && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
                         xf_per_pair <= FFS_PAIR_MAX_XF && xf_per_pair == slots_per_pair;
     const int flags = ref_half | STORE_8B | (p->lab_flags & (31 << 10));
@@ -350,20 +350,25 @@ int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int
     const int ahead = nt % 8 == 0 ? bit_prefetch_rows(p) : 0;  // eight prefetch blocks per grid row, one per XCD
     const cf* tw = NS == 2 ? p->tw1h : p->tw1;
     // reference slot and last candidate slot both half slots (one real vector each): one paired column transform
-    const bool paired = (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 && xf_per_pair == slots_per_pair;
-    const int flags = ref_half | (ahead << 16) | (paired ? PAIR_REF_LAST : 0);
-    if (!paired || xf_per_pair > 2) {
-        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, false>, lds))) return rc_lds;
-        hipLaunchKernelGGL((k_pass_a3<NS, LI, C, false>), dim3(nt + (ahead ? 8 : 0), n_xf), dim3(256), lds, st, descs, p->work,
-                           p->N2, (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair,
-                           nt, flags);
-    }
-    if (paired) {
-        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, true>, lds))) return rc_lds;
-        hipLaunchKernelGGL((k_pass_a3<NS, LI, C, true>), dim3(nt, n_xf / xf_per_pair), dim3(256), lds, st, descs, p->work, p->N2,
-                           (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt,
-                           ref_half);
-    }
+    const bool paired = (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 && xf_per_pair <= FFS_PAIR_MAX_XF &&
+                        xf_per_pair == slots_per_pair;
+    const int flags = ref_half | (ahead << 16);
+    const dim3 gx(nt + (ahead ? 8 : 0));
+    const int groups_y = n_xf / xf_per_pair;
+#define FFS_A3_LAUNCH(PM, GY)                                                                                              \
+    do {                                                                                                                   \
+        if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, PM>, lds))) return rc_lds;                          \
+        hipLaunchKernelGGL((k_pass_a3<NS, LI, C, PM>), dim3(gx.x, (GY)), dim3(256), lds, st, descs, p->work, p->N2,        \
+                           (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair,  \
+                           nt, flags);                                                                                     \
+    } while (0)
+    if (!paired)
+        FFS_A3_LAUNCH(0, n_xf);
+    else if (xf_per_pair == 2)
+        FFS_A3_LAUNCH(1, groups_y);
+    else
+        FFS_A3_LAUNCH(2, groups_y * (xf_per_pair - 1));
+#undef FFS_A3_LAUNCH
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
