@@ -1912,6 +1912,23 @@ FFS_DEV void bit_counts(const void* sp, const void* rp, int R, int d, int a, int
         const int jr = bit0 >> 5;      // arithmetic shift: floor
         const unsigned sh = (unsigned)bit0 & 31u;
         unsigned rw[5];
+        if (jr >= 0 && jr + 4 <= wr_max && w0 > w_first && w0 + 3 < w_last) {
+            // interior: four whole s-words (one 16-byte load; vectors start on 64-byte boundaries) against five r-words
+            // (a 4-byte aligned 16-byte load + one dword), no edge masks
+            uint4 sv, rv4;
+            __builtin_memcpy(&sv, s + w0, 16);
+            __builtin_memcpy(&rv4, r + jr, 16);
+            const unsigned r4 = r[jr + 4];
+            const unsigned sw4[4] = {sv.x, sv.y, sv.z, sv.w}, rr[5] = {rv4.x, rv4.y, rv4.z, rv4.w, r4};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned rv = __builtin_amdgcn_alignbit(rr[k + 1], rr[k], sh);
+                n11 += __popc(sw4[k] & rv);
+                n1x += __popc(sw4[k]);
+                nx1 += __popc(rv);
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 5; ++k) rw[k] = (jr + k >= 0 && jr + k <= wr_max) ? r[jr + k] : 0u;
 #pragma unroll
