@@ -259,3 +259,30 @@ def window_one_range(lo, hi, n, seg=False, seg_shift=0):
             if n + lo - 1 >= hi + 1:
                 g0, gw = hi + 1, n + lo - hi - 2
     return g0, gw, inv
+
+
+def paired_real_columns(ref_cols, cand_cols, dtype=np.complex64):
+    """Model of the paired first-pass transform (k_pass_a<.., PM> / k_pass_a3<.., PM>): two REAL column tiles share one
+    complex column transform z = ref + i*cand; with Z = column_fft(z) the stored half rows k = 0..L/2 are
+        ref^[k] = (Z[k] + conj Z[(L-k) % L]) / 2,     cand^[k] = (Z[k] - conj Z[(L-k) % L]) / (2i).
+    Returns (ref^[:L/2+1], cand^[:L/2+1]) -- what the half slots of the reference and of a single last candidate hold
+    before the inter-pass twiddle."""
+    L = ref_cols.shape[0]
+    z = (np.asarray(ref_cols, np.float32) + 1j * np.asarray(cand_cols, np.float32)).astype(dtype)
+    Z = column_fft(z, dtype)
+    k = np.arange(L // 2 + 1)
+    m = np.conj(Z[(L - k) % L])
+    return (0.5 * (Z[k] + m)).astype(dtype), (-0.5j * (Z[k] - m)).astype(dtype)
+
+
+def paired_hermitian_columns(A_half, B_half, L, dtype=np.complex64):
+    """Model of the paired last-pass transform (k_pass_c3<.., PAIRED>): two columns whose spectra are Hermitian in the
+    column index (a single real candidate's product spectrum), each given by its stored rows 0..L/2, share one complex
+    column transform of V = A + i*B (rows above L/2 rebuilt by conjugation): Re = column A's values, Im = column B's.
+    Forward-transform convention as in the kernels (the row pass has already conjugated)."""
+    k = np.arange(L)
+    idx = np.where(k <= L // 2, k, L - k)
+    full = lambda h: np.where((k <= L // 2).reshape((L,) + (1,) * (h.ndim - 1)), h[idx], np.conj(h[idx]))
+    V = (full(np.asarray(A_half)) + 1j * full(np.asarray(B_half))).astype(dtype)
+    out = column_fft(V, dtype)
+    return out.real, out.imag

@@ -109,3 +109,31 @@ def test_one_range_window_test_equals_the_two_range_one():
             if not seg and hi >= 0:
                 lag = np.where(m <= hi, m, m - n)
             assert np.array_equal(two, (lag >= lo) & (lag <= hi)), (trial, n, lo, hi, seg, shift)
+
+
+def test_two_real_columns_through_one_complex_transform():
+    """The identity behind the paired first pass (reference + single last candidate of a transform group): the half
+    spectra separated from one complex column transform equal the two real transforms, for power-of-two and 3*2^k
+    column lengths."""
+    rng = np.random.RandomState(11)
+    for L in (16, 32, 64, 256, 48, 192, 384):
+        ref = (rng.rand(L, 5) < 0.4).astype(np.float32) * 2 - 1
+        cand = (rng.rand(L, 5) < 0.6).astype(np.float32) * 0.96
+        r_half, c_half = fm.paired_real_columns(ref, cand)
+        want_r = np.fft.fft(ref.astype(np.float64), axis=0)[: L // 2 + 1]
+        want_c = np.fft.fft(cand.astype(np.float64), axis=0)[: L // 2 + 1]
+        tol = 2e-5 * L
+        assert np.abs(r_half - want_r).max() < tol, L
+        assert np.abs(c_half - want_c).max() < tol, L
+
+
+def test_two_hermitian_columns_through_one_complex_transform():
+    """The identity behind the paired last pass: two column spectra that are Hermitian in the column index (real
+    outputs) ride one complex transform as real and imaginary part."""
+    rng = np.random.RandomState(12)
+    for L in (16, 64, 48, 192):
+        a, b = rng.randn(L, 4), rng.randn(L, 4)
+        A, B = np.fft.ifft(a, axis=0) * L, np.fft.ifft(b, axis=0) * L   # spectra whose FORWARD transform is L*a, L*b
+        ra, rb = fm.paired_hermitian_columns(A[: L // 2 + 1], B[: L // 2 + 1], L)
+        assert np.abs(ra - L * a).max() < 3e-4 * L, L
+        assert np.abs(rb - L * b).max() < 3e-4 * L, L
