@@ -53,6 +53,7 @@ EXPORTED_SYMBOLS = (
     "ffs_rasterize_subtitles_bits",
     "ffs_raster_lengths",
     "ffs_rasterize_batch_bits",
+    "ffs_two_level_pack",
     "ffs_pack_bits",
     "ffs_scatter_segments",
     "ffs_comm_unique_id",
@@ -149,6 +150,8 @@ def load():
         lib.ffs_rasterize_subtitles_bits.argtypes = lib.ffs_rasterize_subtitles.argtypes
         lib.ffs_raster_lengths.restype = c.c_int
         lib.ffs_raster_lengths.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_void_p]
+        lib.ffs_two_level_pack.restype = c.c_int
+        lib.ffs_two_level_pack.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p]
         lib.ffs_rasterize_batch_bits.restype = c.c_int
         lib.ffs_rasterize_batch_bits.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p,
                                                  c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double, c.c_double,
@@ -464,6 +467,20 @@ def rasterize_batch_bits(start_us, end_us, is_metadata, vec_sub_first, vec_sub_c
                                           start_us.size, first.ctypes.data, count.ctypes.data, ratio.ctypes.data,
                                           word.ctypes.data, length.ctypes.data, n_vec, float(sample_rate),
                                           float(start_seconds), out.data_ptr(), out_words, current_stream_ptr(torch)))
+
+
+def two_level_pack(values: np.ndarray):
+    """Host-only (``ffs_two_level_pack``): (lo, hi, packed) for a contiguous float64 vector whose samples take two
+    finite levels -- ``packed`` = the samples as little-endian bits (uint8[4 * ceil(n/32)], bit i = (values[i] == hi))
+    -- or None when they do not."""
+    assert values.dtype == np.float64 and values.flags.c_contiguous and values.ndim == 1 and values.size > 0
+    levels = np.zeros(2, dtype=np.float64)
+    words = np.empty((values.size + 31) // 32, dtype=np.uint32)
+    rc = load().ffs_two_level_pack(values.ctypes.data, values.size, levels.ctypes.data, levels[1:].ctypes.data,
+                                   words.ctypes.data)
+    if rc < 0:
+        check(rc)
+    return (float(levels[0]), float(levels[1]), words.view(np.uint8)) if rc == 1 else None
 
 
 def packed_words(n: int) -> int:

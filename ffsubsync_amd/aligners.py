@@ -35,19 +35,20 @@ def _as_array(x: Any) -> np.ndarray:
     """aligners.py:51-57 input handling: '0110' strings become ints; everything -> float64."""
     if isinstance(x, str):
         x = [int(ch) for ch in x]
-    return np.asarray(x).astype(float).ravel()
+    return np.ascontiguousarray(x, dtype=np.float64).ravel()  # (no copy of an array that already is float64)
 
 
 class _Vec:
     """One activity vector as the native library wants it: two-level samples + (lo, hi) -- 0/1 bytes on
     the host, or a ``DeviceRaster`` already in HBM -- or arbitrary floats."""
 
-    __slots__ = ("n", "two_level", "lo", "hi", "bits", "_values", "dev", "raster")
+    __slots__ = ("n", "two_level", "lo", "hi", "bits", "packed", "_values", "dev", "raster")
 
     def __init__(self, x: Any) -> None:
         self.dev = None
         self.raster = None
         self._values = None
+        self.packed = None  # the samples as little-endian bits (host vectors whose levels the library found)
         if hasattr(x, "bits") and hasattr(x, "lo") and hasattr(x, "hi") and hasattr(x.bits, "data_ptr"):
             # a DeviceRaster: nothing to convert or upload
             self.raster, self.n = x, len(x)
@@ -58,6 +59,11 @@ class _Vec:
         self.n = values.size
         if self.n == 0:
             self.two_level, self.lo, self.hi, self.bits = True, 0.0, 1.0, np.zeros(0, np.uint8)
+            return
+        found = _native.two_level_pack(values)  # two passes in C instead of five numpy temporaries
+        if found is not None:
+            self.two_level, self.bits = True, None
+            self.lo, self.hi, self.packed = found
             return
         lo, hi = float(values.min()), float(values.max())
         is_hi = values == hi
@@ -110,7 +116,8 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
         # bit-packed (FFS_DTYPE_U1): host vectors are packed here (an eighth of the PCIe bytes), rasters
         # that live in HBM as bytes are packed on the device, bit-packed rasters are used in place
         dtype = _native.FFS_DTYPE_U1
-        chunks = [None if v.raster is not None else np.packbits(v.bits, bitorder="little") for v in vecs]
+        chunks = [None if v.raster is not None else v.packed if v.packed is not None
+                  else np.packbits(v.bits, bitorder="little") for v in vecs]
         for v in vecs:
             if v.raster is not None:
                 v.dev = v.raster.packed_words()

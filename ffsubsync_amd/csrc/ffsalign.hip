@@ -1407,6 +1407,57 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
     return rc;
 }
 
+// Host-only.  One activity vector as the reference hands it over (float64): are its samples two-level, and if so
+// which levels, and the samples as bits -- two passes over the array instead of numpy's five temporaries.
+int ffs_two_level_pack(const double* x, int64_t n, double* lo_out, double* hi_out, uint32_t* words) {
+    if (n <= 0 || !x || !lo_out || !hi_out || !words) return fail(FFS_E_INVALID, "bad argument");
+    double lo[4] = {x[0], x[0], x[0], x[0]}, hi[4] = {x[0], x[0], x[0], x[0]};
+    bool nan = false;
+    int64_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double v = x[i + k];
+            lo[k] = v < lo[k] ? v : lo[k];
+            hi[k] = v > hi[k] ? v : hi[k];
+            nan |= v != v;
+        }
+    }
+    for (; i < n; ++i) {
+        const double v = x[i];
+        lo[0] = v < lo[0] ? v : lo[0];
+        hi[0] = v > hi[0] ? v : hi[0];
+        nan |= v != v;
+    }
+    double l = lo[0], h = hi[0];
+    for (int k = 1; k < 4; ++k) {
+        l = lo[k] < l ? lo[k] : l;
+        h = hi[k] > h ? hi[k] : h;
+    }
+    *lo_out = l;
+    *hi_out = h;
+    if (nan || !std::isfinite(l) || !std::isfinite(h)) return 0;
+    const int64_t n_words = (n + 31) / 32;
+    if (h == l) {
+        memset(words, 0, (size_t)n_words * 4);
+        return 1;
+    }
+    for (int64_t w = 0; w < n_words; ++w) {
+        const int64_t i0 = w * 32;
+        const int cnt = (int)(n - i0 < 32 ? n - i0 : 32);
+        uint32_t bits = 0, ok = 1;
+        for (int k = 0; k < cnt; ++k) {
+            const double v = x[i0 + k];
+            const uint32_t is_hi = v == h;
+            ok &= is_hi | (uint32_t)(v == l);
+            bits |= is_hi << k;
+        }
+        if (!ok) return 0;
+        words[w] = bits;
+    }
+    return 1;
+}
+
 int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshold, uint32_t* dst_dev, void* hip_stream) {
     if (n < 0 || (src_dtype != FFS_DTYPE_U8 && src_dtype != FFS_DTYPE_F32)) return fail(FFS_E_INVALID, "bad argument");
     if (n == 0) return FFS_OK;

@@ -222,6 +222,12 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
                              double sample_rate, double start_seconds, uint32_t* out_dev, int64_t out_words,
                              void* hip_stream);
 
+/* Host-only helper of the drop-in classes: the float64 vectors FFTAligner.fit receives (aligners.py:51-57) are
+ * two-level activity vectors in practice.  Returns 1 and writes lo = min, hi = max and the samples as bits
+ * (bit i = (x[i] == hi); ceil(n/32) words; all zero when hi == lo) when every sample equals one of the two levels
+ * and both are finite; returns 0 (words unspecified) otherwise -- such vectors go to the device as floats. */
+int ffs_two_level_pack(const double* x, int64_t n, double* lo_out, double* hi_out, uint32_t* words);
+
 /* Two-level vector -> FFS_DTYPE_U1 on the device.  src_dtype FFS_DTYPE_U8: bit = (byte != 0);
  * FFS_DTYPE_F32: bit = (x > threshold), e.g. VAD labels against 0.5 or (lo+hi)/2.  Writes
  * ceil(n/32) words; unused high bits of the last word are 0. */

@@ -315,3 +315,36 @@ def test_strong_and_weak_scaling_shards():
             assert all(a[1] == b[0] for a, b in zip(bounds, bounds[1:]))
             per = (n + world - 1) // world
             assert all(hi - lo <= per for lo, hi in bounds)
+
+
+def test_two_level_pack_equals_the_numpy_detection():
+    """ffs_two_level_pack (host-only): the levels and bits the drop-in classes derive from the float64 vectors
+    FFTAligner.fit receives -- against the numpy formulation it replaced (min / max / == hi / all(== hi | == lo))."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.aligners import _Vec
+
+    rng = np.random.RandomState(8)
+    for trial in range(200):
+        n = int(rng.choice([1, 2, 31, 32, 33, 63, 64, 65, 1000, 4097]))
+        lo, hi = sorted(rng.choice([-1.0, 0.0, 0.25, 0.96, 1.0, 3.5], size=2, replace=False))
+        x = np.where(rng.rand(n) < rng.choice([0.0, 0.1, 0.5, 1.0]), hi, lo).astype(np.float64)
+        kind = trial % 5
+        if kind == 3 and n > 2:
+            x[rng.randint(n)] = 0.5 * (lo + hi)          # a third level
+        if kind == 4 and n > 1:
+            x[rng.randint(n)] = [np.nan, np.inf, -np.inf][trial % 3]
+        got = _native.two_level_pack(x)
+        want_two = bool(np.all((x == x.max()) | (x == x.min()))) and np.isfinite(x.min()) and np.isfinite(x.max())
+        assert (got is not None) == want_two, (trial, n, kind)
+        v = _Vec(x)
+        assert v.two_level == want_two and len(v) == n
+        if want_two:
+            assert (v.lo, v.hi) == (float(x.min()), float(x.max()))
+            bits = np.packbits((x == x.max()) & (x.max() != x.min()), bitorder="little")
+            assert np.array_equal(v.packed[: bits.size], bits) and not v.packed[bits.size:].any()
+            assert v.packed.size == (n + 31) // 32 * 4
+        else:
+            assert v.packed is None
+    # strings and integer lists still come through (aligners.py:51-57)
+    v = _Vec("0110")
+    assert v.two_level and (v.lo, v.hi) == (0.0, 1.0) and v.packed[0] == 0b0110
