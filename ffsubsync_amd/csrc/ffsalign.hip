@@ -3,6 +3,12 @@
 //
 // Written for gfx950 (MI355X) only: hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define FFS_HOST_AVX2 1  // host pass only: the device pass parses host functions too, without the x86 headers
+#else
+#define FFS_HOST_AVX2 0
+#endif
 #include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
@@ -1408,54 +1414,109 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
 }
 
 // Host-only.  One activity vector as the reference hands it over (float64): are its samples two-level, and if so
-// which levels, and the samples as bits -- two passes over the array instead of numpy's five temporaries.
-int ffs_two_level_pack(const double* x, int64_t n, double* lo_out, double* hi_out, uint32_t* words) {
-    if (n <= 0 || !x || !lo_out || !hi_out || !words) return fail(FFS_E_INVALID, "bad argument");
-    double lo[4] = {x[0], x[0], x[0], x[0]}, hi[4] = {x[0], x[0], x[0], x[0]};
-    bool nan = false;
+// which levels, and the samples as bits -- two passes over the array instead of numpy's five temporaries.  The AVX2
+// bodies are chosen at run time (the library is built without -march).
+namespace {
+struct MinMax {
+    double lo, hi;
+    bool nan;
+};
+MinMax minmax_scalar(const double* x, int64_t n, MinMax m) {
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = x[i];
+        m.lo = v < m.lo ? v : m.lo;
+        m.hi = v > m.hi ? v : m.hi;
+        m.nan |= v != v;
+    }
+    return m;
+}
+// bits of up to 32 samples: bit k = (x[k] == hi); *ok is cleared when a sample equals neither level
+uint32_t word_scalar(const double* x, int cnt, double lo, double hi, bool* ok) {
+    uint32_t bits = 0, good = 1;
+    for (int k = 0; k < cnt; ++k) {
+        const uint32_t is_hi = x[k] == hi;
+        good &= is_hi | (uint32_t)(x[k] == lo);
+        bits |= is_hi << k;
+    }
+    if (!good) *ok = false;
+    return bits;
+}
+#if FFS_HOST_AVX2
+__attribute__((target("avx2"))) MinMax minmax_avx2(const double* x, int64_t n, MinMax m) {
+    __m256d lo = _mm256_set1_pd(m.lo), hi = _mm256_set1_pd(m.hi), unord = _mm256_setzero_pd();
     int64_t i = 0;
     for (; i + 4 <= n; i += 4) {
+        const __m256d v = _mm256_loadu_pd(x + i);
+        lo = _mm256_min_pd(v, lo);  // (a NaN operand returns the second one: NaNs are caught below)
+        hi = _mm256_max_pd(v, hi);
+        unord = _mm256_or_pd(unord, _mm256_cmp_pd(v, v, _CMP_UNORD_Q));
+    }
+    double l[4], h[4];
+    _mm256_storeu_pd(l, lo);
+    _mm256_storeu_pd(h, hi);
+    for (int k = 0; k < 4; ++k) {
+        m.lo = l[k] < m.lo ? l[k] : m.lo;
+        m.hi = h[k] > m.hi ? h[k] : m.hi;
+    }
+    m.nan |= _mm256_movemask_pd(unord) != 0;
+    return minmax_scalar(x + i, n - i, m);
+}
+__attribute__((target("avx2"))) bool pack_avx2(const double* x, int64_t n_full_words, double lo, double hi, uint32_t* words) {
+    const __m256d vlo = _mm256_set1_pd(lo), vhi = _mm256_set1_pd(hi);
+    int all_ok = 0xf;
+    for (int64_t w = 0; w < n_full_words; ++w) {
+        const double* p = x + 32 * w;
+        uint32_t bits = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double v = x[i + k];
-            lo[k] = v < lo[k] ? v : lo[k];
-            hi[k] = v > hi[k] ? v : hi[k];
-            nan |= v != v;
+        for (int g = 0; g < 8; ++g) {
+            const __m256d v = _mm256_loadu_pd(p + 4 * g);
+            const __m256d eh = _mm256_cmp_pd(v, vhi, _CMP_EQ_OQ), el = _mm256_cmp_pd(v, vlo, _CMP_EQ_OQ);
+            bits |= (uint32_t)_mm256_movemask_pd(eh) << (4 * g);
+            all_ok &= _mm256_movemask_pd(_mm256_or_pd(eh, el));
         }
+        words[w] = bits;
     }
-    for (; i < n; ++i) {
-        const double v = x[i];
-        lo[0] = v < lo[0] ? v : lo[0];
-        hi[0] = v > hi[0] ? v : hi[0];
-        nan |= v != v;
-    }
-    double l = lo[0], h = hi[0];
-    for (int k = 1; k < 4; ++k) {
-        l = lo[k] < l ? lo[k] : l;
-        h = hi[k] > h ? hi[k] : h;
-    }
-    *lo_out = l;
-    *hi_out = h;
-    if (nan || !std::isfinite(l) || !std::isfinite(h)) return 0;
-    const int64_t n_words = (n + 31) / 32;
-    if (h == l) {
+    return all_ok == 0xf;
+}
+#endif
+}  // namespace
+
+int ffs_two_level_pack(const double* x, int64_t n, double* lo_out, double* hi_out, uint32_t* words) {
+    if (n <= 0 || !x || !lo_out || !hi_out || !words) return fail(FFS_E_INVALID, "bad argument");
+#if FFS_HOST_AVX2
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+#else
+    const bool avx2 = false;
+#endif
+    (void)avx2;
+    MinMax m{x[0], x[0], false};
+#if FFS_HOST_AVX2
+    m = avx2 ? minmax_avx2(x, n, m) : minmax_scalar(x, n, m);
+#else
+    m = minmax_scalar(x, n, m);
+#endif
+    *lo_out = m.lo;
+    *hi_out = m.hi;
+    if (m.nan || !std::isfinite(m.lo) || !std::isfinite(m.hi)) return 0;
+    const int64_t n_words = (n + 31) / 32, n_full = n / 32;
+    (void)n_full;
+    if (m.hi == m.lo) {
         memset(words, 0, (size_t)n_words * 4);
         return 1;
     }
-    for (int64_t w = 0; w < n_words; ++w) {
-        const int64_t i0 = w * 32;
-        const int cnt = (int)(n - i0 < 32 ? n - i0 : 32);
-        uint32_t bits = 0, ok = 1;
-        for (int k = 0; k < cnt; ++k) {
-            const double v = x[i0 + k];
-            const uint32_t is_hi = v == h;
-            ok &= is_hi | (uint32_t)(v == l);
-            bits |= is_hi << k;
-        }
-        if (!ok) return 0;
-        words[w] = bits;
+    bool ok = true;
+    int64_t w = 0;
+#if FFS_HOST_AVX2
+    if (avx2) {
+        ok = pack_avx2(x, n_full, m.lo, m.hi, words);
+        w = n_full;
     }
-    return 1;
+#endif
+    for (; ok && w < n_words; ++w) {
+        const int64_t i0 = w * 32;
+        words[w] = word_scalar(x + i0, (int)(n - i0 < 32 ? n - i0 : 32), m.lo, m.hi, &ok);
+    }
+    return ok ? 1 : 0;
 }
 
 int ffs_pack_bits(const void* src_dev, int src_dtype, int64_t n, double threshold, uint32_t* dst_dev, void* hip_stream) {
