@@ -42,6 +42,7 @@ EXPORTED_SYMBOLS = (
     "ffs_plan_destroy",
     "ffs_plan_workspace_bytes",
     "ffs_align_batch",
+    "ffs_align_batch_typed",
     "ffs_correlate_full",
     "ffs_vad_energy",
     "ffs_vad_energy_bits",
@@ -118,6 +119,12 @@ def load():
         lib.ffs_align_batch.restype = c.c_int
         lib.ffs_align_batch.argtypes = [
             c.c_void_p, c.c_int, c.c_int, c.c_int,
+            c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+            c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p,
+        ]
+        lib.ffs_align_batch_typed.restype = c.c_int
+        lib.ffs_align_batch_typed.argtypes = [
+            c.c_void_p, c.c_int, c.c_int, c.c_void_p,
             c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
             c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p,
         ]
@@ -251,11 +258,13 @@ class Plan:
         except Exception:
             pass
 
-    def align_batch(self, n_pairs: int, n_cand: int, dtype: int, vec_ptr: np.ndarray, vec_len: np.ndarray,
+    def align_batch(self, n_pairs: int, n_cand: int, dtype, vec_ptr: np.ndarray, vec_len: np.ndarray,
                     vec_lo: np.ndarray, vec_hi: np.ndarray, max_offset_samples: Optional[int],
                     filter_max_offset: Optional[int], cand_out, pair_out, stream: Optional[int] = None) -> None:
         """Asynchronous batched solve; ``cand_out``/``pair_out`` are uint8 CUDA tensors of
-        n_pairs*n_cand*24 and n_pairs*24 bytes.  Host arrays are consumed before returning."""
+        n_pairs*n_cand*24 and n_pairs*24 bytes.  Host arrays are consumed before returning.
+        ``dtype``: one FFS_DTYPE_* for every vector, or a (reference type, candidate type) tuple / an array with one
+        entry per vector (``ffs_align_batch_typed``: e.g. a float64 reference against bit-packed candidates)."""
         torch = require_gpu()
         n_vec = n_pairs * (1 + n_cand)
         vec_ptr = np.ascontiguousarray(vec_ptr, dtype=np.uint64)
@@ -268,8 +277,22 @@ class Plan:
                 pair_out.numel() * pair_out.element_size() < n_pairs * 24:
             raise ValueError("result buffers too small")
         st = current_stream_ptr(torch) if stream is None else stream
+        if not isinstance(dtype, (int, np.integer)):
+            if isinstance(dtype, tuple) and len(dtype) == 2:
+                dtype = np.tile(np.array([dtype[0]] + [dtype[1]] * n_cand, dtype=np.int32), n_pairs)
+            vec_dtype = np.ascontiguousarray(dtype, dtype=np.int32)
+            if vec_dtype.size != n_vec:
+                raise ValueError("one element type per vector")
+            check(self.lib.ffs_align_batch_typed(
+                self.handle, n_pairs, n_cand, vec_dtype.ctypes.data,
+                vec_ptr.ctypes.data, vec_len.ctypes.data, vec_lo.ctypes.data, vec_hi.ctypes.data,
+                -1 if max_offset_samples is None else int(max_offset_samples),
+                -1 if filter_max_offset is None else int(filter_max_offset),
+                cand_out.data_ptr(), pair_out.data_ptr(), st,
+            ))
+            return
         check(self.lib.ffs_align_batch(
-            self.handle, n_pairs, n_cand, dtype,
+            self.handle, n_pairs, n_cand, int(dtype),
             vec_ptr.ctypes.data, vec_len.ctypes.data, vec_lo.ctypes.data, vec_hi.ctypes.data,
             -1 if max_offset_samples is None else int(max_offset_samples),
             -1 if filter_max_offset is None else int(filter_max_offset),
@@ -368,8 +391,10 @@ def vad_energy_bits(pcm, frame_len: int, threshold_db: float, out=None, first_fr
         raise ValueError("first_frame must be a multiple of 8")
     if out is None:
         out = torch.zeros((first_frame + n_frames + 31) // 32, dtype=torch.int32, device=pcm.device)
-    elif out.numel() * 32 < first_frame + n_frames:
+    elif out.numel() * out.element_size() * 8 < first_frame + n_frames:
         raise ValueError("output word buffer too small")
+    elif out.device != pcm.device or not out.is_contiguous():
+        raise ValueError("output word buffer must be contiguous and on the PCM's device")
     if n:
         check(load().ffs_vad_energy_bits(pcm.data_ptr(), n, int(frame_len), float(threshold_db),
                                          out.data_ptr() + first_frame // 8, current_stream_ptr(torch)))

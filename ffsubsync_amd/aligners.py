@@ -109,24 +109,31 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
                         else _native.plan_length(len(ref), len(s), max_offset_samples))
     if n_fft > _native.MAX_FFT_LENGTH:
         raise ValueError("inputs too long for the device transform (N=%d > 2^24)" % n_fft)
-    all_two_level = all(v.two_level for v in vecs)
+    # One element type per ROLE (ffs_align_batch_typed): references and candidates are judged separately, so the
+    # two-level subtitle rasters stay bit-packed (an eighth of a byte per sample over PCIe and in HBM) when only the
+    # reference is float-valued -- e.g. the {0, .4, .6, 1} output of the weighted fused VAD, speech_transformers.py:290-293.
+    stride = 1 + n_cand
+    role_two_level = [all(v.two_level for v in vecs[0::stride]),
+                      all(v.two_level for i, v in enumerate(vecs) if i % stride)]
     lens = np.array([len(v) for v in vecs], dtype=np.int64)
     keep_alive = []  # device tensors the descriptors point into
-    if all_two_level:
-        # bit-packed (FFS_DTYPE_U1): host vectors are packed here (an eighth of the PCIe bytes), rasters
-        # that live in HBM as bytes are packed on the device, bit-packed rasters are used in place
-        dtype = _native.FFS_DTYPE_U1
-        chunks = [None if v.raster is not None else v.packed if v.packed is not None
-                  else np.packbits(v.bits, bitorder="little") for v in vecs]
-        for v in vecs:
+    chunks = []
+    for i, v in enumerate(vecs):
+        if role_two_level[1 if i % stride else 0]:
+            # bit-packed (FFS_DTYPE_U1): host vectors are packed here, rasters that live in HBM as bytes are packed on
+            # the device, bit-packed rasters are used in place
             if v.raster is not None:
                 v.dev = v.raster.packed_words()
                 keep_alive.append(v.dev)
-    else:
-        # float inputs (fused / weighted VAD levels) go over as float64: the transforms nominate in fp32, the
-        # winning lags are re-evaluated in fp64 from these very samples (no input rounding)
-        dtype = _native.FFS_DTYPE_F64
-        chunks = [np.ascontiguousarray(v.host_values(), dtype=np.float64).view(np.uint8) for v in vecs]
+                chunks.append(None)
+            else:
+                chunks.append(v.packed if v.packed is not None else np.packbits(v.bits, bitorder="little"))
+        else:
+            # float inputs (fused / weighted VAD levels) go over as float64: the transforms nominate in fp32, the
+            # winning lags are re-evaluated in fp64 from these very samples (no input rounding)
+            chunks.append(np.ascontiguousarray(v.host_values(), dtype=np.float64).view(np.uint8))
+    role_dtype = [_native.FFS_DTYPE_U1 if t else _native.FFS_DTYPE_F64 for t in role_two_level]
+    dtype = role_dtype[0] if role_dtype[0] == role_dtype[1] else (role_dtype[0], role_dtype[1])
     # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
     offs = np.zeros(len(chunks), dtype=np.int64)
     total = 0

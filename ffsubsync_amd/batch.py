@@ -25,6 +25,12 @@ class DeviceBatch:
     lo: np.ndarray
     hi: np.ndarray
     dtype: int = _native.FFS_DTYPE_U8
+    ref_dtype: Optional[int] = None  # element type of the references when it differs from the candidates' (`dtype`)
+
+    @property
+    def call_dtype(self):
+        """What ``Plan.align_batch`` takes: one type, or (reference type, candidate type) when the roles differ."""
+        return self.dtype if self.ref_dtype in (None, self.dtype) else (self.ref_dtype, self.dtype)
 
     @property
     def n_pairs(self) -> int:
@@ -40,7 +46,7 @@ class DeviceBatch:
         rows = np.arange(self.n_pairs)
         cols = 1 + np.asarray(index, dtype=np.int64)
         pick = lambda a: np.ascontiguousarray(np.stack([a[:, 0], a[rows, cols]], axis=1))
-        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi), self.dtype)
+        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi), self.dtype, self.ref_dtype)
 
     def required_fft_length(self, max_offset_samples: Optional[int] = None, reference_length: bool = False) -> int:
         """Plan length for the whole batch: the shortest alias-free transform for the lags the solve has
@@ -58,7 +64,7 @@ class DeviceBatch:
         are multiples of 64 bytes, so every packed vector starts on an 8-byte boundary."""
         if self.dtype == _native.FFS_DTYPE_U1:
             return self
-        if self.dtype != _native.FFS_DTYPE_U8:
+        if self.dtype != _native.FFS_DTYPE_U8 or self.ref_dtype not in (None, self.dtype):
             raise ValueError("only 0/1 byte batches can be bit-packed")
         assert not (self.offs % 64).any() and self.data.numel() % 64 == 0
         words = _native.pack_bits(self.data)
@@ -136,6 +142,13 @@ def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_items)
 
 
+def pairs_in_flight_for(n_pairs: int, ceiling: int = 512) -> int:
+    """Pairs per sweep of the transform kernels for a call of ``n_pairs`` problems: all of them up to 512 (measured
+    plateau: 512 and 1024 pairs per sweep run at the same rate, profiles/r02_ab_experiments.json; fewer, larger sweeps
+    have fewer launch tails), which also bounds the workspace at ~30 GiB for seven 2 h candidates."""
+    return max(1, min(int(n_pairs), int(ceiling)))
+
+
 class BatchAligner:
     """MaxScoreAligner(FFTAligner, None, sample_rate, max_offset_seconds) over a DeviceBatch."""
 
@@ -173,7 +186,7 @@ class BatchAligner:
             sl = slice(lo, hi)
             ptrs = (batch.data.data_ptr() + batch.offs[sl]).astype(np.uint64)
             c0, p0 = (lo - pair_lo) * self.n_cand * 24, (lo - pair_lo) * 24
-            plan.align_batch(hi - lo, self.n_cand, batch.dtype, ptrs.ravel(), batch.lens[sl].ravel(),
+            plan.align_batch(hi - lo, self.n_cand, batch.call_dtype, ptrs.ravel(), batch.lens[sl].ravel(),
                              batch.lo[sl].ravel(), batch.hi[sl].ravel(), self.max_offset_samples,
                              self.max_offset_samples, cand_out[c0:], pair_out[p0:])
 
@@ -234,5 +247,7 @@ def make_comm(rank: int, world: int, group=None) -> "_native.Comm":
     import torch.distributed as dist
 
     box = [_native.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
+    # `rank` is the caller's rank WITHIN `group`; broadcast's `src` is a global rank
+    src = 0 if group is None else dist.get_global_rank(group, 0)
+    dist.broadcast_object_list(box, src=src, group=group)
     return _native.Comm(rank, world, bytes(box[0]))

@@ -83,6 +83,11 @@ struct CandDesc {  // one candidate (one FFTAligner solve)
 // instead of the reference's 2^ceil(log2(R+S)).
 constexpr int CAND_NO_LAGS = 1;    // nothing for the transform / nominee kernels to do
 constexpr int CAND_HAS_ZERO = 16;  // d_zero is valid
+// Element types of the two vectors (FFS_DTYPE_* codes 0..3), preset by the host: bits 8..10 the candidate's, bits
+// 12..14 the reference's.  Read only by the mixed-type (DT == 4) instantiations of the exact re-evaluation kernels --
+// e.g. a four-level float64 reference from the weighted fused VAD (speech_transformers.py:290-293) against bit-packed
+// subtitle rasters.
+constexpr int CAND_DTS_SHIFT = 8, CAND_DTR_SHIFT = 12;
 
 struct BlockNom {
     float bmax;
@@ -339,11 +344,22 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
                                                          const cf* __restrict__ tb, const cf* __restrict__ ts,
                                                          const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
                                                          int slots_per_pair, int nt, int pf_ahead,
-                                                         unsigned* __restrict__ pf_sink, int half_flags) {
+                                                         unsigned* __restrict__ pf_sink, int half_flags, int row_sel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     typedef ColShape<L> CS;
     constexpr int LT = L / 16;
+    // grid row -> (transform group, transform within the group, paired or not).  row_sel (PM == 0 only; 0 = every
+    // transform): first | count << 16 -- the launch covers transforms [first, first + count) of every group, e.g. only
+    // the reference slots, or only the candidate slots, when the two come in different element types
+    constexpr bool CAN_PAIR = PM != 0;
+    const int sel_first = PM == 0 ? (row_sel & 0xffff) : 0, sel_count = PM == 0 ? (row_sel >> 16) : 0;
+    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : (sel_count ? sel_count : xf_per_pair));
+    auto desc_of = [&](int y, bool* is_paired) {
+        const int g = y / rows_per_group, j = y % rows_per_group;
+        *is_paired = CAN_PAIR && j == 0;
+        return g * xf_per_pair + sel_first + j;
+    };
     if (DT == 0 && blockIdx.x >= (unsigned)nt) {
         // Prefetch block.  The input bytes are the only HBM reads of this kernel, and a read that misses
         // while every CU streams writes takes microseconds (measured: 9.0 -> 6.9 us/pair with cache-resident
@@ -353,7 +369,8 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         // the same XCD (= same L2): group index mirrors the tile mapping below.
         const int y = blockIdx.y + pf_ahead;
         if (y >= (int)gridDim.y) return;
-        const XformDesc dn = descs[y];
+        bool pp0;
+        const XformDesc dn = descs[desc_of(y, &pp0)];
         const int i = blockIdx.x - nt, ng = gridDim.x - nt;
         const int grp = (i % 8) * (ng / 8) + i / 8;
         unsigned acc = 0;
@@ -367,14 +384,6 @@ __global__ __launch_bounds__((L / 16) * C) void k_pass_a(const XformDesc* __rest
         if (acc == 0xdeadbeefu && pf_sink) *pf_sink = acc;  // keeps the loads alive (pf_sink is scratch)
         return;
     }
-    // grid row -> (transform group, transform within the group, paired or not)
-    constexpr bool CAN_PAIR = PM != 0;
-    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : xf_per_pair);
-    auto desc_of = [&](int y, bool* is_paired) {
-        const int g = y / rows_per_group, j = y % rows_per_group;
-        *is_paired = CAN_PAIR && j == 0;
-        return g * xf_per_pair + j;
-    };
     if (DT == 2 && blockIdx.x >= (unsigned)nt) {
         const int y = (int)blockIdx.y + pf_ahead;
         if (y >= (int)gridDim.y) return;
@@ -1527,17 +1536,18 @@ __global__ __launch_bounds__(256, (PM != 0 && NS == 3) ? FFS_A3P_WAVES : FFS_C3_
                                                  long long N, const cf* __restrict__ tw, const cf* __restrict__ tbR,
                                                  const cf* __restrict__ tsR, const cf* __restrict__ thR,
                                                  const cf* __restrict__ tw3, int log2CL, int xf_per_pair,
-                                                 int slots_per_pair, int nt, int half_flags) {
+                                                 int slots_per_pair, int nt, int half_flags, int row_sel) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     cf* lds = reinterpret_cast<cf*>(smem);
     constexpr int L = NS * LI, LTI = LI / 16, NT = LTI * C, CW = (C + 31) / 32;
     static_assert(NT == 256, "256 threads per block");
-    // grid row -> (transform group, transform within the group, paired or not)
-    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : xf_per_pair);
+    // grid row -> (transform group, transform within the group, paired or not); row_sel as in k_pass_a
+    const int sel_first = PM == 0 ? (row_sel & 0xffff) : 0, sel_count = PM == 0 ? (row_sel >> 16) : 0;
+    const int rows_per_group = PM == 2 ? xf_per_pair - 1 : (PM == 1 ? 1 : (sel_count ? sel_count : xf_per_pair));
     auto desc_of = [&](int y, bool* is_paired) {
         const int g = y / rows_per_group, j = y % rows_per_group;
         *is_paired = PM != 0 && j == 0;
-        return g * xf_per_pair + j;
+        return g * xf_per_pair + sel_first + j;
     };
     if (blockIdx.x >= (unsigned)nt) {  // input prefetch block (see prefetch_bit_inputs); distance in bits 16..23 of half_flags
         const int y = (int)blockIdx.y + ((half_flags >> 16) & 255);
@@ -1956,6 +1966,50 @@ FFS_DEV double mapped_sample(const void* p, int i) {
     return 2.0 * (double)reinterpret_cast<const float*>(p)[i] - 1.0;
 }
 
+// Mixed element types (DT == 4): the mapped sample x' of either vector in fp64, whatever its storage -- a two-level
+// byte / bit picks the fp64 level value (v0, v1 = 2*lo-1, 2*hi-1 as the reference computes them), a float sample is
+// mapped as aligners.py:55-57 does.  `dt` is wave-uniform (one branch per call site, no divergence).
+FFS_DEV double sample_any(const void* p, int dt, int i, double v0, double v1) {
+    if (dt == 2) return get_bit(p, i) ? v1 : v0;
+    if (dt == 0) return reinterpret_cast<const unsigned char*>(p)[i] ? v1 : v0;
+    if (dt == 3) return 2.0 * reinterpret_cast<const double*>(p)[i] - 1.0;
+    return 2.0 * (double)reinterpret_cast<const float*>(p)[i] - 1.0;
+}
+// sum over i in [a, b) of s'[i] * r'[i + d] for this thread's share (every nt-th sample), any pairing of types
+FFS_DEV double mixed_dot(const CandDesc& cd, int d, int a, int b, int tid, int nt) {
+    const int dts = (cd.flags >> CAND_DTS_SHIFT) & 7, dtr = (cd.flags >> CAND_DTR_SHIFT) & 7;
+    double sum = 0.0;
+    if (dts == 2 && dtr == 3) {
+        // the common pairing: bit-packed candidate, float64 reference.  sum s'[i] r'[i+d] = s0 * sum r' + (s1 - s0) *
+        // sum over set bits of r': two fp64 accumulators, one 8-byte load per sample, the bit word shared by 32 lanes
+        // (two samples per 16-byte load, four loads in flight per lane: the loop is latency-bound otherwise)
+        const unsigned* __restrict__ sw = reinterpret_cast<const unsigned*>(cd.s);
+        const double* __restrict__ r = reinterpret_cast<const double*>(cd.r) + d;
+        double all = 0.0, set = 0.0, all1 = 0.0, set1 = 0.0;
+        int i = a + 2 * tid;
+#pragma unroll 4
+        for (; i + 1 < b; i += 2 * nt) {
+            double2 x;
+            __builtin_memcpy(&x, r + i, 16);
+            const double x0 = 2.0 * x.x - 1.0, x1 = 2.0 * x.y - 1.0;
+            all += x0;
+            all1 += x1;
+            set += ((sw[i >> 5] >> (i & 31)) & 1u) ? x0 : 0.0;
+            set1 += ((sw[(i + 1) >> 5] >> ((i + 1) & 31)) & 1u) ? x1 : 0.0;
+        }
+        if (i < b) {  // the odd sample at the end of the range
+            const double x0 = 2.0 * r[i] - 1.0;
+            all += x0;
+            set += ((sw[i >> 5] >> (i & 31)) & 1u) ? x0 : 0.0;
+        }
+        all += all1;
+        set += set1;
+        return cd.s0 * all + (cd.s1 - cd.s0) * set;
+    }
+    for (int i = a + tid; i < b; i += nt) sum += sample_any(cd.s, dts, i, cd.s0, cd.s1) * sample_any(cd.r, dtr, i + d, cd.r0, cd.r1);
+    return sum;
+}
+
 template <int DT>
 __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ cands, const NomList* __restrict__ noms,
                                                  RescoreAcc* __restrict__ acc, int first_cand) {
@@ -1964,7 +2018,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
     const int count = nl.count;
     if (count <= 0) return;
     const CandDesc& cd = cands[ci];
-    constexpr int VEC = (DT == 0) ? 16 : (DT == 2 ? 128 : (DT == 3 ? 2 : 4));  // elements per 16-byte load
+    constexpr int VEC = (DT == 0) ? 16 : (DT == 2 ? 128 : (DT == 3 ? 2 : 4));  // (DT 4, mixed types: 4)  // elements per 16-byte load
     for (int ni = 0; ni < count; ++ni) {
         const int d = nl.d[ni];
         const int i0 = d < 0 ? -d : 0;
@@ -2027,9 +2081,12 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
                 atomicAdd(&out.n1x, n1x);
                 atomicAdd(&out.nx1, nx1);
             }
-        } else if (DT == 3) {
+        } else if (DT == 3 || DT == 4) {
             double sum = 0.0;
-            for (int i = a + (int)threadIdx.x; i < b; i += 256) sum += mapped_sample<3>(cd.s, i) * mapped_sample<3>(cd.r, i + d);
+            if (DT == 4)
+                sum = mixed_dot(cd, d, a, b, (int)threadIdx.x, 256);
+            else
+                for (int i = a + (int)threadIdx.x; i < b; i += 256) sum += mapped_sample<3>(cd.s, i) * mapped_sample<3>(cd.r, i + d);
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
             __shared__ double s_part3[4];
@@ -2067,7 +2124,7 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
 }
 
 FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
-    if (dt == 1 || dt == 3) {
+    if (dt == 1 || dt == 3 || dt == 4) {
         double sum = 0.0;
         for (int i = 0; i < RSEG; ++i) sum += a.part[i];
         return sum;
@@ -2094,7 +2151,7 @@ __global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict
         const int i0 = d < 0 ? -d : 0;
         const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
         double score = 0.0;
-        if (DT != 1 && DT != 3) {
+        if (DT != 1 && DT != 3 && DT != 4) {
             const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
             const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r) + (DT == 0 ? d : 0);
             unsigned int n11 = 0, n1x = 0, nx1 = 0;
@@ -2141,8 +2198,11 @@ __global__ __launch_bounds__(256) void k_pool_rescore(const CandDesc* __restrict
             score = exact_score(cd, a, d, 0);
         } else {
             double sum = 0.0;
-            for (int i = i0 + (int)threadIdx.x; i < i1; i += 256)
-                sum += mapped_sample<DT>(cd.s, i) * mapped_sample<DT>(cd.r, i + d);
+            if (DT == 4)
+                sum = mixed_dot(cd, d, i0, i1, (int)threadIdx.x, 256);
+            else
+                for (int i = i0 + (int)threadIdx.x; i < i1; i += 256)
+                    sum += mapped_sample<DT>(cd.s, i) * mapped_sample<DT>(cd.r, i + d);
 #pragma unroll
             for (int sft = 32; sft >= 1; sft >>= 1) sum += __shfl_xor(sum, sft, 64);
             __syncthreads();
@@ -2265,7 +2325,9 @@ __global__ __launch_bounds__(256) void k_direct(const CandDesc* __restrict__ can
             const int i0 = d < 0 ? -d : 0;
             const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
             double sc;
-            if (DT != 1 && DT != 3) {
+            if (DT == 4) {
+                sc = mixed_dot(cd, d, i0, i1, 0, 1);
+            } else if (DT != 1 && DT != 3) {
                 const unsigned char* s = reinterpret_cast<const unsigned char*>(cd.s);
                 const unsigned char* r = reinterpret_cast<const unsigned char*>(cd.r);
                 RescoreAcc a;

@@ -63,6 +63,27 @@ int fail(int code, const char* fmt, ...) {
         }                                      \
     } while (0)
 
+// the exact re-evaluation kernels: DT as above, or 4 when the reference and the candidates differ in element type
+#define FFS_BY_RESCORE_DTYPE(mixed, dtype, stmt)  \
+    do {                                          \
+        if (mixed) {                              \
+            constexpr int DT = 4;                 \
+            stmt;                                 \
+        } else if ((dtype) == FFS_DTYPE_U8) {     \
+            constexpr int DT = 0;                 \
+            stmt;                                 \
+        } else if ((dtype) == FFS_DTYPE_F32) {    \
+            constexpr int DT = 1;                 \
+            stmt;                                 \
+        } else if ((dtype) == FFS_DTYPE_F64) {    \
+            constexpr int DT = 3;                 \
+            stmt;                                 \
+        } else {                                  \
+            constexpr int DT = 2;                 \
+            stmt;                                 \
+        }                                         \
+    } while (0)
+
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
 constexpr unsigned kPoolCapacity = 1u << 20;
@@ -149,7 +170,6 @@ struct ffs_plan {
     // the five run-time knobs; none of them can change a result
     bool allow_pruned = true;       // FFS_DISABLE_PRUNED_PASS_C=1 forces the full last pass
     bool allow_half_last = true;    // FFS_DISABLE_HALF_LAST=1: store all rows of a single-candidate last slot
-    bool allow_radix3 = true;       // FFS_DISABLE_RADIX3=1 (read by ffs_plan_length): power-of-two lengths only
     int lab_flags = 0;              // lab build only (make lab): DBG_* section switches, timing only
     // device tables
     cf *tw1 = nullptr, *tw2 = nullptr;        // stage tables for N1 / N2
@@ -298,9 +318,10 @@ int bit_prefetch_rows(const ffs_plan* p) {
 #ifndef FFS_PAIR_MAX_XF
 #define FFS_PAIR_MAX_XF 64  // A/B builds: largest transform group that takes the paired transform
 #endif
+// row_sel = first | count << 16: only transforms [first, first + count) of every group (0 = all of them; see k_pass_a)
 template <int L, int C, int DT>
 int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
-                       int ref_half, hipStream_t st) {
+                       int ref_half, hipStream_t st, int row_sel) {
     const size_t lds = col_lds_bytes(L);
     int rc_lds;
     const int nt = p->N2 / C;
@@ -313,8 +334,9 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
     // bit-packed inputs, reference slot and last candidate slot both half slots (one real vector each): one paired
     // column transform per group instead of two, in the same launch as the group's other transforms
     constexpr bool CAN_PAIR = DT == 2 && L % 3 != 0;
-    const bool paired = CAN_PAIR && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
+    const bool paired = CAN_PAIR && !row_sel && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
                         xf_per_pair <= FFS_PAIR_MAX_XF && xf_per_pair == slots_per_pair;
+    const int grid_rows = row_sel ? (n_xf / xf_per_pair) * (row_sel >> 16) : n_xf;
     const int flags = ref_half | STORE_8B | (p->lab_flags & (31 << 10));
     if constexpr (CAN_PAIR) {
         if (paired) {
@@ -324,21 +346,21 @@ int launch_pass_a_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int 
                 if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT, 1>, lds_p))) return rc_lds;
                 hipLaunchKernelGGL((k_pass_a<L, C, DT, 1>), dim3(nt + pf, groups_y), dim3((L / 16) * C), lds_p, st, descs, p->work,
                                    p->N2, (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair,
-                                   slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags);
+                                   slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags, 0);
             } else {
                 if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT, 2>, lds_p))) return rc_lds;
                 hipLaunchKernelGGL((k_pass_a<L, C, DT, 2>), dim3(nt + pf, groups_y * (xf_per_pair - 1)), dim3((L / 16) * C), lds_p,
                                    st, descs, p->work, p->N2, (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL,
-                                   xf_per_pair, slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags);
+                                   xf_per_pair, slots_per_pair, nt, ahead, (unsigned*)p->bnom, flags, 0);
             }
             HIP_TRY(hipGetLastError());
             return FFS_OK;
         }
     }
     if ((rc_lds = ensure_lds(p, (const void*)k_pass_a<L, C, DT>, lds))) return rc_lds;
-    hipLaunchKernelGGL((k_pass_a<L, C, DT>), dim3(nt + pf, n_xf), dim3((L / 16) * C), lds, st, descs, p->work, p->N2,
+    hipLaunchKernelGGL((k_pass_a<L, C, DT>), dim3(nt + pf, grid_rows), dim3((L / 16) * C), lds, st, descs, p->work, p->N2,
                        (long long)p->N, p->tw1, p->tbA, p->tsA, p->twn1, p->log2CL, xf_per_pair, slots_per_pair, nt, ahead,
-                       (unsigned*)p->bnom, flags);
+                       (unsigned*)p->bnom, flags, row_sel);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
 }
@@ -349,15 +371,15 @@ int col3r_cols(const ffs_plan* p) { return p->N1 == 512 ? 16 : 4096 / (p->N1 / 3
 
 template <int NS, int LI, int C>
 int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair,
-                        int ref_half, hipStream_t st) {
+                        int ref_half, hipStream_t st, int row_sel) {
     const size_t lds = (size_t)LI * C * sizeof(cf);
     int rc_lds;
     const int nt = p->N2 / C;
     const int ahead = nt % 8 == 0 ? bit_prefetch_rows(p) : 0;  // eight prefetch blocks per grid row, one per XCD
     const cf* tw = NS == 2 ? p->tw1h : p->tw1;
     // reference slot and last candidate slot both half slots (one real vector each): one paired column transform
-    const bool paired = (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 && xf_per_pair <= FFS_PAIR_MAX_XF &&
-                        xf_per_pair == slots_per_pair;
+    const bool paired = !row_sel && (ref_half & HALF_REF) && (ref_half & HALF_LAST) && xf_per_pair >= 2 &&
+                        xf_per_pair <= FFS_PAIR_MAX_XF && xf_per_pair == slots_per_pair;
     const int flags = ref_half | (ahead << 16);
     const dim3 gx(nt + (ahead ? 8 : 0));
     const int groups_y = n_xf / xf_per_pair;
@@ -366,10 +388,10 @@ int launch_pass_a3_inst(const ffs_plan* p, const XformDesc* descs, int n_xf, int
         if ((rc_lds = ensure_lds(p, (const void*)k_pass_a3<NS, LI, C, PM>, lds))) return rc_lds;                          \
         hipLaunchKernelGGL((k_pass_a3<NS, LI, C, PM>), dim3(gx.x, (GY)), dim3(256), lds, st, descs, p->work, p->N2,        \
                            (long long)p->N, tw, p->tbR, p->tsR, p->thR, p->twn1, p->log2CL, xf_per_pair, slots_per_pair,  \
-                           nt, flags);                                                                                     \
+                           nt, flags, PM == 0 ? row_sel : 0);                                                              \
     } while (0)
     if (!paired)
-        FFS_A3_LAUNCH(0, n_xf);
+        FFS_A3_LAUNCH(0, row_sel ? groups_y * (row_sel >> 16) : n_xf);
     else if (xf_per_pair == 2)
         FFS_A3_LAUNCH(1, groups_y);
     else
@@ -413,30 +435,30 @@ int launch_pass_c3(const ffs_plan* p, const CandDesc* cands, int first_cand, int
 
 template <int DT>
 int launch_pass_a(const ffs_plan* p, const XformDesc* descs, int n_xf, int xf_per_pair, int slots_per_pair, int ref_half,
-                  hipStream_t st) {
+                  hipStream_t st, int row_sel = 0) {
     if (DT == 2 && col3r_ok(p)) {
         switch (p->N1) {
-            case 192: return launch_pass_a3_inst<3, 64, 64>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-            case 384: return launch_pass_a3_inst<3, 128, 32>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-            case 768: return launch_pass_a3_inst<3, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-            case 512: return launch_pass_a3_inst<2, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+            case 192: return launch_pass_a3_inst<3, 64, 64>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+            case 384: return launch_pass_a3_inst<3, 128, 32>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+            case 768: return launch_pass_a3_inst<3, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+            case 512: return launch_pass_a3_inst<2, 256, 16>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
         }
     }
     switch (p->N1) {
-        case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 192: return launch_pass_a_inst<192, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 384: return launch_pass_a_inst<384, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 768: return launch_pass_a_inst<768, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
-        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st);
+        case 48: return launch_pass_a_inst<48, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 96: return launch_pass_a_inst<96, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 192: return launch_pass_a_inst<192, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 384: return launch_pass_a_inst<384, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 768: return launch_pass_a_inst<768, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 16: return launch_pass_a_inst<16, 256, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 32: return launch_pass_a_inst<32, 128, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 64: return launch_pass_a_inst<64, 64, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 128: return launch_pass_a_inst<128, 32, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 256: return launch_pass_a_inst<256, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 512: return launch_pass_a_inst<512, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 1024: return launch_pass_a_inst<1024, 16, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 2048: return launch_pass_a_inst<2048, 8, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
+        case 4096: return launch_pass_a_inst<4096, 4, DT>(p, descs, n_xf, xf_per_pair, slots_per_pair, ref_half, st, row_sel);
     }
     return fail(FFS_E_INVALID, "unsupported column length %d", p->N1);
 }
@@ -693,7 +715,8 @@ int64_t next_pow2(int64_t x) {
 }
 
 // Fill the candidate descriptor for (ref, sub); returns a negative code on error.
-int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd) {
+int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd, int ref_dt,
+              int cand_dt) {
     const int64_t R = ref.len, S = sub.len;
     if (R <= 0 || S <= 0)
         return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
@@ -723,6 +746,7 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
         cd->flags |= CAND_HAS_ZERO;
         cd->d_zero = (int32_t)d_zero;
     }
+    cd->flags |= (cand_dt << CAND_DTS_SHIFT) | (ref_dt << CAND_DTR_SHIFT);
     cd->s0 = mapped(sub.lo);
     cd->s1 = mapped(sub.hi);
     cd->r0 = mapped(ref.lo);
@@ -826,7 +850,6 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_pruned = !on("FFS_DISABLE_PRUNED_PASS_C");
         p->allow_seg = !on("FFS_DISABLE_SEGMENTED");
         p->allow_half_last = !on("FFS_DISABLE_HALF_LAST");
-        p->allow_radix3 = !on("FFS_DISABLE_RADIX3");
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
 #ifdef FFS_LAB
@@ -960,15 +983,20 @@ int ffs_plan_destroy(ffs_plan* p) {
 
 int64_t ffs_plan_workspace_bytes(const ffs_plan* p) { return p ? p->workspace_bytes : 0; }
 
-int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void* const* vec_ptr,
-                    const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
-                    int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
-                    void* hip_stream) {
+static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtype, const void* const* vec_ptr,
+                      const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
+                      int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                      void* hip_stream) {
+    // `dtype` = the candidates' element type, `ref_dt` = the references'; `mixed` when they differ: the first pass
+    // runs once per role (row_sel) and the exact re-evaluation goes through the type-generic instantiations (DT 4)
+    const bool mixed = ref_dt != dtype;
+    auto known = [](int dt) { return dt == FFS_DTYPE_U8 || dt == FFS_DTYPE_F32 || dt == FFS_DTYPE_U1 || dt == FFS_DTYPE_F64; };
+    auto esz_of = [](int dt) -> size_t { return dt == FFS_DTYPE_U8 ? 1 : (dt == FFS_DTYPE_F32 ? 4 : (dt == FFS_DTYPE_F64 ? 8 : 0)); };
+    auto amask_of = [](int dt) -> uintptr_t { return dt == FFS_DTYPE_U8 ? 0 : (dt == FFS_DTYPE_F64 ? 7 : 3); };
     if (!p) return fail(FFS_E_INVALID, "plan is null");
     if (n_pairs < 0 || n_cand < 1 || n_cand > p->max_cand)
         return fail(FFS_E_INVALID, "n_cand=%d outside [1, plan max_cand=%d]", n_cand, p->max_cand);
-    if (dtype != FFS_DTYPE_U8 && dtype != FFS_DTYPE_F32 && dtype != FFS_DTYPE_U1 && dtype != FFS_DTYPE_F64)
-        return fail(FFS_E_INVALID, "unknown dtype %d", dtype);
+    if (!known(dtype) || !known(ref_dt)) return fail(FFS_E_INVALID, "unknown dtype %d / %d", ref_dt, dtype);
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
     if (n_pairs == 0) return FFS_OK;
@@ -982,6 +1010,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     const int n_packed = (n_cand + 1) / 2;
     const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
     const int xf_per_pair = n_slots;
+    const int sel_ref = 0 | (1 << 16), sel_cand = 1 | ((n_slots - 1) << 16);  // row_sel of the two first-pass launches when mixed
     const bool ref_half = !p->direct_only && ref_half_ok(p);
     // odd candidate count: the last packed transform carries one real candidate -> half of its rows suffice
     // (needs the one-row-per-block mid kernels, like ref_half; the plan that runs the kernels decides)
@@ -1025,10 +1054,10 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (!ref.ptr || !subs[j].ptr) {
                 if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
             }
-            if (dtype != FFS_DTYPE_U8 && (((uintptr_t)ref.ptr | (uintptr_t)subs[j].ptr) & (dtype == FFS_DTYPE_F64 ? 7 : 3)))
+            if (((uintptr_t)ref.ptr & amask_of(ref_dt)) || ((uintptr_t)subs[j].ptr & amask_of(dtype)))
                 return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
             const CandDesc& cd = hc[(size_t)pi * n_cand + j];
-            if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j]))) return rc;
+            if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j], ref_dt, dtype))) return rc;
             // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
             // keeps working on the whole vectors through the candidate descriptor)
             int64_t s_eff, r_eff;
@@ -1080,7 +1109,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 seg_blocks = (int)((s_max + B - 1) / B);
                 seg_lo = d_lo;
                 // byte / float vectors move the pointer to the block's first sample, bit-packed ones the bit offset
-                const size_t esz = (dtype == FFS_DTYPE_U8) ? 1 : (dtype == FFS_DTYPE_F32 ? 4 : (dtype == FFS_DTYPE_F64 ? 8 : 0));
+                const size_t esz = esz_of(dtype), esz_r = esz_of(ref_dt);
                 n_xf = (size_t)n_pairs * seg_blocks * n_slots;
                 for (int pi = 0; pi < n_pairs; ++pi) {
                     const VecView& ref = views[(size_t)pi * stride];
@@ -1093,8 +1122,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                         if (rb.len <= rb.lead) {
                             rb.len = rb.lead = 0;  // nothing of the reference in this stretch
                         } else {
-                            rb.ptr = (const char*)ref.ptr + start * (int64_t)esz;  // may point in front of the vector (lead)
-                            if (!esz) rb.off = ref.off + start;
+                            rb.ptr = (const char*)ref.ptr + start * (int64_t)esz_r;  // may point in front of the vector (lead)
+                            if (!esz_r) rb.off = ref.off + start;
                         }
                         fill_xform(x, &rb, nullptr, ref.ptr);
                         std::vector<VecView> sb(n_cand);
@@ -1134,7 +1163,7 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
     PairResult* pres = (PairResult*)pair_out_dev;
 
     if (p->direct_only) {
-        FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
+        FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
         HIP_TRY(hipGetLastError());
     } else {
         HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
@@ -1153,7 +1182,12 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             const XformDesc* dxs = dx + (size_t)p0 * seg_blocks * n_slots;
             {
                 ProfSpan span(p, st, FFS_K_PASS_A);
-                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st));
+                if (mixed) {  // the reference slot of every group in its own type, then the candidate slots in theirs
+                    FFS_BY_DTYPE(ref_dt, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_ref));
+                    if (!rc) FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_cand));
+                } else {
+                    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st));
+                }
             }
             if (rc) return rc;
             {
@@ -1179,8 +1213,8 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                 return rc;
             {
                 ProfSpan span(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
-                                                       first_cand));
+                FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
+                                                                      st, dc, dn, da, first_cand));
             }
             HIP_TRY(hipGetLastError());
         }
@@ -1189,8 +1223,15 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             const int first_cand = p0 * n_cand;
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
-                FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
-                                                           n_slots, hflags, st));
+                if (mixed) {
+                    FFS_BY_DTYPE(ref_dt, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
+                                                                n_slots, hflags, st, sel_ref));
+                    if (!rc) FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair,
+                                                                        xf_per_pair, n_slots, hflags, st, sel_cand));
+                } else {
+                    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
+                                                               n_slots, hflags, st));
+                }
             }
             if (rc) return rc;
             {
@@ -1219,21 +1260,46 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
-                FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0, st, dc, dn, da,
-                                                       first_cand));
+                FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
+                                                                      st, dc, dn, da, first_cand));
             }
             HIP_TRY(hipGetLastError());
         }
-        FFS_BY_DTYPE(dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
+        FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
         hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
         hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
-                           (int)n_cands, dtype, pa.header, dpb);
+                           (int)n_cands, mixed ? 4 : dtype, pa.header, dpb);
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
                        (long long)filter_max_offset);
     HIP_TRY(hipGetLastError());
     return leave_stream(p, st);
+}
+
+int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void* const* vec_ptr,
+                    const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
+                    int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                    void* hip_stream) {
+    return align_impl(p, n_pairs, n_cand, dtype, dtype, vec_ptr, vec_len, vec_lo, vec_hi, max_offset_samples,
+                      filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+}
+
+int ffs_align_batch_typed(ffs_plan* p, int n_pairs, int n_cand, const int32_t* vec_dtype, const void* const* vec_ptr,
+                          const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
+                          int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                          void* hip_stream) {
+    if (!vec_dtype) return fail(FFS_E_INVALID, "null argument");
+    if (n_pairs <= 0 || n_cand < 1) return n_pairs == 0 ? FFS_OK : fail(FFS_E_INVALID, "bad n_pairs / n_cand");
+    // one type per ROLE: every reference of the call shares vec_dtype[0], every candidate vec_dtype[1]
+    const int ref_dt = vec_dtype[0], cand_dt = vec_dtype[1];
+    const size_t stride = 1 + (size_t)n_cand;
+    for (size_t i = 0; i < (size_t)n_pairs * stride; ++i)
+        if (vec_dtype[i] != (i % stride == 0 ? ref_dt : cand_dt))
+            return fail(FFS_E_INVALID, "vector %zu has element type %d: within one call all references must share one type "
+                        "and all candidates one type (split the call)", i, (int)vec_dtype[i]);
+    return align_impl(p, n_pairs, n_cand, ref_dt, cand_dt, vec_ptr, vec_len, vec_lo, vec_hi, max_offset_samples,
+                      filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
 }
 
 int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_len, double ref_lo, double ref_hi,
@@ -1356,6 +1422,47 @@ int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us,
                           hip_stream);
 }
 
+namespace {
+// Pinned host staging for tables that an asynchronous copy reads after the entry point has returned.
+struct PinnedStage {
+    void* host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    int device = -1;
+    bool pending = false;
+};
+int stage_acquire(size_t bytes, PinnedStage** out) {
+    thread_local PinnedStage stages[2];
+    thread_local int next = 0;
+    PinnedStage& sg = stages[next];
+    next ^= 1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (sg.pending) {
+        (void)hipEventSynchronize(sg.done);  // the copy that read this buffer (two calls ago) has completed
+        sg.pending = false;
+    }
+    if (sg.done && sg.device != dev) {  // events belong to a device
+        (void)hipEventDestroy(sg.done);
+        sg.done = nullptr;
+    }
+    if (!sg.done) {
+        HIP_TRY(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+        sg.device = dev;
+    }
+    if (sg.cap < bytes) {
+        if (sg.host) (void)hipHostFree(sg.host);
+        sg.host = nullptr;
+        sg.cap = 0;
+        const size_t cap = bytes + bytes / 2 + 4096;
+        HIP_TRY(hipHostMalloc(&sg.host, cap, hipHostMallocDefault));
+        sg.cap = cap;
+    }
+    *out = &sg;
+    return FFS_OK;
+}
+}  // namespace
+
 int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs_total,
                              const int64_t* vec_sub_first, const int64_t* vec_sub_count, const double* vec_ratio,
                              const int64_t* vec_out_word, const int64_t* vec_len, int64_t n_vec, double sample_rate,
@@ -1372,6 +1479,7 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
         if (vec_sub_first[v] < 0 || vec_sub_count[v] < 0 || vec_sub_first[v] + vec_sub_count[v] > n_subs_total)
             return fail(FFS_E_INVALID, "vector %lld: subtitle range outside the arrays", (long long)v);
         if (vec_len[v] < 0 || vec_len[v] >= (int64_t(1) << 31)) return fail(FFS_E_TOO_LONG, "raster longer than 2^31 samples");
+        if (vec_sub_count[v] >= (int64_t(1) << 31)) return fail(FFS_E_INVALID, "vector %lld: too many subtitles", (long long)v);
         if (vec_out_word[v] < 0 || vec_out_word[v] + (vec_len[v] + 31) / 32 > out_words)
             return fail(FFS_E_INVALID, "vector %lld: output range outside the buffer", (long long)v);
         vecs[(size_t)v] = RasterVec{(long long)vec_sub_first[v], (long long)vec_out_word[v], vec_ratio[v], (int)vec_sub_count[v],
@@ -1385,22 +1493,25 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
     if ((rc_dev = guard.enter(out_dev))) return rc_dev;
     HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)out_words * 4, st));
     if (n_vec == 0 || longest == 0) return FFS_OK;
-    // one staging allocation: start | end | vector table | metadata flags
+    // one staging allocation: start | end | vector table | metadata flags.  The tables are the caller's (and this
+    // function's) pageable memory and must have been read before we return: they are copied into a pinned per-thread
+    // staging buffer (two of them, alternating; a buffer is reused once the copy that read it has completed -- an event,
+    // not a synchronisation of the caller's stream, which may hold a pipelined VAD sweep or the previous solve) and go
+    // to the device in ONE asynchronous copy.
     const size_t nsub = (size_t)n_subs_total, off_end = nsub * 8, off_vec = 2 * nsub * 8;
     const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterVec), total = off_meta + (is_metadata ? nsub : 0);
+    PinnedStage* stage = nullptr;
+    int rc = stage_acquire(total, &stage);
+    if (rc) return rc;
+    char* hs = (char*)stage->host;
+    memcpy(hs, start_us, nsub * 8);
+    memcpy(hs + off_end, end_us, nsub * 8);
+    memcpy(hs + off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterVec));
+    if (is_metadata) memcpy(hs + off_meta, is_metadata, nsub);
     char* d = nullptr;
     HIP_TRY(hipMallocAsync((void**)&d, total, st));
-    int rc = FFS_OK;
-    auto put = [&](size_t off, const void* src, size_t bytes) {
-        if (rc == FFS_OK && bytes && hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, st) != hipSuccess)
-            rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
-    };
-    put(0, start_us, nsub * 8);
-    put(off_end, end_us, nsub * 8);
-    put(off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterVec));
-    if (is_metadata) put(off_meta, is_metadata, nsub);
-    // the tables are the caller's (and this function's) pageable memory: they must have been read before we return
-    if (rc == FFS_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(FFS_E_HIP, "stream synchronisation failed");
+    if (hipMemcpyAsync(d, hs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
     if (rc == FFS_OK) {
         const unsigned bx = (unsigned)((longest + 255) / 256);
         hipLaunchKernelGGL(k_rasterize_batch, dim3(bx < 64 ? bx : 64, (unsigned)(n_vec < 65535 ? n_vec : 65535)), dim3(256), 0, st,

@@ -126,6 +126,22 @@ int ffs_align_batch(ffs_plan* plan, int n_pairs, int n_cand, int dtype,
                     ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
                     void* hip_stream);
 
+/* The same solve with one element type PER VECTOR: vec_dtype[i] is the FFS_DTYPE_* of vec_ptr[i] (pair-major like the
+ * other arrays).  Within one call every reference must share one type and every candidate one type; the two may
+ * differ.  The case this exists for: a multi-level float reference -- the `weighted` fused VAD emits
+ * {0, 0.4, 0.6, 1} (speech_transformers.py:290-293), non_speech_label may be != 0 -- against two-level subtitle
+ * rasters (speech_transformers.py:957-980), which then stay bit-packed (FFS_DTYPE_U1): the first pass reads each role
+ * in its own format, the fp32 transforms nominate, and the nominees are re-evaluated in fp64 from the caller's own
+ * samples (sum_i s'[i] * (2 r[i+d] - 1) with s' the candidate's fp64 level values).  vec_lo / vec_hi of a float vector
+ * are bounds of its samples (used for the tie margin).  With all types equal this is ffs_align_batch.
+ * Replaces: aligners.py:50-80, 131-167 for float-valued inputs. */
+int ffs_align_batch_typed(ffs_plan* plan, int n_pairs, int n_cand, const int32_t* vec_dtype,
+                          const void* const* vec_ptr, const int64_t* vec_len,
+                          const double* vec_lo, const double* vec_hi,
+                          int64_t max_offset_samples, int64_t filter_max_offset,
+                          ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                          void* hip_stream);
+
 /* Full correlation of one reference with one or two candidates (b_dev may be NULL):
  *   out_x_dev[m] = sum_i x'[i] * ref'[(i + m) mod n_fft],  m in [0, n_fft)
  * i.e. the reference's `convolve` array (aligners.py:74) with convolve[k] = out[(N-1-S-k) mod N].
@@ -214,8 +230,9 @@ int ffs_rasterize_subtitles_bits(const int64_t* start_us, const int64_t* end_us,
  * NULL); vector v rasterises the subtitles [vec_sub_first[v], vec_sub_first[v] + vec_sub_count[v]) -- several vectors
  * may name the same track -- with times scaled by vec_ratio[v], as vec_len[v] samples (ffs_raster_length) whose bit 0
  * is bit 0 of word out_dev[vec_out_word[v]].  out_dev[0, out_words) is zeroed first.  Same results, bit for bit, as
- * one ffs_rasterize_subtitles_bits call per vector (the arithmetic is IEEE fp64 on both sides).  The call returns
- * after the tables have been read (one stream synchronisation); the rasterisation itself is enqueued on hip_stream. */
+ * one ffs_rasterize_subtitles_bits call per vector (the arithmetic is IEEE fp64 on both sides).  The host arrays may
+ * be freed after return (they are staged in pinned memory; the caller's stream is NOT synchronised); the upload and
+ * the rasterisation are enqueued on hip_stream. */
 int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
                              int64_t n_subs_total, const int64_t* vec_sub_first, const int64_t* vec_sub_count,
                              const double* vec_ratio, const int64_t* vec_out_word, const int64_t* vec_len, int64_t n_vec,

@@ -6,10 +6,10 @@ FFTAligner(None) and FFTAligner(6000)).
 
 Runs only in the build container (needs /root/reference).  The JSON it writes is committed; the
 `-m gpu` test tests/test_gpu_headline.py and bench.py compare the timed batch with it.  The same
-run is timed and written to profiles/r02_cpu_reference_baseline.json (the unmodified
+run is timed and written to profiles/r04_cpu_reference_baseline.json (the unmodified
 reference, one process and a pool, on this container's cores).
 
-    python tests/golden/make_headline_golden.py [n_pairs=128] [procs=8]
+    python tests/golden/make_headline_golden.py [n_pairs=1024] [procs=8]
 """
 import json
 import logging
@@ -133,7 +133,7 @@ def main():
                  "best_solves_per_s": procs / float(np.mean([r["seconds_seven_ratio"] for r in res])), "cores": procs},
         "single_ratio_none_mean_s": float(np.mean([r["seconds_single"] for r in res])),
     }
-    with open(os.path.join(ROOT, "profiles", "r02_cpu_reference_baseline.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r04_cpu_reference_baseline.json"), "w") as f:
         json.dump(base, f, indent=1)
     print(json.dumps(base))
 

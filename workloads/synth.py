@@ -98,6 +98,22 @@ def pair_float_arrays(spec: PairSpec):
     return ref.astype(float), [c.astype(float) * a for c, a in zip(cands, spec.cand_amp)]
 
 
+def fused_reference(spec: PairSpec, w_silero: float = 0.6, w_webrtc: float = 0.4) -> np.ndarray:
+    """The reference of ``spec`` as the `weighted` fused detector would hand it over
+    (ffsubsync/speech_transformers.py:290-293: 0.6 * silero + 0.4 * webrtc of two 0/1 label vectors): the spec's own
+    speech runs stand in for one detector, the same runs with every edge moved by up to +-15 frames and a tenth of them
+    missed for the other -- two detectors that mostly agree.  float64, levels {0, 0.4, 0.6, 1}; seeded by the spec."""
+    rng = np.random.RandomState(spec.seed + 77001)
+    n = spec.ref_starts.size
+    keep = rng.rand(n) > 0.1
+    js, je = rng.randint(-15, 16, n), rng.randint(-15, 16, n)
+    a = rasterize(spec.ref_len, spec.ref_starts, spec.ref_ends).astype(np.float64)
+    st, en = (spec.ref_starts + js)[keep], (spec.ref_ends + je)[keep]
+    ok = en > st
+    b = rasterize(spec.ref_len, st[ok], en[ok]).astype(np.float64)
+    return w_silero * a + w_webrtc * b
+
+
 def simple_pair(n_ref: int, n_sub: int, offset: int, seed: int = 0, density: float = 0.4, flip: float = 0.05):
     """A random 0/1 reference and a noisy copy of a window of it, so that the best offset is
     ``offset``: sub[i] ~ ref[i + offset].  (BASELINE config 1: n=60000, offset=+3720.)"""
@@ -183,3 +199,29 @@ def build_device_batch(specs: Sequence[PairSpec], device=None, chunk_pairs: int 
     if packed:
         return DeviceBatch(data, offs // 8, lens, lo, hi, _native.FFS_DTYPE_U1)
     return DeviceBatch(data, offs, lens, lo, hi, _native.FFS_DTYPE_U8)
+
+
+def build_fused_batch(specs: Sequence[PairSpec], device=None):
+    """The specs as a mixed-type ``DeviceBatch``: candidates bit-packed (FFS_DTYPE_U1) exactly as ``build_device_batch``
+    lays them out, references the four-level float64 vectors of ``fused_reference`` (FFS_DTYPE_F64) appended to the same
+    buffer -- what a pipeline with the weighted fused VAD hands the aligner."""
+    import torch
+
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.batch import DeviceBatch
+
+    db = build_device_batch(specs, device=device, packed=True)
+    refs = [fused_reference(sp) for sp in specs]
+    sizes = np.array([(r.size * 8 + 63) // 64 * 64 for r in refs], dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    host = np.zeros(int(sizes.sum()), dtype=np.uint8)
+    for r, o in zip(refs, starts):
+        host[o:o + r.size * 8] = r.view(np.uint8)
+    base = (db.data.numel() + 63) // 64 * 64
+    data = torch.zeros(base + host.size, dtype=torch.uint8, device=db.data.device)
+    data[: db.data.numel()] = db.data
+    data[base:] = torch.from_numpy(host).to(db.data.device)
+    offs, lo, hi = db.offs.copy(), db.lo.copy(), db.hi.copy()
+    offs[:, 0] = base + starts
+    lo[:, 0], hi[:, 0] = 0.0, 1.0
+    return DeviceBatch(data, offs, db.lens, lo, hi, _native.FFS_DTYPE_U1, ref_dtype=_native.FFS_DTYPE_F64)
