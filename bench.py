@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--input-format", choices=("bits", "bytes"), default="bits",
                     help="bits = FFS_DTYPE_U1 (native), bytes = FFS_DTYPE_U8")
     ap.add_argument("--cpu-pairs", type=int, default=16, help="pairs timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--algorithm", choices=("auto", "fft", "runs"), default="auto",
+                    help="auto (library default): run-boundary path for bit-packed vectors with short boundary lists, "
+                         "transforms otherwise; fft: transforms only; runs: run-boundary path without the budget")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-vad", action="store_true", help="skip the VAD frame-energy sweep figures")
     ap.add_argument("--e2e-files", type=int, default=32,
@@ -546,11 +549,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n_fft, steps, warmup, max_offset=6000, the_db=None, cands=n_cand):
+    info_now = {}  # what the most recent timed() call went through (run-boundary statistics of its plan)
+
+    def timed(n_fft, steps, warmup, max_offset=6000, the_db=None, cands=n_cand, algorithm=None):
         """W untimed + K timed passes over this rank's pairs with a plan of length n_fft."""
         the_db = db if the_db is None else the_db
         aligner = batch.BatchAligner(n_fft, cands, max_offset_samples=max_offset, pairs_in_flight=args.pairs_in_flight,
-                                     streams=args.streams)
+                                     streams=args.streams, algorithm=algorithm or args.algorithm)
 
         def step():
             aligner.solve_async(the_db, 0, P, cand_out, pair_out)
@@ -581,6 +586,17 @@ def main():
             elapsed = float(t.item())
         seg = (n_fft % 3 == 0 and n_fft // 3 >= 65536 and os.environ.get("FFS_DISABLE_SEGMENTED") != "1"
                and max_offset is not None)
+        calls, chunks, fft_chunks = aligner.plan.runs_stats()
+        info_now.clear()
+        info_now.update({
+            "algorithm": algorithm or args.algorithm,
+            "path": ("transforms" if calls == 0 or fft_chunks == chunks else
+                     "run boundaries" if fft_chunks == 0 else
+                     "run boundaries, %d of %d sub-batches through the transforms" % (fft_chunks, chunks)),
+            "boundaries_last_call": aligner.plan.runs_boundaries_last_call() if calls else 0,
+            "vectors_bytes_per_pair": float(np.mean(the_db.lens.sum(axis=1))) / 8.0,
+            "pairs_per_call": P, "cands": cands,
+        })
         aligner.close()
         return elapsed, ktimes, seg
 
@@ -609,12 +625,23 @@ def main():
 
     def kernel_table(ktimes, steps, n_fft, seg, cands=n_cand, ref_bytes_per_sample=None):
         mm = must_move(n_fft, seg, cands, ref_bytes_per_sample)
+        last_info = dict(info_now)  # of the timed() call these kernel times belong to
         per_kernel = {}
         for k, (ms, n) in ktimes.items():
             if n == 0:
                 continue
             pairs_per_launch = P * steps / n
             entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms, "us_per_pair": 1e3 * ms / (P * steps)}
+            if k == "runs_extract" and last_info.get("boundaries_last_call"):
+                # reads every bit-packed vector once, writes two 4-byte entries per boundary (+ the sentinel of each list)
+                per_pair = (last_info["vectors_bytes_per_pair"]
+                            + 8.0 * last_info["boundaries_last_call"] / last_info["pairs_per_call"] + 8.0 * (1 + cands))
+                entry["must_move_bytes_per_launch"] = per_pair * pairs_per_launch
+                entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+                entry["frac_of_8TBps"] = entry["must_move_GBps"] * 1e9 / HBM_PEAK
+                entry["boundaries_per_vector"] = last_info["boundaries_last_call"] / (last_info["pairs_per_call"] * (1.0 + cands))
+            if k == "runs_corr":
+                entry["bound"] = "LDS atomics (one ds_add_u32 per boundary coincidence inside the lag window) -- not an HBM kernel"
             if k in mm:
                 entry["must_move_bytes_per_launch"] = mm[k] * pairs_per_launch
                 entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
@@ -625,6 +652,8 @@ def main():
         return per_kernel
 
     elapsed, ktimes, seg_mode = timed(n_dev, args.steps, args.warmup)
+    head_info = dict(info_now)
+    by_runs = head_info["path"] != "transforms"
 
     # correctness of what was timed: every pair the reference-generated goldens cover (bench seeds 0..255,
     # tests/golden/headline_golden.json = the UNMODIFIED reference's (ratio, offset, score)), plus the
@@ -667,7 +696,9 @@ def main():
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
-        "dtype": "f32",
+        # the arithmetic the timed path computes in: exact int32 counts (run-boundary path; fp64 only for the final score
+        # expression) or fp32 transforms that nominate + integer re-evaluation (transform path)
+        "dtype": "i32" if by_runs else "f32",
         "data": "synthetic",
         "config": {
             "workload": "configs[2]: %d x %.0f s@100 Hz pairs %s (%d batches of 1024), MaxScoreAligner over 7 framerate "
@@ -680,8 +711,15 @@ def main():
             "streams": args.streams,
             "input_format": "bit-packed 0/1 vectors (FFS_DTYPE_U1) resident in HBM" if db.dtype == _native.FFS_DTYPE_U1
                             else "0/1 bytes (FFS_DTYPE_U8) resident in HBM",
-            "arithmetic": "fp32 transforms nominate lags; integer (popcount) re-evaluation of the winners: offsets and "
-                          "scores are exact",
+            "algorithm": head_info["algorithm"],
+            "path": head_info["path"],
+            "arithmetic": ("run-boundary correlation (csrc/ffs_runs.h): the exact integer correlation of the run-length-coded "
+                           "vectors at EVERY lag of the window (boundary lists -> sparse second difference -> two prefix sums), "
+                           "argmax over exact scores; chosen per sub-batch by the library (FFS_ALGO_AUTO) because the boundary "
+                           "lists are short -- the batched-FFT path on the same pairs is the `fft_path` entry"
+                           if by_runs else
+                           "fp32 transforms nominate lags; integer (popcount) re-evaluation of the winners: offsets and "
+                           "scores are exact"),
             "parallelism": ("pairs sharded by rank, %s of 24 B/pair results" % gather_impl) if use_dist else "single GPU",
             "gather_impl": gather_impl,
             # 0 = the library's own collective (ffs_gather_results), 1 = torch.distributed's all_gather_into_tensor was used
@@ -691,7 +729,7 @@ def main():
             "devices_used": len({(x[2], x[1]) for x in ranks_seen}) if use_dist else 1,
         },
         "offset_match": {"pairs_matching_reference_golden": "%d/%d" % (g_ok, g_total),
-                         "golden": "tests/golden/headline_golden.json (unmodified reference, bench seeds 0..255): winning index and "
+                         "golden": "tests/golden/headline_golden.json (unmodified reference, bench seeds 0..1023): winning index and "
                                    "offset bit-identical, all 7 per-candidate scores within 1e-5, per-candidate offsets "
                                    "bit-identical wherever the reference's own top-2 gap exceeds 0.5 (exact ties on the "
                                    "plateaus of wrong-ratio candidates are decided by its fp64 rounding noise)",
@@ -706,21 +744,21 @@ def main():
         },
     }
 
-    if profile and rank == 0:
-        per_kernel = kernel_table(ktimes, args.steps, n_dev, seg_mode)
-        dom = max((k for k in per_kernel if k in share), key=lambda k: per_kernel[k]["total_ms"])
-        pairs_per_launch = P * args.steps / per_kernel[dom]["launches"]
+    def roofline_of(per_kernel, pairs, steps, n_fft, seg_mode, cands=n_cand):
+        """`roofline` object for the kernel that takes the most time among those that move bytes through HBM."""
+        hbm_kernels = [k for k in per_kernel if "must_move_GBps" in per_kernel[k]]
+        dom = max(hbm_kernels, key=lambda k: per_kernel[k]["total_ms"])
+        pairs_per_launch = pairs * steps / per_kernel[dom]["launches"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_per_pair.json")
         if os.path.exists(tpath):  # PMC-measured HBM bytes (profiles/run_pmc.sh), keyed by device length
-            tj = json.load(open(tpath)).get(str(n_dev), {})
+            tj = json.load(open(tpath)).get(str(n_fft), {})
             if dom in tj:
                 traffic = tj[dom] * pairs_per_launch
-        result["kernels"] = per_kernel
         mm_launch = per_kernel[dom]["must_move_bytes_per_launch"]
-        result["roofline"] = {
-            "kernel": {"pass_a": "k_pass_a", "pass_c": "k_pass_c_pruned",
-                       "mid": ("k_mid_seg_one" if (n_cand + 1) // 2 <= 4 else "k_mid_seg_pipe") if seg_mode else "k_mid"}[dom],
+        out = {
+            "kernel": {"pass_a": "k_pass_a", "pass_c": "k_pass_c_pruned", "runs_extract": "k_runs_extract",
+                       "mid": ("k_mid_seg_one" if (cands + 1) // 2 <= 4 else "k_mid_seg_pipe") if seg_mode else "k_mid"}[dom],
             "bound": "hbm",
             "achieved": per_kernel[dom]["must_move_GBps"],
             "peak": HBM_PEAK / 1e9,
@@ -731,11 +769,25 @@ def main():
             "bytes_per_launch": mm_launch,
             "avg_launch_ms": per_kernel[dom]["avg_ms"],
             "frac_of_copy_ceiling": per_kernel[dom]["must_move_GBps"] * 1e9 / HBM_COPY_CEILING,
-            "note": "achieved = bytes this kernel HAS to move per launch (DESIGN.md section 5: every stored row read "
-                    "once, every result row written once) / its average launch duration from HIP events on the "
-                    "launch stream; traffic = PMC-measured HBM bytes per launch (profiles/traffic_per_pair.json); "
-                    "wasted = traffic / must-move",
+            "share_of_kernel_time": per_kernel[dom]["total_ms"] / sum(v["total_ms"] for v in per_kernel.values()),
         }
+        if dom == "runs_extract":
+            out["note"] = ("achieved = bytes k_runs_extract HAS to move per launch (every bit-packed vector read once, 8 bytes "
+                           "written per run boundary; DESIGN.md section 5) / its average launch duration from HIP events on the "
+                           "launch stream; traffic = PMC-measured HBM bytes per launch (profiles/traffic_per_pair.json).  The "
+                           "other kernel of the path, k_runs_corr, works out of LDS (boundary lists of a few KB per vector, one "
+                           "ds_add_u32 per boundary coincidence) and moves no comparable HBM volume: see kernels.runs_corr")
+        else:
+            out["note"] = ("achieved = bytes this kernel HAS to move per launch (DESIGN.md section 5: every stored row read "
+                           "once, every result row written once) / its average launch duration from HIP events on the "
+                           "launch stream; traffic = PMC-measured HBM bytes per launch (profiles/traffic_per_pair.json); "
+                           "wasted = traffic / must-move")
+        return out
+
+    if profile and rank == 0:
+        per_kernel = kernel_table(ktimes, args.steps, n_dev, seg_mode)
+        result["kernels"] = per_kernel
+        result["roofline"] = roofline_of(per_kernel, P, args.steps, n_dev, seg_mode)
 
     # BASELINE configs[3] in the same invocation: the SAME 1024 pairs split over the ranks, every step = this rank's share
     # (contiguous block, batch.shard_bounds) + the all-gather of the 24-byte records.  On one GPU it is the proxy the
@@ -752,13 +804,35 @@ def main():
             result["strong_scaling_proxy"] = {"error": repr(exc)[:300]}
 
     secondary = rank == 0 and world == 1 and not args.skip_secondary
+    if secondary and by_runs:
+        # The SAME pairs through the batched-FFT path (FFS_ALGO_FFT: what rounds 1-3 timed as the headline, and what the
+        # library still runs for float / byte inputs and for vectors whose boundary lists are long): the north star's
+        # "batched 1-D real FFT + complex multiply + inverse FFT + argmax" kernels with their own roofline.
+        st_x = max(2, args.steps // 4)
+        el_x, kt_x, seg_x = timed(n_dev, st_x, 1, algorithm="fft")
+        pres_x = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
+        cres_x = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[: P * n_cand].reshape(P, n_cand)
+        result["fft_path"] = {
+            "what": "same %d pairs, FFS_ALGO_FFT (window-shortened block-segmented transforms, n_fft_device %d): fp32 "
+                    "transforms nominate, integer re-evaluation decides" % (P, n_dev),
+            "value": P * st_x / el_x, "unit": "7-ratio solves/s", "ms_per_step": 1e3 * el_x / st_x, "dtype": "f32",
+            "identical_pair_results": bool(np.array_equal(pres_x, pres)),
+            "identical_candidate_results": bool(all(np.array_equal(cres_x[f], cres[f]) for f in ("score", "offset", "flags"))),
+            "normaliser_frac_of_8TBps": (P * st_x / el_x) * 168 * n_ref / HBM_PEAK,
+            "max_abs_fp32_error_at_winning_lags": float(np.abs(cres_x["score_f32"].astype(np.float64) - cres_x["score"]).max()),
+        }
+        if profile:
+            pk_x = kernel_table(kt_x, st_x, n_dev, seg_x)
+            result["fft_path"]["kernels"] = pk_x
+            result["fft_path"]["roofline"] = roofline_of(pk_x, P, st_x, n_dev, seg_x)
     if secondary and not args.reference_length and n_dev != n_ref:
         # the same pairs with the reference's own transform length N = 2^21 (single transform), for the record
         st2 = max(2, args.steps // 4)
-        el2, kt2, seg2 = timed(n_ref, st2, 1)
+        el2, kt2, seg2 = timed(n_ref, st2, 1, algorithm="fft")
         pres2 = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
         result["reference_length"] = {
             "n_fft_device": n_ref,
+            "path": "transforms (FFS_ALGO_FFT), single transform of the reference's own length",
             "value": P * st2 / el2,
             "ms_per_step": 1e3 * el2 / st2,
             "identical_pair_results": bool(np.array_equal(pres2, pres)),
@@ -777,16 +851,26 @@ def main():
         for label, mo, key in (("max_offset_6000", 6000, "single_6000"), ("max_offset_none", None, "single_none")):
             n1 = sdb.required_fft_length(mo)
             st1 = max(2, args.steps // 4)
-            el, kt1, seg1 = timed(n1, st1, 1, max_offset=mo, the_db=sdb, cands=1)
+            el_auto, path_auto = None, None
+            if args.algorithm != "fft":  # what the library picks on its own, then the transform kernels for the table
+                el_auto, _, _ = timed(n1, st1, 1, max_offset=mo, the_db=sdb, cands=1)
+                path_auto = info_now["path"]
+                c_auto = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:P].copy()
+            el, kt1, seg1 = timed(n1, st1, 1, max_offset=mo, the_db=sdb, cands=1, algorithm="fft")
             c1 = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:P]
             hits = [(int(c1[i]["offset"]) == golden[s][key][1]
                      and abs(float(c1[i]["score"]) - float(golden[s][key][0])) <= 1e-5 * abs(float(golden[s][key][0])))
                     for i, s in enumerate(seeds) if s in golden]
             single[label] = {
                 "n_fft_device": int(n1),
-                "solves_per_s": P * st1 / el,
+                "solves_per_s": P * st1 / (el_auto or el),
+                "path": path_auto or "transforms",
+                "transforms_solves_per_s": P * st1 / el,
                 "pairs_matching_reference_golden": "%d/%d" % (sum(hits), len(hits)),
             }
+            if el_auto is not None:
+                single[label]["identical_results_on_both_paths"] = bool(
+                    all(np.array_equal(c_auto[f], c1[f]) for f in ("score", "offset", "flags")))
             if profile:
                 single[label]["kernels"] = {
                     k: {kk: v[kk] for kk in ("us_per_pair", "must_move_GBps", "frac_of_8TBps") if kk in v}
@@ -801,7 +885,8 @@ def main():
         pres_w = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
         result["windowless"] = {
             "what": "max_offset_samples=None (aligners.py:25-29 default): same pairs, every lag searched",
-            "n_fft_device": int(n_w), "value": P * st_w / el_w, "unit": "7-ratio solves/s", "ms_per_step": 1e3 * el_w / st_w,
+            "n_fft_device": int(n_w), "path": info_now["path"], "value": P * st_w / el_w, "unit": "7-ratio solves/s",
+            "ms_per_step": 1e3 * el_w / st_w,
             "pairs_matching_ground_truth": int(sum(
                 int(pres_w[i]["best_cand"]) == sp.true_ratio_index and abs(int(pres_w[i]["offset"]) - sp.true_offset_samples) <= 30
                 for i, sp in enumerate(specs))),
@@ -811,6 +896,41 @@ def main():
             result["windowless"]["kernels"] = {
                 k: {kk: v[kk] for kk in ("avg_ms", "us_per_pair", "must_move_GBps", "frac_of_8TBps") if kk in v}
                 for k, v in kernel_table(kt_w, st_w, n_w, seg_w).items()}
+
+        # How the automatic choice moves with the number of runs per vector: the benchmark generator with gaps, runs and
+        # jitter scaled down (1/scale times as many runs: from subtitle-like activity to a flickering frame-level
+        # detector), 256 pairs each, library default (auto) next to the forced transform path.
+        if args.algorithm == "auto" and args.duration == 7200.0:
+            keep_db, keep_P, keep_specs = db, P, specs
+            sweep = []
+            try:
+                for scale in (1.0, 0.5, 0.25, 0.125, 0.0625, 0.03125):
+                    P = 256
+                    specs = [synth.make_pair_spec(7000 + i, duration_s=args.duration, run_scale=scale) for i in range(P)]
+                    db = synth.build_device_batch(specs)
+                    n_s = db.required_fft_length(6000)
+                    el_a, kt_a, _ = timed(n_s, 3, 1)
+                    path_a = info_now["path"]
+                    bnd = info_now["boundaries_last_call"] / (P * 8.0)
+                    pa_ = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P].copy()
+                    el_f, _, _ = timed(n_s, 3, 1, algorithm="fft")
+                    pf_ = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
+                    sweep.append({
+                        "run_scale": scale, "boundaries_per_vector": bnd, "auto_solves_per_s": P * 3 / el_a, "auto_path": path_a,
+                        "transforms_solves_per_s": P * 3 / el_f, "identical_pair_results": bool(np.array_equal(pa_, pf_)),
+                        "pairs_matching_ground_truth": int(sum(
+                            int(pa_[i]["best_cand"]) == sp.true_ratio_index
+                            and abs(int(pa_[i]["offset"]) - sp.true_offset_samples) <= 30 for i, sp in enumerate(specs))),
+                    })
+                result["boundary_density"] = {
+                    "what": "256 pairs x 2 h x 7 ratios, max_offset_samples=6000; workloads.synth.make_pair_spec(run_scale): "
+                            "gaps U[0.2,8] s and runs U[0.5,6] s times run_scale.  Budget of the automatic choice: five boundary "
+                            "coincidences per point of the plan length; lists of 32 767 boundaries or more always go through "
+                            "the transforms", "sweep": sweep}
+            except Exception as exc:
+                result["boundary_density"] = {"error": repr(exc)[:300], "sweep": sweep}
+            finally:
+                db, P, specs = keep_db, keep_P, keep_specs
 
         # the same headline batch as 0/1 BYTES (FFS_DTYPE_U8), the north star's literal input format
         if db.dtype == _native.FFS_DTYPE_U1:
@@ -824,7 +944,7 @@ def main():
                 pres_b = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:nb]
                 result["byte_inputs"] = {
                     "what": "FFS_DTYPE_U8 vectors (one byte per 10 ms frame) resident in HBM, first %d pairs of the batch" % nb,
-                    "value": nb * st_b / el_b, "unit": "7-ratio solves/s",
+                    "path": info_now["path"], "value": nb * st_b / el_b, "unit": "7-ratio solves/s",
                     "identical_pair_results": bool(np.array_equal(pres_b, pres[:nb])),
                 }
                 if profile:
@@ -866,7 +986,7 @@ def main():
                 "what": "%d pairs: float64 four-level reference vectors (0.6*silero + 0.4*webrtc levels) + seven bit-packed "
                         "candidates per pair, resident in HBM; ffs_align_batch_typed (reference FFS_DTYPE_F64, candidates "
                         "FFS_DTYPE_U1); n_fft_device %d" % (nf, n_dev),
-                "value": nf * st_f / el_f, "unit": "7-ratio solves/s",
+                "path": info_now["path"], "value": nf * st_f / el_f, "unit": "7-ratio solves/s",
                 "pairs_matching_reference_golden": "%d/%d" % (f_ok, f_tot),
                 "golden": "tests/golden/float_golden.json (unmodified reference on seeds 5000..): offsets bit-identical, scores "
                           "within 1e-5",

@@ -61,12 +61,16 @@ EXPORTED_SYMBOLS = (
     "ffs_comm_create",
     "ffs_gather_results",
     "ffs_comm_destroy",
+    "ffs_plan_set_algorithm",
+    "ffs_plan_runs_stats",
     "ffs_plan_profile",
     "ffs_plan_profile_read",
     "ffs_last_error",
     "ffs_version",
 )
-KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore")
+KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore", "runs_extract", "runs_corr")
+FFS_ALGO_AUTO, FFS_ALGO_FFT, FFS_ALGO_RUNS = 0, 1, 2
+ALGORITHMS = {"auto": FFS_ALGO_AUTO, "fft": FFS_ALGO_FFT, "runs": FFS_ALGO_RUNS}
 
 
 class NativeError(RuntimeError):
@@ -176,6 +180,10 @@ def load():
         lib.ffs_gather_results.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
         lib.ffs_comm_destroy.restype = c.c_int
         lib.ffs_comm_destroy.argtypes = [c.c_void_p]
+        lib.ffs_plan_set_algorithm.restype = c.c_int
+        lib.ffs_plan_set_algorithm.argtypes = [c.c_void_p, c.c_int]
+        lib.ffs_plan_runs_stats.restype = c.c_int
+        lib.ffs_plan_runs_stats.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
         lib.ffs_plan_profile.restype = c.c_int
         lib.ffs_plan_profile.argtypes = [c.c_void_p, c.c_int]
         lib.ffs_plan_profile_read.restype = c.c_int
@@ -236,6 +244,23 @@ class Plan:
     @property
     def workspace_bytes(self) -> int:
         return int(self.lib.ffs_plan_workspace_bytes(self.handle))
+
+    def set_algorithm(self, algorithm) -> None:
+        """"auto" (default: run-boundary path for short boundary lists, transforms otherwise), "fft" (transforms only) or
+        "runs" (run-boundary path without the coincidence budget); identical results either way."""
+        check(self.lib.ffs_plan_set_algorithm(self.handle, ALGORITHMS.get(algorithm, algorithm)))
+
+    def runs_stats(self):
+        """(calls that tried the run-boundary path, their sub-batches, sub-batches that went through the transforms)."""
+        v = (ctypes.c_int64 * 4)()
+        check(self.lib.ffs_plan_runs_stats(self.handle, ctypes.byref(v, 0), ctypes.byref(v, 8), ctypes.byref(v, 16), None))
+        return int(v[0]), int(v[1]), int(v[2])
+
+    def runs_boundaries_last_call(self) -> int:
+        """Boundary-list entries of all vectors of the most recent run-boundary call."""
+        v = ctypes.c_int64()
+        check(self.lib.ffs_plan_runs_stats(self.handle, None, None, None, ctypes.byref(v)))
+        return int(v.value)
 
     def profile(self, enable: bool) -> None:
         check(self.lib.ffs_plan_profile(self.handle, 1 if enable else 0))
@@ -350,6 +375,8 @@ def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Op
     else:
         cache.order.remove(key)
     cache.order.append(key)
+    # cached plans follow FFS_ALGORITHM like new ones do (auto | fft | runs; results are identical either way)
+    plan.set_algorithm(os.environ.get("FFS_ALGORITHM", "auto"))
     # evict least recently used plans beyond the budget (never the one just asked for)
     total = sum(p.workspace_bytes for p in cache.plans.values())
     while total > PLAN_CACHE_BYTES and len(cache.order) > 1:

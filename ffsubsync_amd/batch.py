@@ -153,7 +153,8 @@ class BatchAligner:
     """MaxScoreAligner(FFTAligner, None, sample_rate, max_offset_seconds) over a DeviceBatch."""
 
     def __init__(self, n_fft: int, n_cand: int, max_offset_samples: Optional[int] = 6000,
-                 pairs_in_flight: int = 4, device: Optional[int] = None, streams: int = 1) -> None:
+                 pairs_in_flight: int = 4, device: Optional[int] = None, streams: int = 1,
+                 algorithm: Optional[str] = None) -> None:
         """``streams`` > 1: the pairs of a call are split into that many contiguous parts, each solved by its own
         plan (own workspace, ``pairs_in_flight`` shared between them) on its own HIP stream -- concurrent sub-batches
         fill each other's launch tails (+2-3 % solves/s at two streams, profiles/overlap_experiment.py).  The caller's
@@ -163,6 +164,9 @@ class BatchAligner:
         per_plan = max(1, (pairs_in_flight + self.streams - 1) // self.streams)
         self.plans = [_native.Plan(n_fft, per_plan, max(n_cand, 1), device) for _ in range(self.streams)]
         self.plan = self.plans[0]
+        if algorithm is not None:  # "auto" | "fft" | "runs" (Plan.set_algorithm); None: the library default / FFS_ALGORITHM
+            for p in self.plans:
+                p.set_algorithm(algorithm)
         self._side = [self.torch.cuda.Stream(device=device) for _ in range(self.streams)] if self.streams > 1 else []
         self.n_cand = n_cand
         self.max_offset_samples = max_offset_samples

@@ -2123,19 +2123,29 @@ __global__ __launch_bounds__(256) void k_rescore(const CandDesc* __restrict__ ca
     }
 }
 
+// Exact correlation of the mapped two-level vectors at lag d from the three counts (n11 = samples where both are at
+// their upper level, n1x / nx1 = the candidate's / the reference's upper-level samples inside the overlap).  ONE fixed
+// sequence of fp64 operations (explicit fused multiply-adds): the transform path's nominees and the run-boundary path's
+// every lag are scored by exactly this arithmetic, so the two paths agree bit for bit.
+FFS_DEV double two_level_score(const CandDesc& cd, int n11, int n1x, int nx1, int d) {
+    const int i0 = d < 0 ? -d : 0;
+    const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
+    const int ov = i1 > i0 ? (i1 - i0) : 0;
+    const int n10 = n1x - n11, n01 = nx1 - n11;
+    const int n00 = ov - n11 - n10 - n01;
+    double r = (double)n00 * (cd.s0 * cd.r0);
+    r = __builtin_fma((double)n01, cd.s0 * cd.r1, r);
+    r = __builtin_fma((double)n10, cd.s1 * cd.r0, r);
+    return __builtin_fma((double)n11, cd.s1 * cd.r1, r);
+}
+
 FFS_DEV double exact_score(const CandDesc& cd, const RescoreAcc& a, int d, int dt) {
     if (dt == 1 || dt == 3 || dt == 4) {
         double sum = 0.0;
         for (int i = 0; i < RSEG; ++i) sum += a.part[i];
         return sum;
     }
-    const int i0 = d < 0 ? -d : 0;
-    const int i1 = (cd.R - d) < cd.S ? (cd.R - d) : cd.S;
-    const long long ov = i1 > i0 ? (long long)(i1 - i0) : 0;
-    const long long n11 = a.n11, n10 = (long long)a.n1x - n11, n01 = (long long)a.nx1 - n11;
-    const long long n00 = ov - n11 - n10 - n01;
-    return (double)n11 * (cd.s1 * cd.r1) + (double)n10 * (cd.s1 * cd.r0) + (double)n01 * (cd.s0 * cd.r1) +
-           (double)n00 * (cd.s0 * cd.r0);
+    return two_level_score(cd, (int)a.n11, (int)a.n1x, (int)a.nx1, d);
 }
 
 // Pool re-evaluation: one block per entry (grid-stride), the whole overlap in one block.

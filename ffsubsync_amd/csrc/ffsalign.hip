@@ -16,12 +16,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <mutex>
 #include <vector>
 
 #include "../../include/ffsubsync_amd.h"
 #include "ffs_kernels.h"
+#include "ffs_runs.h"
 
 using namespace ffsa;
 
@@ -198,6 +200,24 @@ struct ffs_plan {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     int64_t workspace_bytes = 0;
+    // Run-boundary path (ffs_runs.h): FFS_ALGO_AUTO sends every sub-batch of bit-packed two-level vectors whose boundary
+    // lists are short enough through it (one event wait per call to read the list lengths), the others through the
+    // transforms; FFS_ALGO_FFT never uses it; FFS_ALGO_RUNS ignores the coincidence budget (truncated lists still go
+    // through the transforms).  Buffers grown on demand.
+    int algo = FFS_ALGO_AUTO;
+    long long runs_budget = 0;          // boundary coincidences per candidate above which the transforms are cheaper (ffs_plan_create)
+    int* runs_q = nullptr;              // [vectors][RUNS_CAP] boundary positions
+    int* runs_c = nullptr;              // [vectors][RUNS_CAP] ones in front of each boundary
+    int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
+    int2* runs_n_host = nullptr;        // pinned copy of runs_n
+    size_t runs_vecs = 0;               // vectors the four buffers above have room for
+    RunsBest* runs_best = nullptr;      // [candidates][tiles] (windows wider than one tile)
+    size_t runs_best_n = 0;
+    hipEvent_t runs_ev = nullptr;
+    int64_t runs_calls = 0, runs_fft_chunks = 0, runs_chunks = 0, runs_last_boundaries = 0;  // statistics (ffs_plan_runs_stats)
+    // FFS_HOST_TIMING=1: host nanoseconds of the run-boundary calls by section, printed when the plan is destroyed
+    bool host_timing = false;
+    double ht_vec = 0, ht_cand = 0, ht_wait = 0, ht_decide = 0, ht_total = 0;
     // kernels whose dynamic-LDS limit has been raised on this plan's device (the attribute is per device)
     mutable std::vector<const void*> lds_configured;
     // optional per-kernel event timing
@@ -238,6 +258,49 @@ int ensure_lds(const ffs_plan* p, const void* fn, size_t bytes) {
         if (f == fn) return FFS_OK;
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     p->lds_configured.push_back(fn);
+    return FFS_OK;
+}
+
+// Transform workspace of a plan (and of its block-segmented sub-plan), allocated on first use.
+int ensure_workspace(ffs_plan* p) {
+    if (p->direct_only || p->work) return FFS_OK;
+    const size_t work_bytes = (size_t)p->pairs_in_flight * p->max_slots * p->N * sizeof(cf);
+    HIP_TRY(hipMalloc((void**)&p->work, work_bytes));
+    const size_t bn_bytes = (size_t)p->pairs_in_flight * (p->max_slots - 1) * 2 * (p->N2 / p->C) * sizeof(BlockNom);
+    HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
+    HIP_TRY(hipMalloc((void**)&p->xlist, (1 + (size_t)p->pairs_in_flight * p->max_cand) * sizeof(int)));
+    HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
+    if (p->seg) return ensure_workspace(p->seg);
+    return FFS_OK;
+}
+
+// Boundary-list buffers of the run-boundary path for `n_vec` vectors (and `n_best` tile records).
+int ensure_runs(ffs_plan* p, size_t n_vec, size_t n_best) {
+    if (!p->runs_ev) HIP_TRY(hipEventCreateWithFlags(&p->runs_ev, hipEventDisableTiming));
+    if (n_vec > p->runs_vecs) {
+        if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));  // the previous call may still be reading them
+        (void)hipFree(p->runs_q);
+        (void)hipFree(p->runs_c);
+        (void)hipFree(p->runs_n);
+        if (p->runs_n_host) (void)hipHostFree(p->runs_n_host);
+        p->runs_q = p->runs_c = nullptr;
+        p->runs_n = p->runs_n_host = nullptr;
+        p->runs_vecs = 0;
+        const size_t cap = n_vec + n_vec / 4 + 64;
+        HIP_TRY(hipMalloc((void**)&p->runs_q, cap * RUNS_CAP * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&p->runs_c, cap * RUNS_CAP * sizeof(int)));
+        HIP_TRY(hipMalloc((void**)&p->runs_n, cap * sizeof(int2)));
+        HIP_TRY(hipHostMalloc((void**)&p->runs_n_host, cap * sizeof(int2), hipHostMallocDefault));
+        p->runs_vecs = cap;
+    }
+    if (n_best > p->runs_best_n) {
+        if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+        (void)hipFree(p->runs_best);
+        p->runs_best = nullptr;
+        p->runs_best_n = 0;
+        HIP_TRY(hipMalloc((void**)&p->runs_best, n_best * sizeof(RunsBest)));
+        p->runs_best_n = n_best;
+    }
     return FFS_OK;
 }
 
@@ -714,18 +777,14 @@ int64_t next_pow2(int64_t x) {
     return n;
 }
 
-// Fill the candidate descriptor for (ref, sub); returns a negative code on error.
-int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd, int ref_dt,
-              int cand_dt) {
+// Fill the candidate descriptor for (ref, sub); returns a negative code on error.  What only the transform path needs
+// (the plan-length check and the fp32 tie margin) is added by finish_cand_for_transforms.
+int fill_cand(const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd, int ref_dt, int cand_dt) {
     const int64_t R = ref.len, S = sub.len;
     if (R <= 0 || S <= 0)
         return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
                     (long long)R, (long long)S);
     const int64_t n_ref = ffs_fft_length(R, S);
-    const int64_t n_need = ffs_plan_length(R, S, max_off);
-    if (n_need > p->N)
-        return fail(FFS_E_TOO_LONG, "R=%lld S=%lld needs transform length %lld > plan length %lld", (long long)R,
-                    (long long)S, (long long)n_need, (long long)p->N);
     memset(cd, 0, sizeof *cd);
     cd->s = sub.ptr;
     cd->r = ref.ptr;
@@ -751,6 +810,15 @@ int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t
     cd->s1 = mapped(sub.hi);
     cd->r0 = mapped(ref.lo);
     cd->r1 = mapped(ref.hi);
+    return FFS_OK;
+}
+
+int finish_cand_for_transforms(const ffs_plan* p, int64_t max_off, CandDesc* cd) {
+    const int64_t R = cd->R, S = cd->S;
+    const int64_t n_need = ffs_plan_length(R, S, max_off);
+    if (n_need > p->N)
+        return fail(FFS_E_TOO_LONG, "R=%lld S=%lld needs transform length %lld > plan length %lld", (long long)R,
+                    (long long)S, (long long)n_need, (long long)p->N);
     const double as = fmax(fabs(cd->s0), fabs(cd->s1)), ar = fmax(fabs(cd->r0), fabs(cd->r1));
     const double lg = (double)ilog2(p->N > 2 ? p->N : 2);
     // measured max fp32 error of the pipeline: ~0.02 (activity density 0.5) to ~0.2 (density 0.2) of
@@ -784,10 +852,15 @@ void fill_xform(XformDesc* x, const VecView* a, const VecView* b, const void* sa
 extern "C" {
 
 const char* ffs_last_error(void) { return g_err.c_str(); }
-int ffs_version(void) { return 200; }
+int ffs_version(void) { return 300; }
 
 int64_t ffs_fft_length(int64_t ref_len, int64_t sub_len) {
     if (ref_len <= 0 || sub_len <= 0) return 0;
+    // Between powers of two the reference's float expression (below) and the integer ceil(log2) agree -- log2 of
+    // 2^k +- 1 differs from k by more than 1e-7 relative up to 2^24, a thousand times the rounding error of the quotient --
+    // so only exact powers of two (where log(x)/log(2) can land a hair above the integer) take the float path.
+    const int64_t x = ref_len + sub_len;
+    if ((x & (x - 1)) != 0 && x < (int64_t(1) << 40)) return int64_t(1) << (64 - __builtin_clzll((unsigned long long)x));
     // aligners.py:67-68: int(2 ** math.ceil(math.log(R + S, 2))) -- math.log(x, 2) is
     // log(x)/log(2) in doubles, which is not exact at every power of two; keep the same quirk.
     const double bits = log((double)(ref_len + sub_len)) / log(2.0);
@@ -812,7 +885,7 @@ int64_t ffs_plan_length(int64_t ref_len, int64_t sub_len, int64_t max_offset_sam
     int64_t n = next_pow2(need);
     // three quarters of that is enough for many inputs (a 2 h pair at 100 Hz needs 726 001 points:
     // 3 * 2^18 = 786 432 instead of 2^20), and the column passes handle one factor of three
-    const char* e = getenv("FFS_DISABLE_RADIX3");
+    const char* e = getenv("FFS_DISABLE_RADIX3");  // (read per call: only the transform path asks for plan lengths)
     if (!(e && e[0] == '1') && n / 4 * 3 >= need && radix3_length(n / 4 * 3)) n = n / 4 * 3;
     return n < n_ref ? n : n_ref;
 }
@@ -850,6 +923,16 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->allow_pruned = !on("FFS_DISABLE_PRUNED_PASS_C");
         p->allow_seg = !on("FFS_DISABLE_SEGMENTED");
         p->allow_half_last = !on("FFS_DISABLE_HALF_LAST");
+        if (const char* ea = getenv("FFS_ALGORITHM")) {  // auto (default) | fft | runs
+            if (!strcmp(ea, "fft")) p->algo = FFS_ALGO_FFT;
+            else if (!strcmp(ea, "runs")) p->algo = FFS_ALGO_RUNS;
+        }
+        // Measured break-even (profiles/r04_runs_experiments.json): k_runs_corr spends ~1.2e-4 us*CU per boundary
+        // coincidence, the transform pipeline 6-9e-4 us*CU per point of the plan length and candidate -> five
+        // coincidences per transform point (3.9 M for the window-shortened 2 h plan, 7.9 M for the windowless one).
+        p->runs_budget = 5 * n_fft;
+        if (const char* eb = getenv("FFS_RUNS_BUDGET")) p->runs_budget = atoll(eb);
+        if (const char* et = getenv("FFS_HOST_TIMING")) p->host_timing = et[0] == '1';
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
 #ifdef FFS_LAB
@@ -934,14 +1017,11 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         for (int k = 0; k < N1; ++k) t[k] = wn(N1, k);
         if ((rc = upload(&p->twn1, t, &p->workspace_bytes))) return rc;
     }
-    const size_t work_bytes = (size_t)pairs_in_flight * p->max_slots * N * sizeof(cf);
-    HIP_TRY(hipMalloc((void**)&p->work, work_bytes));
-    p->workspace_bytes += (int64_t)work_bytes;
-    const size_t bn_bytes = (size_t)pairs_in_flight * (p->max_slots - 1) * 2 * (N2 / p->C) * sizeof(BlockNom);
-    HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
-    p->workspace_bytes += (int64_t)bn_bytes;
-    HIP_TRY(hipMalloc((void**)&p->xlist, (1 + (size_t)pairs_in_flight * max_cand) * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
+    // The transform workspace ([pairs_in_flight][max_slots][N] complex fp32 -- 15 GiB for 512 seven-ratio 2 h pairs --,
+    // block-nominee records, the overflow pool) is allocated by the first call that runs the transforms
+    // (ensure_workspace): calls served by the run-boundary path never touch it.  workspace_bytes counts it from the start.
+    p->workspace_bytes += (int64_t)((size_t)pairs_in_flight * p->max_slots * N * sizeof(cf));
+    p->workspace_bytes += (int64_t)((size_t)pairs_in_flight * (p->max_slots - 1) * 2 * (N2 / p->C) * sizeof(BlockNom));
     p->workspace_bytes += (int64_t)kPoolCapacity * sizeof(PoolEntry);
     if (r3 && p->allow_seg && p->N2 == 4096 && n_fft / 3 >= 65536) {
         if ((rc = ffs_plan_create(device, n_fft / 3, pairs_in_flight * kSegBlocks, max_cand, &p->seg))) return rc;
@@ -954,6 +1034,11 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
 
 int ffs_plan_destroy(ffs_plan* p) {
     if (!p) return FFS_OK;
+    if (p->host_timing && p->runs_calls)
+        fprintf(stderr, "[ffs host timing] %lld run-boundary calls: total %.1f us/call = vectors+extract launch %.1f, candidate "
+                "descriptors %.1f, wait for list lengths %.1f, decision+rest %.1f\n", (long long)p->runs_calls,
+                p->ht_total / p->runs_calls / 1e3, p->ht_vec / p->runs_calls / 1e3, p->ht_cand / p->runs_calls / 1e3,
+                p->ht_wait / p->runs_calls / 1e3, p->ht_decide / p->runs_calls / 1e3);
     (void)hipSetDevice(p->device);
     (void)hipDeviceSynchronize();
     (void)hipFree(p->tw1);
@@ -972,6 +1057,12 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->pool_entries);
     (void)hipFree(p->xlist);
     if (p->seg) (void)ffs_plan_destroy(p->seg);
+    (void)hipFree(p->runs_q);
+    (void)hipFree(p->runs_c);
+    (void)hipFree(p->runs_n);
+    (void)hipFree(p->runs_best);
+    if (p->runs_n_host) (void)hipHostFree(p->runs_n_host);
+    if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
@@ -1006,6 +1097,9 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     HIP_TRY(hipSetDevice(p->device));
     int rc;
     if ((rc = enter_stream(p, st))) return rc;
+    auto now_ns = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double ht0 = p->host_timing ? now_ns() : 0.0;
+    double ht1 = ht0, ht2 = ht0, ht3 = ht0;
 
     const int n_packed = (n_cand + 1) / 2;
     const int n_slots = 1 + n_packed;  // length-N buffers per pair, in either layout
@@ -1026,7 +1120,12 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
     const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
     const size_t o_cand = 64;
-    const size_t o_xf = o_cand + n_cands * sizeof(CandDesc);
+    // Run-boundary path: bit-packed two-level vectors on both sides (ffs_runs.h); everything else, and every sub-batch
+    // whose boundary lists turn out too long, goes through the transforms.
+    const bool runs_ok = p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U1 && ref_dt == FFS_DTYPE_U1;
+    const size_t n_vec = (size_t)n_pairs * (1 + (size_t)n_cand);
+    const size_t o_rv = o_cand + n_cands * sizeof(CandDesc);  // RunsVec[n_vec] when runs_ok
+    const size_t o_xf = (o_rv + (runs_ok ? n_vec * sizeof(RunsVec) : 0) + 63) & ~(size_t)63;
     const size_t host_bytes_max = o_xf + (n_xf_alloc > n_xf ? n_xf_alloc : n_xf) * sizeof(XformDesc);
     const size_t o_nom = (host_bytes_max + 255) & ~(size_t)255;
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
@@ -1043,6 +1142,64 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     CandDesc* hc = (CandDesc*)(hb + o_cand);
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     const int stride = 1 + n_cand;
+    RunsVec* hrv = (RunsVec*)(hb + o_rv);
+    char* db = (char*)p->dev_desc;
+    if (runs_ok) {
+        // Run-boundary path, step 1: the boundary lists of every vector only need (pointer, length) -- launched before
+        // the candidate descriptors are built, so the host loop below runs while the device reads the vectors, and the
+        // list lengths are back by the time they are needed.
+        for (int pi = 0; pi < n_pairs; ++pi) {
+            const size_t b = (size_t)pi * stride;
+            for (int v = 0; v < stride; ++v) {
+                if (vec_len[b] <= 0 || vec_len[b + v] <= 0)
+                    return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
+                                (long long)vec_len[b], (long long)vec_len[b + (v ? v : 1)]);
+                if (!vec_ptr[b + v]) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
+                if ((uintptr_t)vec_ptr[b + v] & 3)
+                    return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
+                hrv[b + v] = RunsVec{(const unsigned*)vec_ptr[b + v], (int32_t)vec_len[b + v], 0};
+            }
+        }
+        if ((rc = ensure_runs(p, n_vec, 0))) return rc;
+        HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsVec), hipMemcpyHostToDevice, st));
+        {
+            ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
+            hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsVec*)(db + o_rv), p->runs_q,
+                               p->runs_c, p->runs_n, RUNS_CAP);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(p->runs_n_host, p->runs_n, n_vec * sizeof(int2), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(p->runs_ev, st));
+    }
+    if (p->host_timing) ht1 = now_ns();
+    int tiles_max = 1;
+    for (int pi = 0; pi < n_pairs; ++pi) {
+        const size_t b = (size_t)pi * stride;
+        const VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
+        for (int j = 0; j < n_cand; ++j) {
+            const VecView sub{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
+            if (!ref.ptr || !sub.ptr) {
+                if (ref.len > 0 && sub.len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
+            }
+            if (((uintptr_t)ref.ptr & amask_of(ref_dt)) || ((uintptr_t)sub.ptr & amask_of(dtype)))
+                return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
+            CandDesc& cd = hc[(size_t)pi * n_cand + j];
+            if ((rc = fill_cand(ref, sub, max_offset_samples, &cd, ref_dt, dtype))) return rc;
+            if (runs_ok && !(cd.flags & CAND_NO_LAGS)) {
+                const int t = (cd.d_hi - cd.d_lo + RUNS_T) / RUNS_T;
+                if (t > tiles_max) tiles_max = t;
+            }
+        }
+    }
+    // ---- descriptors of the transform path (built only when some sub-batch needs it) -------------------------
+    BinList bins;
+    memset(&bins, 0, sizeof bins);
+    bool pruned = false, seg = false;
+    int seg_blocks = 0;
+    int64_t seg_lo = 0;
+    auto build_xforms = [&]() -> int {
+    for (size_t i = 0; i < n_cands; ++i)
+        if ((rc = finish_cand_for_transforms(p, max_offset_samples, &hc[i]))) return rc;
     std::vector<VecView> views((size_t)n_pairs * stride);  // per pair: reference, candidates (reachable prefixes)
     for (int pi = 0; pi < n_pairs; ++pi) {
         const size_t b = (size_t)pi * stride;
@@ -1051,13 +1208,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         int64_t ref_used = 1;
         for (int j = 0; j < n_cand; ++j) {
             subs[j] = VecView{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
-            if (!ref.ptr || !subs[j].ptr) {
-                if (ref.len > 0 && subs[j].len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
-            }
-            if (((uintptr_t)ref.ptr & amask_of(ref_dt)) || ((uintptr_t)subs[j].ptr & amask_of(dtype)))
-                return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
             const CandDesc& cd = hc[(size_t)pi * n_cand + j];
-            if ((rc = fill_cand(p, ref, subs[j], max_offset_samples, &hc[(size_t)pi * n_cand + j], ref_dt, dtype))) return rc;
             // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
             // keeps working on the whole vectors through the candidate descriptor)
             int64_t s_eff, r_eff;
@@ -1078,18 +1229,13 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     std::vector<int> bin_set;
     bool bins_overflow = p->direct_only;
     for (size_t i = 0; i < n_cands && !bins_overflow; ++i) add_bins(p, hc[i], &bin_set, &bins_overflow);
-    BinList bins;
-    memset(&bins, 0, sizeof bins);
     bins.n = (int)bin_set.size();
     for (int i = 0; i < bins.n; ++i) bins.b[i] = bin_set[i];
-    bool pruned = p->allow_pruned && !bins_overflow && bins.n > 0 && bins.n * 2 <= p->N1;
+    pruned = p->allow_pruned && !bins_overflow && bins.n > 0 && bins.n * 2 <= p->N1;
     // Block-segmented mode (see k_mid_seg): every candidate is cut into n_blocks <= 3 blocks of B samples,
     // block k is correlated with the reference stretch [kB + D_lo, kB + D_lo + M) by a length-M transform
     // (lag d at output index d - D_lo, nothing wraps), the blocks' spectrum products are added in the
     // mid pass.  [D_lo, D_hi] = union of the call's lag windows.
-    bool seg = false;
-    int seg_blocks = 0;
-    int64_t seg_lo = 0;
     if (p->seg && p->allow_seg && p->allow_pruned && !p->direct_only && max_offset_samples >= 0 && p->seg->N2 == 4096 &&
         ref_half_ok(p->seg)) {
         const ffs_plan* sp = p->seg;
@@ -1147,16 +1293,18 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             }
         }
     }
-    const size_t host_bytes = o_xf + n_xf * sizeof(XformDesc);
-    char* db = (char*)p->dev_desc;
-    HIP_TRY(hipMemcpyAsync(db, hb, host_bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(p->upload_done, st));
+    return FFS_OK;
+    };
+    if (!runs_ok && (rc = build_xforms())) return rc;
+    // one upload when the transforms run anyway; with the run-boundary path only [header, candidates] for now
+    HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
     const CandDesc* dc = (const CandDesc*)(db + o_cand);
     const XformDesc* dx = (const XformDesc*)(db + o_xf);
     NomList* dn = (NomList*)(db + o_nom);
     RescoreAcc* da = (RescoreAcc*)(db + o_acc);
     PoolBest* dpb = (PoolBest*)(db + o_pbest);
-    PoolArgs pa{dn, (PoolHeader*)(db + o_pool), p->pool_entries, dpb,
+    PoolArgs pa{dn, (PoolHeader*)(db + o_pool), nullptr, dpb,  // .entries: once the transform workspace exists
                 (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight};
     pa.half_last = (hflags & HALF_LAST) ? 1 : 0;
     CandResult* cres = (CandResult*)cand_out_dev;
@@ -1166,10 +1314,69 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
         HIP_TRY(hipGetLastError());
     } else {
-        HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
+        // ---- run-boundary path: boundary lists of every vector, exact correlation of every candidate whose lists are
+        // short enough; the list lengths come back (one event wait) and decide which sub-batches need the transforms
+        const int n_chunks = (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight;
+        std::vector<char> chunk_fft((size_t)n_chunks, runs_ok ? 0 : 1);
+        bool any_fft = !runs_ok;
+        if (runs_ok) {
+            if ((rc = ensure_runs(p, n_vec, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0))) return rc;
+            const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4 : p->runs_budget;
+            {
+                ProfSpan span(p, st, FFS_K_RUNS_CORR);
+                hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(256), 0, st, dc, n_cand, p->runs_q,
+                                   p->runs_c, p->runs_n, RUNS_CAP, budget, dn, da, p->runs_best, tiles_max);
+                if (tiles_max > 1)
+                    hipLaunchKernelGGL(k_runs_pick, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, (int)n_cands, n_cand,
+                                       p->runs_n, RUNS_CAP, budget, p->runs_best, tiles_max, dn, da);
+            }
+            HIP_TRY(hipGetLastError());
+            if (p->host_timing) ht2 = now_ns();
+            HIP_TRY(hipEventSynchronize(p->runs_ev));  // the list lengths are on the host; k_runs_corr keeps the device busy
+            if (p->host_timing) ht3 = now_ns();
+            for (int pi = 0; pi < n_pairs; ++pi) {
+                const int ch = pi / p->pairs_in_flight;
+                if (chunk_fft[ch]) continue;
+                const int2 nr = p->runs_n_host[(size_t)pi * stride];
+                for (int j = 0; j < n_cand; ++j) {
+                    const CandDesc& cd = hc[(size_t)pi * n_cand + j];
+                    if (cd.flags & CAND_NO_LAGS) continue;
+                    if (runs_over_budget(p->runs_n_host[(size_t)pi * stride + 1 + j].x, nr.x, (long long)cd.d_hi - cd.d_lo + 1, cd.R,
+                                         RUNS_CAP, budget)) {
+                        chunk_fft[ch] = 1;
+                        any_fft = true;
+                        break;
+                    }
+                }
+            }
+            p->runs_calls += 1;
+            p->runs_chunks += n_chunks;
+            p->runs_last_boundaries = 0;
+            for (size_t i = 0; i < n_vec; ++i) p->runs_last_boundaries += p->runs_n_host[i].x;
+            if (any_fft) {
+                for (int ch = 0; ch < n_chunks; ++ch) p->runs_fft_chunks += chunk_fft[ch];
+                if ((rc = build_xforms())) return rc;  // also completes the candidate descriptors (tie margins)
+                HIP_TRY(hipMemcpyAsync(db + o_cand, hb + o_cand, o_xf + n_xf * sizeof(XformDesc) - o_cand, hipMemcpyHostToDevice, st));
+                for (int ch = 0; ch < n_chunks; ++ch) {  // clean accumulators for the sub-batches that are solved again
+                    if (!chunk_fft[ch]) continue;
+                    const size_t c0 = (size_t)ch * p->pairs_in_flight * n_cand;
+                    const size_t c1 = c0 + (size_t)p->pairs_in_flight * n_cand < n_cands ? c0 + (size_t)p->pairs_in_flight * n_cand : n_cands;
+                    HIP_TRY(hipMemsetAsync(da + c0 * KNOM, 0, (c1 - c0) * KNOM * sizeof(RescoreAcc), st));
+                    HIP_TRY(hipMemsetAsync(dpb + c0, 0, (c1 - c0) * sizeof(PoolBest), st));
+                }
+                HIP_TRY(hipEventRecord(p->upload_done, st));
+            }
+        } else {
+            HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
+        }
+        if (any_fft) {
+            if ((rc = ensure_workspace(p))) return rc;
+            pa.entries = p->pool_entries;
+        }
         const int tiles = p->N2 / p->C;
         const bool full3 = !pruned && col3r_ok(p);  // full last pass over radix-3 columns: k_pass_c3's (wider) tiles
         for (int p0 = 0; seg && p0 < n_pairs; p0 += p->pairs_in_flight) {
+            if (!chunk_fft[p0 / p->pairs_in_flight]) continue;
             // block-segmented pipeline on the length-M sub-plan: 3x shorter transforms, the blocks'
             // spectrum products are added in the mid pass, last pass over one third of the data
             ffs_plan* sp = p->seg;
@@ -1218,7 +1425,8 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             }
             HIP_TRY(hipGetLastError());
         }
-        for (int p0 = 0; !seg && p0 < n_pairs; p0 += p->pairs_in_flight) {
+        for (int p0 = 0; !seg && any_fft && p0 < n_pairs; p0 += p->pairs_in_flight) {
+            if (!chunk_fft[p0 / p->pairs_in_flight]) continue;
             const int np = (n_pairs - p0) < p->pairs_in_flight ? (n_pairs - p0) : p->pairs_in_flight;
             const int first_cand = p0 * n_cand;
             {
@@ -1265,8 +1473,10 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             }
             HIP_TRY(hipGetLastError());
         }
-        FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
-        hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
+        if (any_fft) {
+            FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
+            hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
+        }
         hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
                            (int)n_cands, mixed ? 4 : dtype, pa.header, dpb);
         HIP_TRY(hipGetLastError());
@@ -1274,7 +1484,12 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
                        (long long)filter_max_offset);
     HIP_TRY(hipGetLastError());
-    return leave_stream(p, st);
+    rc = leave_stream(p, st);
+    if (p->host_timing && runs_ok) {
+        const double ht4 = now_ns();
+        p->ht_vec += ht1 - ht0, p->ht_cand += ht2 - ht1, p->ht_wait += ht3 - ht2, p->ht_decide += ht4 - ht3, p->ht_total += ht4 - ht0;
+    }
+    return rc;
 }
 
 int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void* const* vec_ptr,
@@ -1314,6 +1529,7 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     HIP_TRY(hipSetDevice(p->device));
     int rc;
     if ((rc = enter_stream(p, st))) return rc;
+    if ((rc = ensure_workspace(p))) return rc;
     if ((rc = ensure_desc(p, 4096))) return rc;
     HIP_TRY(hipEventSynchronize(p->upload_done));
     XformDesc* hx = (XformDesc*)p->host_desc;
@@ -1782,6 +1998,24 @@ int ffs_comm_destroy(ffs_comm* c) {
         (void)a->CommDestroy(c->comm);
     }
     delete c;
+    return FFS_OK;
+}
+
+int ffs_plan_set_algorithm(ffs_plan* p, int algorithm) {
+    if (!p) return fail(FFS_E_INVALID, "plan is null");
+    if (algorithm != FFS_ALGO_AUTO && algorithm != FFS_ALGO_FFT && algorithm != FFS_ALGO_RUNS)
+        return fail(FFS_E_INVALID, "unknown algorithm %d", algorithm);
+    p->algo = algorithm;
+    return FFS_OK;
+}
+
+int ffs_plan_runs_stats(ffs_plan* p, int64_t* calls, int64_t* sub_batches, int64_t* sub_batches_through_transforms,
+                        int64_t* boundaries_last_call) {
+    if (!p) return fail(FFS_E_INVALID, "plan is null");
+    if (calls) *calls = p->runs_calls;
+    if (sub_batches) *sub_batches = p->runs_chunks;
+    if (sub_batches_through_transforms) *sub_batches_through_transforms = p->runs_fft_chunks;
+    if (boundaries_last_call) *boundaries_last_call = p->runs_last_boundaries;
     return FFS_OK;
 }
 

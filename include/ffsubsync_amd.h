@@ -142,6 +142,29 @@ int ffs_align_batch_typed(ffs_plan* plan, int n_pairs, int n_cand, const int32_t
                           ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
                           void* hip_stream);
 
+/* How ffs_align_batch / ffs_align_batch_typed evaluate the correlation of aligners.py:50-80.  Results are identical
+ * either way (same exact scores, same tie rule); only the time differs.
+ *   FFS_ALGO_AUTO (default): bit-packed two-level vectors (FFS_DTYPE_U1 on both sides) first go through the
+ *     run-boundary path -- the exact integer correlation of the two run-length-coded vectors over every lag of the
+ *     window, no transform (csrc/ffs_runs.h) -- and the call waits once (an event, not the stream) for the lengths of the
+ *     boundary lists; sub-batches (pairs_in_flight pairs) holding a vector with 32 767 boundaries or more, or a candidate
+ *     whose expected number of boundary coincidences inside its lag window (boundaries of the candidate x boundaries of
+ *     the reference x window lags / reference length) exceeds the budget -- by default five per point of the plan's
+ *     transform length, the measured break-even -- are solved by the transforms instead.  Every other element type goes
+ *     through the transforms.
+ *   FFS_ALGO_FFT: transforms only (the path of rounds 1-3).
+ *   FFS_ALGO_RUNS: like AUTO without the coincidence budget (truncated boundary lists still fall back).
+ * Environment: FFS_ALGORITHM=auto|fft|runs presets new plans, FFS_RUNS_BUDGET=<coincidences> the budget. */
+#define FFS_ALGO_AUTO 0
+#define FFS_ALGO_FFT 1
+#define FFS_ALGO_RUNS 2
+int ffs_plan_set_algorithm(ffs_plan* plan, int algorithm);
+/* Since plan creation: calls that tried the run-boundary path, their sub-batches, and how many of those went through
+ * the transforms after all; boundaries_last_call = boundary-list entries of all vectors of the most recent such call
+ * (what k_runs_extract wrote: 8 bytes each).  Any pointer may be NULL. */
+int ffs_plan_runs_stats(ffs_plan* plan, int64_t* calls, int64_t* sub_batches, int64_t* sub_batches_through_transforms,
+                        int64_t* boundaries_last_call);
+
 /* Full correlation of one reference with one or two candidates (b_dev may be NULL):
  *   out_x_dev[m] = sum_i x'[i] * ref'[(i + m) mod n_fft],  m in [0, n_fft)
  * i.e. the reference's `convolve` array (aligners.py:74) with convolve[k] = out[(N-1-S-k) mod N].
@@ -285,7 +308,9 @@ int ffs_comm_destroy(ffs_comm* comm);
 #define FFS_K_PASS_C 2   /* column FFT + lag-window mask + block argmax nominees    */
 #define FFS_K_NOMINEES 3 /* nominee gather per candidate                            */
 #define FFS_K_RESCORE 4  /* exact re-evaluation of nominee lags                     */
-#define FFS_K_COUNT 5
+#define FFS_K_RUNS_EXTRACT 5 /* run-boundary path: boundary lists of every vector (reads the bit-packed vectors) */
+#define FFS_K_RUNS_CORR 6    /* run-boundary path: exact correlation over the lag window + argmax           */
+#define FFS_K_COUNT 7
 int ffs_plan_profile(ffs_plan* plan, int enable);
 /* Synchronises the recorded events, adds their durations to ms_total[FFS_K_COUNT] /
  * launches[FFS_K_COUNT] (caller-zeroed or accumulating) and clears the recording. */

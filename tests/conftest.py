@@ -34,3 +34,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# Modules written against the TRANSFORM path (rounds 1-3): their "identical records" / kernel-instantiation tests must
+# keep exercising the FFT kernels now that bit-packed two-level vectors default to the run-boundary path
+# (FFS_ALGORITHM=auto).  tests/test_gpu_runs.py runs the same parity cases, and its own, on the new path.
+_TRANSFORM_PATH_MODULES = {"test_gpu_parity", "test_gpu_round2", "test_gpu_round3", "test_gpu_headline", "test_gpu_float",
+                           "test_gpu_raster"}
+
+
+@pytest.fixture(autouse=True)
+def _transform_path_for_its_own_tests(request, monkeypatch):
+    if request.module.__name__.split(".")[-1] in _TRANSFORM_PATH_MODULES and "FFS_ALGORITHM" not in os.environ:
+        monkeypatch.setenv("FFS_ALGORITHM", "fft")
+    yield

@@ -1,0 +1,246 @@
+"""The run-boundary path (csrc/ffs_runs.h: exact correlation of run-length-coded activity vectors, FFS_ALGORITHM=auto)
+against the transform path, the CPU oracle and the unmodified reference's goldens.  Through the C ABI; need a real MI355X.
+
+"Identical records" = every field of ffs_cand_result / ffs_pair_result except score_f32 (the fp32 transform's value at
+the winning lag, which only the transform path has; the run-boundary path stores the exact score rounded to fp32).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import golden_cases
+from oracle import aligners_oracle as orc
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEAD = json.load(open(os.path.join(HERE, "golden", "headline_golden.json")))["pairs"]
+GOLD = json.load(open(os.path.join(HERE, "golden", "aligner_golden.json")))
+SMALL = golden_cases.build_cases(include_large=False)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def _same_records(a, b):
+    ca, pa = a
+    cb, pb = b
+    for f in ("score", "offset", "flags"):
+        assert np.array_equal(ca[f], cb[f]), (f, np.argwhere(ca[f] != cb[f])[:5])
+    assert np.array_equal(pa, pb)
+
+
+def _solve(db, n_fft, max_off, algorithm, n_cand=7, pairs_in_flight=64):
+    from ffsubsync_amd import batch
+
+    al = batch.BatchAligner(n_fft, n_cand, max_off, pairs_in_flight=pairs_in_flight, algorithm=algorithm)
+    out = al.solve(db)
+    stats = al.plan.runs_stats()
+    al.close()
+    return out, stats
+
+
+@pytest.fixture(scope="module")
+def headline(torch):
+    from workloads import synth
+
+    n = int(os.environ.get("FFS_RUNS_PAIRS", "128"))
+    specs = [synth.make_pair_spec(g["seed"]) for g in HEAD[:n]]
+    db = synth.build_device_batch(specs)
+    yield specs, db, HEAD[:n]
+    del db
+    torch.cuda.empty_cache()
+
+
+def test_headline_pairs_equal_the_reference_and_the_transform_path(headline):
+    """configs[2] at the timed shape: auto takes the run-boundary path for every sub-batch; records identical to the
+    transform path and to the unmodified reference's goldens (same rule as tests/test_gpu_headline.py)."""
+    import test_gpu_headline as th
+
+    specs, db, gold = headline
+    n_fft = db.required_fft_length(6000)
+    (c_auto, p_auto), st_auto = _solve(db, n_fft, 6000, "auto")
+    (c_fft, p_fft), st_fft = _solve(db, n_fft, 6000, "fft")
+    assert st_auto[0] == 1 and st_auto[1] == 2 and st_auto[2] == 0  # one call, two sub-batches, none through the transforms
+    assert st_fft == (0, 0, 0)
+    _same_records((c_auto, p_auto), (c_fft, p_fft))
+    th._check_seven(p_auto, c_auto, gold)
+    # the exact score is what both paths report; the run-boundary path stores it (rounded) as score_f32 too
+    assert np.array_equal(c_auto["score_f32"], c_auto["score"].astype(np.float32))
+
+
+@pytest.mark.parametrize("max_off", [None, 6000, 150000])
+def test_single_ratio_and_wide_windows(headline, max_off):
+    """FFTAligner() / FFTAligner(6000) on the true-ratio candidate (configs[1]) and a window of 25 tiles: windows wider
+    than one tile (12 288 lags) are cut into tiles whose results k_runs_pick combines."""
+    specs, db, gold = headline
+    from workloads import synth
+
+    db32 = synth.build_device_batch(specs[:32])
+    one = db32.select_candidates([sp.true_ratio_index for sp in specs[:32]])
+    n_fft = one.required_fft_length(max_off)
+    # "runs": windowless 2 h candidates exceed auto's coincidence budget (the transforms cost about the same there)
+    a, st = _solve(one, n_fft, max_off, "runs", n_cand=1, pairs_in_flight=32)
+    b, _ = _solve(one, n_fft, max_off, "fft", n_cand=1, pairs_in_flight=32)
+    assert st[2] == 0
+    _same_records(a, b)
+    key = {None: "single_none", 6000: "single_6000"}.get(max_off)
+    if key:
+        for i, g in enumerate(gold[:32]):
+            assert int(a[0][i, 0]["offset"]) == g[key][1]
+            assert float(a[0][i, 0]["score"]) == pytest.approx(float(g[key][0]), rel=1e-5)
+
+
+def test_seven_ratios_without_a_window(headline):
+    """max_offset_samples=None, seven ratios: 118 tiles per candidate."""
+    specs, db, gold = headline
+    from workloads import synth
+
+    db8 = synth.build_device_batch(specs[:8])
+    n_fft = db8.required_fft_length(None)
+    a, st = _solve(db8, n_fft, None, "runs", pairs_in_flight=8)
+    b, _ = _solve(db8, n_fft, None, "fft", pairs_in_flight=8)
+    assert st[2] == 0
+    _same_records(a, b)
+    # auto: ~13 M boundary coincidences per candidate against a budget of five per transform point (7.9 M) -> transforms
+    c, st_auto = _solve(db8, n_fft, None, "auto", pairs_in_flight=8)
+    assert st_auto == (1, 1, 1)
+    _same_records(c, b)
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_golden_cases_through_the_dropin_classes(torch, name, monkeypatch):
+    """Every reference golden (KATs, lag-window semantics incl. Python negative slices and all-masked windows, float
+    inputs, short inputs) through the drop-in classes with the run-boundary path enabled."""
+    import test_gpu_parity as tp
+
+    monkeypatch.setenv("FFS_ALGORITHM", "auto")
+    tp.test_golden_cases_through_the_dropin_classes(torch, name)
+
+
+def test_large_goldens_and_gss_trace(torch, monkeypatch):
+    import test_gpu_parity as tp
+
+    monkeypatch.setenv("FFS_ALGORITHM", "auto")
+    tp.test_headline_shape_2h_seven_ratios(torch)
+    tp.test_gss_through_the_dropin(torch)
+    tp.test_extreme_densities_stay_exact(torch)
+    tp.test_exact_tie_rule_is_first_maximum_in_k(torch)
+
+
+def _pair(rng, R, S, run_mean, dens, n_cand, amp_choices=(1.0, 0.96, 0.999)):
+    from ffsubsync_amd.aligners import _Vec
+
+    seg = np.maximum(1, rng.geometric(1.0 / run_mean, size=R))
+    ref01 = np.repeat(rng.rand(seg.size) < dens, seg)[:R]
+    lo_hi_ref = [(0.0, 1.0), (-1.0, 1.0), (0.25, 1.0)][rng.randint(3)]
+    ref = np.where(ref01, lo_hi_ref[1], lo_hi_ref[0])
+    cands = []
+    for _ in range(n_cand):
+        off = int(rng.randint(-S // 2, R // 2 + 1))
+        idx = np.arange(S) + off
+        ok = (idx >= 0) & (idx < R)
+        c01 = np.zeros(S, bool)
+        c01[ok] = ref01[idx[ok]]
+        c01 ^= rng.rand(S) < rng.choice([0.0, 0.002, 0.05])
+        cands.append(c01 * amp_choices[rng.randint(len(amp_choices))])
+    return ref, cands, (_Vec(ref), [_Vec(c) for c in cands])
+
+
+def test_randomised_problems_both_paths_and_oracle(torch, monkeypatch):
+    """Fuzz over lengths (incl. multiples of 32 and vectors whose last sample is set), run lengths from 2 (lists longer
+    than the LDS staging area, read from global memory) to 2000, densities, levels, windows (None, narrow, wider than
+    the data, Python-negative-slice) and candidate counts: run-boundary records == transform records, and both against
+    the oracle (offset whenever its top-2 gap exceeds 0.5, score always)."""
+    from ffsubsync_amd.aligners import solve_pairs
+
+    trials = int(os.environ.get("FFS_FUZZ_TRIALS", "60"))
+    rng = np.random.RandomState(4242)
+    for trial in range(trials):
+        R = int(rng.choice([rng.randint(4200, 9000), rng.randint(9000, 70000), 32 * rng.randint(200, 2000)]))
+        S = int(max(2100, R * rng.uniform(0.4, 1.5)))
+        if trial % 6 == 0:
+            S = S // 32 * 32
+        run_mean = int(rng.choice([2, 5, 50, 400, 2000]))
+        n_cand = int(rng.choice([1, 2, 3, 7]))
+        ref, cands, pv = _pair(rng, R, S, run_mean, rng.choice([0.05, 0.4, 0.9]), n_cand)
+        if trial % 9 == 0:
+            cands[0] = cands[0] * 0  # a silent candidate
+            pv = (pv[0], [type(pv[0])(c) for c in cands])
+        mo = [None, None, 6000, int(rng.randint(0, 3 * R)), int(rng.randint(1, 200))][rng.randint(5)]
+        monkeypatch.setenv("FFS_ALGORITHM", "runs")
+        c_r, p_r = solve_pairs([pv], mo, mo)
+        monkeypatch.setenv("FFS_ALGORITHM", "fft")
+        c_f, p_f = solve_pairs([pv], mo, mo)
+        _same_records((c_r, p_r), (c_f, p_f))
+        for j, c in enumerate(cands):
+            conv, S_ = orc.convolve_full(ref, c)
+            m = orc.mask_extreme_offsets(conv, S_, mo)
+            k = int(np.argmax(m))
+            s_o, o_o = m[k], len(m) - 1 - k - S_
+            got_s, got_o = float(c_r[0, j]["score"]), int(c_r[0, j]["offset"])
+            if not np.isfinite(s_o):
+                assert got_s == -np.inf and got_o == o_o, (trial, j)
+                continue
+            assert got_s == pytest.approx(s_o, rel=1e-9, abs=1e-6), (trial, j, R, S, mo)
+            fin = np.sort(m[np.isfinite(m)])
+            if fin.size < 2 or fin[-1] - fin[-2] > 0.5:
+                assert got_o == o_o, (trial, j, R, S, mo, got_o, o_o)
+
+
+def test_dense_vectors_fall_back_to_the_transforms_per_sub_batch(torch):
+    """Four 20-minute pairs, two per sub-batch; pair 2's reference is random bits (60 000 boundaries: its list is
+    truncated): auto solves sub-batch 0 by run boundaries and sub-batch 1 through the transforms, records identical to
+    the all-transform solve; with a zero coincidence budget everything goes through the transforms."""
+    from ffsubsync_amd import _native, batch
+    from ffsubsync_amd.batch import DeviceBatch
+
+    rng = np.random.RandomState(5)
+    R = S = 120000
+    vecs, lens = [], []
+    for p in range(4):
+        dense = p == 2
+        ref = (rng.rand(R) < 0.5) if dense else np.repeat(rng.rand(R // 300 + 1) < 0.4, 300)[:R]
+        off = int(rng.randint(-3000, 3000))
+        idx = np.arange(S) + off
+        ok = (idx >= 0) & (idx < R)
+        c = np.zeros(S, bool)
+        c[ok] = ref[idx[ok]]
+        c2 = np.roll(c, 777)
+        vecs += [ref, c, c2]
+        lens.append([R, S, S])
+    sizes = [(v.size + 7) // 8 for v in vecs]
+    offs = np.zeros(len(vecs), np.int64)
+    tot = 0
+    for i, s in enumerate(sizes):
+        offs[i] = tot
+        tot += (s + 63) // 64 * 64
+    host = np.zeros(tot, np.uint8)
+    for v, o in zip(vecs, offs):
+        pk = np.packbits(v.astype(np.uint8), bitorder="little")
+        host[o:o + pk.size] = pk
+    data = torch.from_numpy(host).cuda()
+    shape = (4, 3)
+    db = DeviceBatch(data, offs.reshape(shape), np.array(lens, np.int64), np.zeros(shape), np.ones(shape), _native.FFS_DTYPE_U1)
+    n_fft = db.required_fft_length(6000)
+    a, st = _solve(db, n_fft, 6000, "auto", n_cand=2, pairs_in_flight=2)
+    b, _ = _solve(db, n_fft, 6000, "fft", n_cand=2, pairs_in_flight=2)
+    assert st == (1, 2, 1)
+    _same_records(a, b)
+    os.environ["FFS_RUNS_BUDGET"] = "0"
+    try:
+        c, st0 = _solve(db, n_fft, 6000, "auto", n_cand=2, pairs_in_flight=2)
+    finally:
+        del os.environ["FFS_RUNS_BUDGET"]
+    assert st0 == (1, 2, 2)
+    _same_records(c, b)
+    # "runs": no budget, but truncated lists still go through the transforms
+    d, st1 = _solve(db, n_fft, 6000, "runs", n_cand=2, pairs_in_flight=2)
+    assert st1 == (1, 2, 1)
+    _same_records(d, b)

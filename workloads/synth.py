@@ -32,11 +32,11 @@ class PairSpec:
     true_ratio_index: int
 
 
-def _speech_runs(rng: np.random.RandomState, duration_s: float):
-    """Alternate gaps U[0.2, 8] s and speech runs U[0.5, 6] s until the duration is used up."""
-    n_max = int(duration_s / 0.7) + 8
-    gaps = rng.uniform(0.2, 8.0, n_max)
-    runs = rng.uniform(0.5, 6.0, n_max)
+def _speech_runs(rng: np.random.RandomState, duration_s: float, run_scale: float = 1.0):
+    """Alternate gaps U[0.2, 8] s and speech runs U[0.5, 6] s (times ``run_scale``) until the duration is used up."""
+    n_max = int(duration_s / (0.7 * run_scale)) + 8
+    gaps = rng.uniform(0.2, 8.0, n_max) * run_scale
+    runs = rng.uniform(0.5, 6.0, n_max) * run_scale
     ends = np.cumsum(gaps + runs)
     starts = ends - runs
     keep = ends < duration_s
@@ -44,10 +44,12 @@ def _speech_runs(rng: np.random.RandomState, duration_s: float):
 
 
 def make_pair_spec(seed: int, duration_s: float = 7200.0, ratios: Optional[Sequence[float]] = None,
-                   max_true_offset_s: float = 55.0, sample_rate: int = SAMPLE_RATE) -> PairSpec:
+                   max_true_offset_s: float = 55.0, sample_rate: int = SAMPLE_RATE, run_scale: float = 1.0) -> PairSpec:
+    """``run_scale`` < 1 shortens gaps, runs and the edge jitter alike: 1 / run_scale times as many runs per vector (a
+    flickering frame-level detector instead of subtitle-like activity); 1.0 is the benchmark workload."""
     ratios = list(candidate_ratios() if ratios is None else ratios)
     rng = np.random.RandomState(seed)
-    t0, t1 = _speech_runs(rng, duration_s)
+    t0, t1 = _speech_runs(rng, duration_s, run_scale)
     ref_len = int(round(duration_s * sample_rate))
     rs = np.rint(t0 * sample_rate).astype(np.int64)
     re = np.minimum(rs + np.rint((t1 - t0) * sample_rate).astype(np.int64), ref_len)
@@ -55,8 +57,8 @@ def make_pair_spec(seed: int, duration_s: float = 7200.0, ratios: Optional[Seque
     true_idx = int(rng.randint(len(ratios)))
     true_ratio = ratios[true_idx]
     keep = rng.rand(t0.size) > 0.15
-    js = rng.uniform(-0.1, 0.1, t0.size)
-    je = rng.uniform(-0.1, 0.1, t0.size)
+    js = rng.uniform(-0.1, 0.1, t0.size) * run_scale
+    je = rng.uniform(-0.1, 0.1, t0.size) * run_scale
     # subtitle clock: t_ref = t_sub * true_ratio + true_offset
     s0 = (t0 + js - true_offset_s) / true_ratio
     s1 = (t1 + je - true_offset_s) / true_ratio
