@@ -283,11 +283,75 @@ def drop_in_figures(torch, specs, n=12):
         out[label] = {"ms_per_solve_median": 1e3 * float(np.median(ts)), "ms_per_solve_min": 1e3 * min(ts),
                       "solves_per_s_one_at_a_time": len(ts) / sum(ts)}
     out["same_answers"] = answers["host_float64_arrays"] == answers["device_rasters"]
+    # the same host float64 arrays, all problems in ONE call (aligners.solve_host_batch: threaded level detection + bit
+    # packing, one upload, one ffs_align_batch)
+    from ffsubsync_amd.aligners import solve_host_batch
+
+    solve_host_batch(host[:2], 6000, 6000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, pres_h = solve_host_batch(host, 6000, 6000)
+    dt = time.perf_counter() - t0
+    out["host_batch"] = {
+        "ms_per_solve": 1e3 * dt / len(host), "solves_per_s": len(host) / dt,
+        "same_answers": [(float(r["score"]), int(r["offset"]), int(r["best_cand"])) for r in pres_h] == answers["host_float64_arrays"],
+        "what": "%d problems' float64 arrays in one solve_host_batch call" % len(host)}
     out["recovered_ratio"] = "%d/%d" % (sum(a[2] == sp.true_ratio_index for a, sp in zip(answers["device_rasters"], specs)), n)
     out["what"] = ("MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform, one 2 h x 7-ratio problem per call, %d problems; "
                    "the unmodified reference needs ~2.9 s for the same call in the build container "
                    "(profiles/r02_cpu_reference_baseline.json)" % n)
     return out
+
+
+def gss_figures(torch, _native, specs, n_files=256):
+    """Batched golden-section search over the framerate ratio (MaxScoreAligner.fit_gss, aligners.py:111-129, for many
+    files at once): every one of the 17 steps is ONE batched rasterisation (each file's subtitle track at that file's
+    current ratio) + ONE batched solve, plan and reference vectors held across the steps.  Files: the benchmark pairs --
+    reference vector bit-packed in HBM, subtitle file = the pair's track in its own clock (the ratio-1.0 candidate)."""
+    import numpy as np
+
+    from ffsubsync_amd import batch
+    from ffsubsync_amd.batch_gss import fit_gss_batch
+    from ffsubsync_amd.subtitle_raster import DeviceRaster
+
+    specs = specs[:n_files]
+    n = len(specs)
+    refs_t = batch.TrackSet([(sp.ref_starts * 10000, sp.ref_ends * 10000, None) for sp in specs])
+    data, offs, lens = refs_t.rasterize(np.arange(n), np.ones(n))
+    # (the rasteriser sizes a vector by its last interval; the aligner only needs the activity, not the silent tail)
+    refs = [DeviceRaster(data[int(o): int(o) + (int(l) + 31) // 32 * 4].view(torch.int32), 0.0, 1.0, int(l)) for o, l in zip(offs, lens)]
+    i1 = [i for i, r in enumerate(specs[0].ratios) if r == 1.0][0]
+    recs = [(sp.cand_starts[i1] * 10000, sp.cand_ends[i1] * 10000, None) for sp in specs]
+    fit_gss_batch(refs[:8], recs[:8], max_offset_samples=6000)  # warm-up: plan, staging buffers
+    torch.cuda.synchronize()
+    stats = {}
+    t0 = time.perf_counter()
+    got = fit_gss_batch(refs, recs, max_offset_samples=6000, stats=stats)
+    el = time.perf_counter() - t0
+    # the search maximises a score that is not unimodal in the ratio (as in the reference): count how many files end
+    # within 1e-3 of the ratio their subtitles were really stretched by, and check one file against the scalar search
+    near = sum(abs(ratio - sp.ratios[sp.true_ratio_index]) < 1e-3 for (_, ratio), sp in zip(got, specs))
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+    from ffsubsync_amd.subtitle_raster import rasterize_candidates
+
+    class Pipe:
+        def __init__(self, r):
+            self.r = r
+
+        def fit_transform(self, *_):
+            return rasterize_candidates(recs[0][0], recs[0][1], None, [self.r])[0]
+
+    msa = MaxScoreAligner(FFTAligner(max_offset_samples=6000))
+    msa.fit(refs[0], [lambda r: Pipe(r)])
+    (s1, o1), pipe = msa.transform()
+    return {
+        "what": "%d files x 2 h: fit_gss_batch(max_offset_samples=6000), golden-section search on [0.9, 1.1] to 1e-4" % n,
+        "files_per_s": n / el, "ms_per_file": 1e3 * el / n, "steps": stats.get("steps"), "ms_per_step": 1e3 * el / max(1, stats.get("steps", 1)),
+        "evaluations_per_s": n * stats.get("steps", 0) / el,
+        "files_ending_within_1e-3_of_the_true_ratio": "%d/%d" % (near, n),
+        "file_0_equals_scalar_search_through_the_drop_in": bool(
+            (repr(pipe.r), int(o1), float(s1)) == (repr(got[0][1]), int(got[0][0][1]), float(got[0][0][0]))),
+    }
 
 
 def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
@@ -343,12 +407,46 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
 
     pres_a, fig_a = timed(per_vector)
     pres_b, fig_b = timed(one_call)
+
+    # A service keeps its plan: the same work with the aligner created once, as a stream of batches -- the interval
+    # tables of batch k+1 are prepared, uploaded and rasterised while batch k is being solved (the calls are asynchronous;
+    # the TrackSet of a batch is built inside the timed region, like everything else that starts from the interval lists).
+    def warm_stream(n_batches=8):
+        al = batch.BatchAligner(batch.pairs_from_intervals(recs, ratios).required_fft_length(6000), 7, 6000,
+                                pairs_in_flight=min(256, n_pairs))
+        outs = [(torch.empty(n_pairs * 7 * 24, dtype=torch.uint8, device="cuda"),
+                 torch.empty(n_pairs * 24, dtype=torch.uint8, device="cuda")) for _ in range(2)]
+        keep = []
+
+        def run(k):
+            db = batch.pairs_from_intervals(recs, ratios)
+            keep.append(db)  # alive until its solve has run
+            al.solve_async(db, 0, n_pairs, outs[k % 2][0], outs[k % 2][1])
+            if len(keep) > 2:
+                keep.pop(0)
+
+        run(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_batches):
+            run(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pres = outs[(n_batches - 1) % 2][1].cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:n_pairs].copy()
+        al.close()
+        return pres, n_batches * n_pairs / dt
+
+    pres_w, rate_w = warm_stream()
     out = {"what": "%d pairs from interval lists -> rasters of the reference track and of the subtitle track at the seven "
                    "ratios -> one batch buffer -> one batched solve; includes plan creation.  One ffs_rasterize_batch_bits "
                    "call for the whole batch (interval arithmetic on the device, written straight into the batch buffer)"
                    % n_pairs}
     out.update(fig_b)
     out["same_results_as_per_vector_calls"] = bool(np.array_equal(pres_a, pres_b))
+    out["warm_plan_stream"] = {
+        "what": "8 batches of %d pairs back to back on one aligner created beforehand (plan, staging buffers and boundary-list "
+                "workspace warm): interval lists -> rasters -> solve, results of the last batch checked" % n_pairs,
+        "solves_per_s": rate_w, "same_results": bool(np.array_equal(pres_w, pres_b))}
     out["per_vector_calls"] = dict(fig_a, what="8 ffs_rasterize_subtitles_bits calls per pair from a Python loop (host interval "
                                                 "arithmetic) + pack_pairs: the round-3 figure before the batched entry point")
     return out
@@ -1004,6 +1102,11 @@ def main():
             result["float_inputs"] = {"error": repr(exc)[:300]}
         finally:
             db, P, specs = keep_db, keep_P, keep_specs
+        if args.duration == 7200.0:
+            try:
+                result["gss"] = gss_figures(torch, _native, specs)
+            except Exception as exc:
+                result["gss"] = {"error": repr(exc)[:300]}
         try:
             result["drop_in"] = drop_in_figures(torch, specs)
         except Exception as exc:

@@ -41,6 +41,16 @@ def install(detectors: bool = True, device_rasters: bool = False) -> None:
     import ffsubsync.aligners as ref_aligners
     import ffsubsync.ffsubsync as ref_main
 
+    # import everything that will be patched BEFORE patching anything: a failure half way (a native wheel's OSError, a
+    # pkg_resources error from auditok ...) must not leave ffsubsync with the aligners swapped and the rest untouched
+    ref_st = None
+    if detectors or device_rasters:
+        try:
+            import ffsubsync.speech_transformers as ref_st  # noqa: F811
+        except (ImportError, OSError) as exc:  # the VAD side of ffsubsync is not importable here: aligner-only install
+            import logging
+
+            logging.getLogger(__name__).warning("ffsubsync.speech_transformers is not importable (%s): aligner-only install", exc)
     for mod in (ref_aligners, ref_main):
         mod.FFTAligner = FFTAligner
         mod.MaxScoreAligner = MaxScoreAligner
@@ -51,11 +61,7 @@ def install(detectors: bool = True, device_rasters: bool = False) -> None:
 
     _al.FailedToFindAlignmentException = ref_aligners.FailedToFindAlignmentException
     FailedToFindAlignmentException = ref_aligners.FailedToFindAlignmentException
-    if not (detectors or device_rasters):
-        return
-    try:
-        import ffsubsync.speech_transformers as ref_st
-    except ImportError:  # the VAD side of ffsubsync is not importable here: aligner-only install
+    if ref_st is None:
         return
     if detectors:
         from .speech_transformers import install_detectors

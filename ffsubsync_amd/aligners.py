@@ -80,6 +80,50 @@ class _Vec:
         return self._values
 
 
+_pack_pool = None
+
+
+def _vecs(arrays: Sequence[Any]) -> List[_Vec]:
+    """``[_Vec(x) for x in arrays]`` with the host passes (level detection + bit packing of float64 vectors, 5.8 MB each
+    for 2 h) spread over a small thread pool: ``ffs_two_level_pack`` runs outside the GIL and is memory-bound, so eight
+    2 h vectors take about the time of two."""
+    global _pack_pool
+    big = [i for i, x in enumerate(arrays) if not hasattr(x, "bits") and not isinstance(x, str) and np.size(x) >= 1 << 16]
+    if len(big) < 2:
+        return [_Vec(x) for x in arrays]
+    if _pack_pool is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+
+        _pack_pool = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2) // 2)), thread_name_prefix="ffs-pack")
+    out: List[Optional[_Vec]] = [None] * len(arrays)
+    futs = {i: _pack_pool.submit(_Vec, arrays[i]) for i in big}
+    for i, x in enumerate(arrays):
+        if i not in futs:
+            out[i] = _Vec(x)
+    for i, f in futs.items():
+        out[i] = f.result()
+    return out  # type: ignore[return-value]
+
+
+def solve_host_batch(problems: Sequence[Tuple[Any, Sequence[Any]]], max_offset_samples: Optional[int],
+                     filter_max_offset: Optional[int] = None):
+    """Many files' numpy vectors at once -- ``problems`` = [(reference, [candidates...]), ...], every problem with the same
+    number of candidates, the arrays exactly what the reference's pipelines hand ``MaxScoreAligner.fit`` (ffsubsync.py:230-235):
+    threaded level detection + bit packing, ONE host-to-device copy, ONE ``ffs_align_batch``.  Returns
+    (cand_results, pair_results) like ``solve_pairs``; pair_results[i]["best_cand"] indexes problem i's candidate list."""
+    flat: List[Any] = []
+    for ref, cands in problems:
+        flat.append(ref)
+        flat.extend(cands)
+    vecs = _vecs(flat)
+    pairs, k = [], 0
+    for ref, cands in problems:
+        pairs.append((vecs[k], vecs[k + 1: k + 1 + len(cands)]))
+        k += 1 + len(cands)
+    return solve_pairs(pairs, max_offset_samples, filter_max_offset)
+
+
 def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Optional[int],
                 filter_max_offset: Optional[int] = None, full_length: bool = False):
     """Solve a list of (reference, [candidates]) problems, all with the same candidate count, in one
@@ -187,8 +231,8 @@ class FFTAligner(TransformerMixin):
     def _solve_many(self, refstring: Any, substrings: Sequence[Any]) -> List[Tuple[float, int]]:
         """All candidates against one reference in a single device batch; leaves the fitted
         attributes as the reference's sequential loop would (those of the last candidate)."""
-        ref = _Vec(refstring)
-        subs = [_Vec(s) for s in substrings]
+        vecs = _vecs([refstring] + list(substrings))
+        ref, subs = vecs[0], vecs[1:]
         cres, _ = solve_pairs([(ref, subs)], self.max_offset_samples)
         out = [(np.float64(r["score"]), int(r["offset"])) for r in cres[0]]
         self.best_score_, self.best_offset_ = out[-1]
@@ -205,9 +249,12 @@ class FFTAligner(TransformerMixin):
         return self.best_offset_
 
 
-class _MaxScoreStandIn(TransformerMixin):
-    """What ``MaxScoreAligner`` needs around ``fit`` when ffsubsync is not installed (aligners.py:89-129, 154-167):
-    the constructor contract of SURVEY 8b, the golden-section wrapper and the pick of the best candidate."""
+class MaxScoreAligner(TransformerMixin):
+    """aligners.py:89-167: the constructor contract of SURVEY 8b, ``fit`` re-done for the device -- all candidate
+    substrings / pipelines of a call (one per framerate ratio) go through ONE batched solve --, the golden-section wrapper
+    and the pick of the best candidate.  ONE implementation whether or not ffsubsync is importable (the same code runs in
+    the CPU tests against the unmodified ``try_sync``, tests/test_install_real_seam.py, and on the GPU box, where
+    ffsubsync is absent); only ``TransformerMixin`` and the exception class are the reference's own when it is there."""
 
     def __init__(self, base_aligner, srtin: Optional[str] = None, sample_rate=None, max_offset_seconds=None) -> None:
         have_window = sample_rate is not None and max_offset_seconds is not None
@@ -239,12 +286,6 @@ class _MaxScoreStandIn(TransformerMixin):
                 % (self.max_offset_seconds,))
         best = max(kept, key=lambda entry: entry[0][0])  # first of equal scores, like the reference's max()
         return best[0], best[1]
-
-
-class MaxScoreAligner(_ref_aligners.MaxScoreAligner if _ref_aligners is not None else _MaxScoreStandIn):
-    """aligners.py:89-167 with ``fit`` re-done for the device: all candidate substrings / pipelines of a call (one per
-    framerate ratio) go through ONE batched solve.  Constructor, ``fit_gss`` and ``transform`` are the reference's own
-    when ffsubsync is importable (this class derives from its ``MaxScoreAligner``), the stand-in's otherwise."""
 
     def fit(self, refstring, subpipes: Union[Pipeline, List[Pipeline]]) -> "MaxScoreAligner":
         if not isinstance(subpipes, list):

@@ -102,6 +102,44 @@ def pack_pairs(pairs, packed: bool = True) -> DeviceBatch:
     return DeviceBatch(data, offs, lens, lo, hi, _native.FFS_DTYPE_U1 if packed else _native.FFS_DTYPE_U8)
 
 
+class TrackSet:
+    """Subtitle tracks ((start_us, end_us, is_metadata) triples) laid out once for repeated batched rasterisation: the
+    concatenated interval tables and each track's extent stay on the host, ``rasterize`` turns any selection of
+    (track, ratio) vectors into bit-packed rasters with ONE ``ffs_rasterize_batch_bits`` call."""
+
+    def __init__(self, tracks) -> None:
+        self.counts = np.array([len(t[0]) for t in tracks], dtype=np.int64)
+        self.firsts = (np.concatenate([[0], np.cumsum(self.counts)[:-1]]).astype(np.int64) if len(tracks)
+                       else np.zeros(0, np.int64))
+        cat = lambda k, dt: (np.concatenate([np.asarray(t[k], dtype=dt) for t in tracks]) if len(tracks) else np.zeros(0, dt))
+        self.start_us, self.end_us = cat(0, np.int64), cat(1, np.int64)
+        if all(t[2] is None for t in tracks):
+            self.meta = None
+        else:  # a track without flags has no metadata lines
+            self.meta = np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else np.asarray(t[2], dtype=np.uint8)
+                                        for t in tracks])
+        self.end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64)
+
+    def rasterize(self, track_of, ratio, sample_rate: int = 100, start_seconds: float = 0):
+        """Vector v = track ``track_of[v]`` with its times scaled by ``ratio[v]`` (``SubtitleScaler`` +
+        ``SubtitleSpeechTransformer``, speech_transformers.py:957-980).  Returns (uint8 CUDA buffer, byte offset of every
+        vector, length of every vector in samples); interval arithmetic on the device, no per-vector tensors."""
+        torch = _native.require_gpu()
+        track_of = np.asarray(track_of, dtype=np.int64).ravel()
+        ratio = np.ascontiguousarray(ratio, dtype=np.float64).ravel()
+        lens = _native.raster_lengths(self.end_max[track_of], ratio, sample_rate)
+        offs, total = _layout(lens, (lens + 31) // 32 * 4)
+        data = torch.empty(total, dtype=torch.uint8, device="cuda")
+        _native.rasterize_batch_bits(self.start_us, self.end_us, self.meta, self.firsts[track_of], self.counts[track_of], ratio,
+                                     offs // 4, lens, data, sample_rate, start_seconds)
+        return data, offs, lens
+
+
+def rasterize_vectors(tracks, track_of, ratio, sample_rate: int = 100, start_seconds: float = 0):
+    """``TrackSet(tracks).rasterize(track_of, ratio)``."""
+    return TrackSet(tracks).rasterize(track_of, ratio, sample_rate, start_seconds)
+
+
 def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 100, start_seconds: float = 0) -> DeviceBatch:
     """Bit-packed DeviceBatch straight from subtitle interval lists: ``records`` is a list of
     (reference_track, candidate_track), a track being (start_us, end_us, is_metadata) arrays
@@ -110,29 +148,15 @@ def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 10
     min(1/ratio, 1)) -- all of it by ONE ``ffs_rasterize_batch_bits`` call that writes into the batch buffer (interval
     arithmetic on the device; no per-vector tensors, no pack copy).  Same vectors as ``pack_pairs`` over
     ``subtitle_raster.rasterize_candidates``."""
-    torch = _native.require_gpu()
     ratios = [float(r) for r in ratios]
     n_pairs, n_vec = len(records), 1 + len(ratios)
     tracks = [t for rec in records for t in rec]  # track 2p: pair p's reference, 2p + 1: its candidates
-    counts = np.array([len(t[0]) for t in tracks], dtype=np.int64)
-    firsts = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.int64) if len(tracks) else np.zeros(0, np.int64)
-    cat = lambda k, dt: (np.concatenate([np.asarray(t[k], dtype=dt) for t in tracks]) if len(tracks) else np.zeros(0, dt))
-    start_us, end_us = cat(0, np.int64), cat(1, np.int64)
-    if all(t[2] is None for t in tracks):
-        meta = None
-    else:  # a track without flags has no metadata lines
-        meta = np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else np.asarray(t[2], dtype=np.uint8)
-                               for t in tracks])
-    end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64).reshape(n_pairs, 2)
     track_of = np.tile(np.array([0] + [1] * len(ratios)), (n_pairs, 1)) + 2 * np.arange(n_pairs)[:, None]
     ratio = np.tile(np.array([1.0] + ratios), (n_pairs, 1))
-    lens = _native.raster_lengths(end_max.ravel()[track_of.ravel()], ratio.ravel(), sample_rate).reshape(n_pairs, n_vec)
-    offs, total = _layout(lens, (lens + 31) // 32 * 4)
-    data = torch.empty(total, dtype=torch.uint8, device="cuda")
-    _native.rasterize_batch_bits(start_us, end_us, meta, firsts[track_of.ravel()], counts[track_of.ravel()], ratio.ravel(),
-                                 offs.ravel() // 4, lens.ravel(), data, sample_rate, start_seconds)
+    data, offs, lens = rasterize_vectors(tracks, track_of.ravel(), ratio.ravel(), sample_rate, start_seconds)
     hi = np.minimum(1.0 / ratio, 1.0)
-    return DeviceBatch(data, offs, lens, np.zeros_like(hi), hi, _native.FFS_DTYPE_U1)
+    return DeviceBatch(data, offs.reshape(n_pairs, n_vec), lens.reshape(n_pairs, n_vec), np.zeros_like(hi), hi,
+                       _native.FFS_DTYPE_U1)
 
 
 def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:

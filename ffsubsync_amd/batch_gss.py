@@ -63,14 +63,95 @@ def gss_batch(evaluate: Callable[[np.ndarray, bool], np.ndarray], n_problems: in
 
 
 def fit_gss_batch(refs: Sequence, subtitle_records: Sequence[Tuple[np.ndarray, np.ndarray, np.ndarray]],
-                  max_offset_samples=None, sample_rate: int = 100, start_seconds: float = 0):
+                  max_offset_samples=None, sample_rate: int = 100, start_seconds: float = 0, stats: dict = None):
     """``MaxScoreAligner(FFTAligner(max_offset_samples)).fit_gss`` for many files at once.
 
     refs[i]: reference activity vector of file i (array or DeviceRaster); subtitle_records[i]:
-    (start_us, end_us, is_metadata) of its subtitles.  Every step rasterises each file's track at
-    that file's current ratio on the device and solves all files in one ``ffs_align_batch`` call.
-    Returns a list of ((score, offset), ratio) -- the evaluation each file's search flagged as last,
-    which is what the reference records in ``_scores`` (aligners.py:124-125)."""
+    (start_us, end_us, is_metadata) of its subtitles.  Returns a list of ((score, offset), ratio) -- the evaluation each
+    file's search flagged as last, which is what the reference records in ``_scores`` (aligners.py:124-125).
+
+    Every search step is ONE ``ffs_rasterize_batch_bits`` call (every file's track at that file's current ratio, interval
+    arithmetic on the device) and ONE ``ffs_align_batch`` call over all files, on one plan held across the ~17 steps;
+    the reference vectors are uploaded once and stay bit-packed in HBM.  Multi-level (float) references take the
+    per-file path (``_fit_gss_batch_per_file``).  ``stats``, if given, receives {"steps", "files", "plan_length"}."""
+    from . import _native
+    from .aligners import _Vec
+    from .batch import TrackSet
+
+    n = len(refs)
+    ref_vecs = [_Vec(r) for r in refs]
+    if n == 0 or not all(v.two_level and len(v) > 0 for v in ref_vecs) or any(len(t[0]) == 0 for t in subtitle_records):
+        return _fit_gss_batch_per_file(refs, subtitle_records, max_offset_samples, sample_rate, start_seconds)
+    torch = _native.require_gpu()
+    # references: bit-packed, one buffer, uploaded once
+    words = [None if v.raster is not None else (v.packed if v.packed is not None else np.packbits(v.bits, bitorder="little"))
+             for v in ref_vecs]
+    offs = np.zeros(n, dtype=np.int64)
+    total = 0
+    for i, wv in enumerate(words):
+        if wv is not None:
+            offs[i] = total
+            total += (wv.size + 63) // 64 * 64
+    host = np.zeros(max(total, 64), dtype=np.uint8)
+    for wv, o in zip(words, offs):
+        if wv is not None:
+            host[o:o + wv.size] = wv
+    ref_dev = torch.from_numpy(host).cuda()
+    keep = [v.raster.packed_words() if v.raster is not None else None for v in ref_vecs]  # HBM-resident references, in place
+    ref_ptr = np.array([k.data_ptr() if k is not None else ref_dev.data_ptr() + int(o) for k, o in zip(keep, offs)], dtype=np.uint64)
+    ref_len = np.array([len(v) for v in ref_vecs], dtype=np.int64)
+    tracks = TrackSet(list(subtitle_records))
+    # one plan for the whole search: long enough for the longest candidate (ratio 1.1)
+    longest = _native.raster_lengths(tracks.end_max, np.full(n, MAX_FRAMERATE_RATIO), sample_rate)
+    n_fft = max(_native.plan_length(int(r), int(s), max_offset_samples) for r, s in zip(ref_len, longest))
+    if n_fft > _native.MAX_FFT_LENGTH:
+        raise ValueError("inputs too long for the device transform (N=%d > 2^24)" % n_fft)
+    plan = _native.get_plan(n_fft, pairs_in_flight=min(max(n, 1), 512), max_cand=8)
+    cand_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    pair_out = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+    lo = np.zeros(2 * n, dtype=np.float64)
+    hi = np.ones(2 * n, dtype=np.float64)
+    lo[0::2] = [v.lo for v in ref_vecs]
+    hi[0::2] = [v.hi for v in ref_vecs]
+    ptrs = np.zeros(2 * n, dtype=np.uint64)
+    lens = np.zeros(2 * n, dtype=np.int64)
+    ptrs[0::2], lens[0::2] = ref_ptr, ref_len
+    recorded = [None] * n
+    which = np.arange(n)
+    steps = [0]
+
+    def evaluate(ratios, is_last):
+        data, c_offs, c_lens = tracks.rasterize(which, ratios, sample_rate, start_seconds)
+        ptrs[1::2] = data.data_ptr() + c_offs.astype(np.uint64)
+        lens[1::2] = c_lens
+        hi[1::2] = np.minimum(1.0 / np.asarray(ratios, dtype=np.float64), 1.0)  # speech_transformers.py:977
+        plan.align_batch(n, 1, _native.FFS_DTYPE_U1, ptrs, lens, lo, hi, max_offset_samples, None, cand_out, pair_out)
+        cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:n]
+        steps[0] += 1
+        if (cres["flags"] & _native.FLAG_AMBIGUOUS).any():  # degenerate input (e.g. a silent reference): the careful path
+            raise _Ambiguous()
+        if is_last:
+            for i, ratio in enumerate(ratios):
+                recorded[i] = ((np.float64(cres[i]["score"]), int(cres[i]["offset"])), float(ratio))
+        return -cres["score"]
+
+    try:
+        gss_batch(evaluate, n)
+    except _Ambiguous:
+        return _fit_gss_batch_per_file(refs, subtitle_records, max_offset_samples, sample_rate, start_seconds)
+    if stats is not None:
+        stats.update({"steps": steps[0], "files": n, "plan_length": int(n_fft)})
+    del ref_dev, keep
+    return recorded
+
+
+class _Ambiguous(Exception):
+    pass
+
+
+def _fit_gss_batch_per_file(refs, subtitle_records, max_offset_samples=None, sample_rate: int = 100, start_seconds: float = 0):
+    """The same search with one rasterisation per file and step and the drop-in's ``solve_pairs`` (any element type,
+    ambiguity handling): what ``fit_gss_batch`` falls back to for multi-level references and degenerate inputs."""
     from .aligners import _Vec, solve_pairs
     from .subtitle_raster import rasterize_candidates
 

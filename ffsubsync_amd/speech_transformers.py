@@ -112,12 +112,10 @@ _FUSION_RULES = {  # speech_transformers.py:253-296: how two label vectors of eq
 def _make_fused_detector(sample_rate: int, frame_rate: int, non_speech_label: float,
                          fusion_strategy: str = "weighted") -> Callable[[bytes], np.ndarray]:
     """speech_transformers.py:256-296 (webrtc and silero labels combined frame by frame).  Both detectors are
-    third-party CPU arithmetic (seams): with ffsubsync installed its own factory is used; the stand-in below
-    keeps the contract -- strategies, error text, clipping to the common length, factories looked up as module
-    attributes at call time (the seam tests/test_vad_fused.py:11-18 patches) -- for boxes without it."""
-    ref = reference_module("speech_transformers")
-    if ref is not None:
-        return ref._make_fused_detector(sample_rate, frame_rate, non_speech_label, fusion_strategy)
+    third-party CPU arithmetic (seams).  ONE implementation whether or not ffsubsync is installed: strategies,
+    error text, clipping to the common length, and the two factories looked up as attributes of THIS module at call time
+    (the patch point, like the seam tests/test_vad_fused.py:11-18 patches in the reference) -- they in turn hand over to
+    the reference's CPU detectors when those are importable."""
     rule = _FUSION_RULES.get(fusion_strategy)
     if rule is None:
         raise ValueError("unknown fused VAD strategy %r; choose one of weighted, intersection, union" % (fusion_strategy,))

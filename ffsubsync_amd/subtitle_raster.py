@@ -146,14 +146,35 @@ class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBounda
         return self.subtitle_speech_results_
 
 
+def _vector_key(values):
+    """Identity of a fitted vector that survives nothing but the vector itself: the object, its shape and a cheap
+    checksum of 64 evenly spread samples + both ends (in-place edits such as DeserializeSpeechTransformer's thresholding
+    or a caller's post-processing of ``video_speech_results_`` change it)."""
+    if not isinstance(values, np.ndarray) or values.size == 0:
+        return (id(values), None, None)
+    flat = values.reshape(-1)
+    probe = flat[:: max(1, flat.size // 64)][:64]
+    return (id(values), values.shape, (float(np.sum(probe * np.arange(1, probe.size + 1))), float(flat[0]), float(flat[-1])))
+
+
 def _device_copy_of(transformer, values):
-    """The bit-packed device copy of a fitted reference vector, made once per vector (cached on the transformer)."""
+    """The bit-packed device copy of a fitted reference vector, made once per vector: cached on the transformer under
+    the vector's identity, shape and a sampled checksum, so that a vector edited in place is uploaded again."""
+    key = _vector_key(values)
     cached = transformer.__dict__.get("_ffs_device_copy")
-    if cached is not None and cached[0] is values:
+    if cached is not None and cached[0] == key:
         return cached[1]
-    raster = DeviceRaster.from_host(values) if isinstance(values, np.ndarray) else None
+    raster = None
+    if isinstance(values, np.ndarray) and values.size:
+        flat = np.ascontiguousarray(values, dtype=np.float64).ravel()
+        found = _native.two_level_pack(flat)  # the same level-detection rule as the aligner's own host path (_Vec)
+        if found is not None:
+            import torch
+
+            lo, hi, packed = found
+            raster = DeviceRaster(torch.from_numpy(packed.view(np.int32).copy()).cuda(), lo, hi, flat.size)
     out = values if raster is None else raster  # more than two levels (fused / weighted labels): the host floats
-    transformer.__dict__["_ffs_device_copy"] = (values, out)
+    transformer.__dict__["_ffs_device_copy"] = (key, out)  # (the key holds no reference to the host vector)
     return out
 
 

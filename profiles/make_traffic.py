@@ -39,8 +39,10 @@ for k, c in acc.items():
         # reads only, so its FETCH_SIZE is taken at face value (an upper-bound-free, uncalibrated figure)
         fmul = 1 if k == "pass_a" else 2
         out[k] = (fmul * fetch + write) * 1024 / ppl
+        if k.startswith("runs_"):  # raw counters next to the corrected figure (k_runs_extract's read volume is known: the bits)
+            out[k + "_raw_fetch_KB_write_KB_per_launch"] = [fetch, write]
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_per_pair.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
-data[n_dev] = out
+data.setdefault(n_dev, {}).update(out)  # (the run-boundary and the transform kernels come from separate passes)
 json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({n_dev: out}, indent=1))

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""rocprofv3 --kernel-trace --stats of profiles/secondary_kernels.py (+ optional --pmc FETCH_SIZE / WRITE_SIZE passes) ->
+per-kernel record: average duration, algorithmic bytes per launch (from the driver's JSON line), achieved GB/s, fraction
+of 8 TB/s, and the PMC-measured HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction).
+
+    python profiles/summarize_secondary.py <trace_dir> <driver_json_line_file> [pmc_dir] > profiles/r04_secondary_kernels.json
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+trace_dir, alg_file = sys.argv[1], sys.argv[2]
+pmc_dir = sys.argv[3] if len(sys.argv) > 3 else None
+alg = json.loads([l for l in open(alg_file).read().splitlines() if l.startswith("{")][-1])
+calls = collections.defaultdict(list)  # kernel name -> [duration ns] in launch order
+for f in glob.glob(trace_dir + "/**/*kernel_trace.csv", recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        if "ffsa::" in r["Kernel_Name"]:
+            calls[r["Kernel_Name"].split("ffsa::")[1].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+if pmc_dir:
+    for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "ffsa::" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
+                pmc[r["Kernel_Name"].split("ffsa::")[1].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+
+def rec(ns_list, nbytes, name=None, sl=None):
+    ns = sum(ns_list) / len(ns_list)
+    out = {"launches": len(ns_list), "avg_us": ns / 1e3, "algorithmic_bytes_per_launch": nbytes,
+           "achieved_GBps": nbytes / ns, "frac_of_8TBps": nbytes / ns / 8000.0}
+    if name in pmc and "FETCH_SIZE" in pmc[name] and "WRITE_SIZE" in pmc[name]:
+        fs, ws = pmc[name]["FETCH_SIZE"], pmc[name]["WRITE_SIZE"]
+        if sl is not None:
+            fs, ws = fs[sl], ws[sl]
+        if fs and ws:
+            out["pmc_hbm_bytes_per_launch"] = (2 * sum(fs) / len(fs) + sum(ws) / len(ws)) * 1024
+            out["pmc_over_algorithmic"] = out["pmc_hbm_bytes_per_launch"] / nbytes
+    return out
+
+
+res = {}
+for name, ns in calls.items():
+    base = name.split("<")[0]
+    if base == "k_vad_energy" and "k_vad_energy" in alg:
+        h = len(ns) // 2
+        res["k_vad_energy[fp32 labels]"] = rec(ns[:h], alg["k_vad_energy"]["bytes_per_launch_fp32_labels"], name, slice(0, h))
+        res["k_vad_energy[bit-packed labels]"] = rec(ns[h:], alg["k_vad_energy"]["bytes_per_launch_bit_labels"], name, slice(h, None))
+    elif base in alg and "bytes_per_launch" in alg[base]:
+        res[name] = rec(ns, alg[base]["bytes_per_launch"], name)
+# the transform kernels: launches come in plan order (default, windowless, reference length), two solves each
+plans = [k for k in alg if k.startswith("transforms_")]
+kind = lambda n: "pass_a" if n.startswith("k_pass_a") else "mid" if n.startswith("k_mid") else "pass_c" if n.startswith("k_pass_c") else None
+by_n = {}
+for name, ns in calls.items():
+    k = kind(name)
+    if k is None or (", true>" in name and "pruned" in name) or name.startswith("k_pass_c<") and ", 2>" in name:
+        continue
+    by_n[name] = (k, ns)
+res["transform_kernels"] = {name: {"role": k, "launches": len(ns), "avg_us": sum(ns) / len(ns) / 1e3} for name, (k, ns) in by_n.items()}
+res["transform_plans"] = {p: alg[p] for p in plans}
+print(json.dumps(res, indent=1, sort_keys=True))

@@ -245,3 +245,28 @@ def test_dense_vectors_fall_back_to_the_transforms_per_sub_batch(torch):
     d, st1 = _solve(db, n_fft, 6000, "runs", n_cand=2, pairs_in_flight=2)
     assert st1 == (1, 2, 1)
     _same_records(d, b)
+
+
+def test_host_batch_entry_equals_one_call_per_problem(torch):
+    """aligners.solve_host_batch (many files' float64 arrays -> threaded packing -> one upload -> one ffs_align_batch)
+    against MaxScoreAligner.fit_transform one problem at a time; a three-level reference in the batch sends that call
+    down the float64 path, with the same answers."""
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner, solve_host_batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(300 + i, duration_s=1800.0) for i in range(5)]
+    problems = [synth.pair_float_arrays(sp) for sp in specs]
+    cres, pres = solve_host_batch(problems, 6000, 6000)
+    for i, (ref, cands) in enumerate(problems):
+        cands = list(cands)
+        (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(ref, cands)
+        assert cands[int(pres[i]["best_cand"])] is winner and int(pres[i]["offset"]) == offset
+        assert float(pres[i]["score"]) == float(score)
+        assert int(pres[i]["best_cand"]) == specs[i].true_ratio_index
+    ref3 = problems[0][0].copy()
+    ref3[::1000] = 0.5
+    c3, p3 = solve_host_batch([(ref3, problems[0][1])] + problems[1:], 6000, 6000)
+    assert int(p3[0]["best_cand"]) == specs[0].true_ratio_index
+    for f in ("best_cand", "offset"):
+        assert np.array_equal(p3[f][1:], pres[f][1:])
+    assert np.allclose(p3["score"][1:], pres["score"][1:], rtol=1e-12)
