@@ -323,15 +323,28 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
             else
                 while (Q[lb0] < x[0]) ++lb0;  // the sentinel stops the walk
             const int xe = x_last + wmax;
+            const unsigned wlim = wmax >= 0 ? (unsigned)wmax : 0u;  // (a one-lag tile never reads h: a stray add at 0 is harmless)
             int qq = Q[lb0];
-            for (int j = lb0; qq <= xe; ++j) {
+            int j = lb0;
+            // boundaries in front of the group's last position also count towards the lower bounds of its members
+            for (; qq < x_last; ++j) {
                 const int qn = Q[j + 1];
                 const int sq = (j & 1) ? -1 : 1;
 #pragma unroll
                 for (int i = 0; i < RUNS_PC; ++i) {
                     const int d = qq - x[i];
                     cnt[i] += d < 0;
-                    if (d >= 0 && d <= wmax) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
+                    if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
+                }
+                qq = qn;
+            }
+            for (; qq <= xe; ++j) {
+                const int qn = Q[j + 1];
+                const int sq = (j & 1) ? -1 : 1;
+#pragma unroll
+                for (int i = 0; i < RUNS_PC; ++i) {
+                    const int d = qq - x[i];
+                    if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
                 }
                 qq = qn;
             }
