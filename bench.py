@@ -133,7 +133,19 @@ def vad_figures(torch, _native, minutes=90.0, iters=20):
     vo.chunked_detect(pcm[:cpu_n].cpu().numpy())
     cpu_s = time.perf_counter() - t1
     lo, hi = _native.speech_bounds(labels)
+    # the rocprofv3 record of the same kernel on the same workload (profiles/secondary_kernels.py under --kernel-trace and
+    # --pmc FETCH_SIZE / WRITE_SIZE; refreshed by profiles/refresh_all.sh): duration, HBM bytes measured vs algorithmic
+    rocprof = None
+    spath = os.path.join(ROOT, "profiles", "r04_secondary_kernels.json")
+    if os.path.exists(spath):
+        sj = json.load(open(spath))
+        rocprof = {k: {kk: v[kk] for kk in ("avg_us", "achieved_GBps", "frac_of_8TBps", "pmc_hbm_bytes_per_launch", "pmc_over_algorithmic")
+                       if kk in v} for k, v in sj.items() if k.startswith("k_vad_energy")}
+        rocprof["source"] = "profiles/r04_secondary_kernels.json (rocprofv3 --kernel-trace --stats + --pmc FETCH_SIZE / WRITE_SIZE)"
     return {
+        "roofline": {"kernel": "k_vad_energy", "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": bytes_ / (ms * 1e-3) / HBM_PEAK, "bytes_per_launch": bytes_, "avg_launch_ms": ms,
+                     "timed_with": "torch.cuda events on the launch stream around %d launches" % iters, "rocprofv3": rocprof},
         "workload": "one %.0f-min 48 kHz s16le file in HBM (%d samples, %d frames)" % (minutes, n, n_frames),
         "kernel": "k_vad_energy",
         "ms_per_file": ms,

@@ -218,6 +218,23 @@ FFS_DEV int lower_bound_i32(const int* a, int n, int x) {  // first k with a[k] 
     return lo;
 }
 
+// the same search by a whole wave (every lane passes the same arguments): 64 probes per step, three dependent loads
+// for a list of 32 768 entries instead of fifteen
+FFS_DEV int wave_lower_bound_i32(const int* __restrict__ a, int n, int x) {
+    const int lane = threadIdx.x & 63;
+    int lo = 0, len = n;  // the answer lies in [lo, lo + len]
+    while (len > 0) {
+        const int step = (len + 63) >> 6;
+        const int idx = lo + (lane + 1) * step - 1;  // last element of this lane's sub-range
+        const bool below = idx < lo + len && a[idx] < x;
+        const int c = __popcll(__ballot(below));  // sub-ranges that lie entirely below x (a prefix of the lanes)
+        const int end = lo + len;
+        lo += c * step;
+        len = (step - 1) < (end - lo) ? (step - 1) : (end - lo);
+    }
+    return lo;
+}
+
 // exclusive scan over the 256 threads of a block of three ints at once (s_tmp: 4 x 3 ints); wrap-around arithmetic
 FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -279,97 +296,113 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
     const int* __restrict__ Pg = rq + (size_t)vs * cap;
     const int* __restrict__ Qg = rq + (size_t)vr * cap;
     const int* __restrict__ CQg = rc + (size_t)vr * cap;
-    const bool staged = n_q <= RUNS_QCAP;
+    const bool whole = n_q <= RUNS_QCAP;  // the reference's whole list fits the staging area
     // ones of rho in [0, x) = sum_k sgn_k * min(x, Q[k]) (sgn = -1 at run starts, +1 at run ends): the two positions
     // that bound the overlap at lag D0
     const int r_lo = D0 > 0 ? D0 : 0, r_hi = (S + D0) < R ? (S + D0) : R;
     int rsum = 0;
     for (int k = tid; k <= n_q; k += 256) {
         const int qv = Qg[k];
-        if (staged) q_lds[k] = qv;
+        if (whole) q_lds[k] = qv;
         if (k < n_q) {
             const int m_hi = qv < r_hi ? qv : r_hi, m_lo = qv < r_lo ? qv : r_lo;
             rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
         }
     }
-    if (staged && tid == 0) q_lds[n_q + 1] = INT32_MAX;  // the walk reads one entry ahead
     for (int i = tid; i < RUNS_T / 2 + 2; i += 256) hist[i] = 0u;
     __syncthreads();
     const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
+    const int wmax = Wt - 2;                                 // h is needed for the lags D0 .. D1 - 1
+    const unsigned wlim = wmax >= 0 ? (unsigned)wmax : 0u;  // (a one-lag tile never reads h: a stray add at 0 is harmless)
     int n11p = 0, gp = 0, bsum = 0;
-    // A thread owns a contiguous, even-aligned share of the candidate's boundaries and takes them RUNS_PC at a time
-    // (positions in registers): the boundaries q that any of them can meet inside the tile form ONE stretch of the
-    // reference's list, so every q is read once per group and tested against the RUNS_PC positions without a dependent
-    // load in between; the additions are fire-and-forget LDS atomics.  The same walk counts, for every p, the q's in
-    // front of p + D0 -- its lower bound, which gives the ones of the reference in front of p + D0 (n11(D0)) and their
-    // parity (g(D0)).
-    auto accumulate = [&](auto Q) {
-        const int per = ((n_p + 255) / 256 + 1) & ~1;
-        const int k0 = tid * per, k1 = (k0 + per) < n_p ? (k0 + per) : n_p;
-        const int wmax = Wt - 2;  // h is needed for the lags D0 .. D1 - 1
-        int lb0 = 0;
-        for (int kc = k0; kc < k1; kc += RUNS_PC) {
-            int x[RUNS_PC], cnt[RUNS_PC];
-            int x_last = 0;
+    // One group = RUNS_PC consecutive boundaries p of the candidate, positions in registers: the boundaries q that any of
+    // them can meet inside the tile form ONE stretch of the reference's list, so every q is read once per group and tested
+    // against the RUNS_PC positions without a dependent load in between; the additions are fire-and-forget LDS atomics.
+    // The same walk counts, for every p, the q's in front of p + D0 -- its lower bound, which gives the ones of the
+    // reference in front of p + D0 (n11(D0)) and their parity (g(D0)).  Q is indexed absolutely; [lo, hi] is the stretch
+    // that is readable through it (the staged slice, or the whole list in global memory).
+    auto group = [&](auto Q, int kc, int k1, int lo, int hi) {
+        int x[RUNS_PC], cnt[RUNS_PC];
+        int x_last = 0;
+#pragma unroll
+        for (int i = 0; i < RUNS_PC; ++i) {
+            const bool valid = kc + i < k1;
+            x[i] = valid ? Pg[kc + i] + D0 : 0x3fffffff;  // never met: q - x < 0 for every real boundary
+            cnt[i] = 0;
+            if (valid) x_last = x[i];
+        }
+        const int lb0 = lo + lower_bound_i32(Q + lo, hi - lo, x[0]);
+        const int xe = x_last + wmax;
+        int qq = Q[lb0];
+        int j = lb0;
+        // boundaries in front of the group's last position also count towards the lower bounds of its members
+        for (; qq < x_last; ++j) {
+            const int qn = Q[j + 1];
+            const int sq = (j & 1) ? -1 : 1;
 #pragma unroll
             for (int i = 0; i < RUNS_PC; ++i) {
-                const bool valid = kc + i < k1;
-                x[i] = valid ? Pg[kc + i] + D0 : 0x3fffffff;  // never met: q - x < 0 for every real boundary
-                cnt[i] = 0;
-                if (valid) x_last = x[i];
+                const int d = qq - x[i];
+                cnt[i] += d < 0;
+                if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
             }
-            if (kc == k0)
-                lb0 = lower_bound_i32(Q, n_q, x[0]);
-            else
-                while (Q[lb0] < x[0]) ++lb0;  // the sentinel stops the walk
-            const int xe = x_last + wmax;
-            const unsigned wlim = wmax >= 0 ? (unsigned)wmax : 0u;  // (a one-lag tile never reads h: a stray add at 0 is harmless)
-            int qq = Q[lb0];
-            int j = lb0;
-            // boundaries in front of the group's last position also count towards the lower bounds of its members
-            for (; qq < x_last; ++j) {
-                const int qn = Q[j + 1];
-                const int sq = (j & 1) ? -1 : 1;
-#pragma unroll
-                for (int i = 0; i < RUNS_PC; ++i) {
-                    const int d = qq - x[i];
-                    cnt[i] += d < 0;
-                    if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
-                }
-                qq = qn;
-            }
-            for (; qq <= xe; ++j) {
-                const int qn = Q[j + 1];
-                const int sq = (j & 1) ? -1 : 1;
-#pragma unroll
-                for (int i = 0; i < RUNS_PC; ++i) {
-                    const int d = qq - x[i];
-                    if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
-                }
-                qq = qn;
-            }
-            const int lb_first = lb0;
+            qq = qn;
+        }
+        for (; qq <= xe; ++j) {
+            const int qn = Q[j + 1];
+            const int sq = (j & 1) ? -1 : 1;
 #pragma unroll
             for (int i = 0; i < RUNS_PC; ++i) {
-                if (kc + i < k1) {
-                    const int lb = lb_first + cnt[i];
-                    const int sp = (i & 1) ? -1 : 1;  // db[p]: the share starts at an even index
-                    int ones = CQg[lb];
-                    if (lb & 1) ones -= Q[lb] - x[i];  // inside a run: the run's ones from x on are not in front of x
-                    n11p -= sp * ones;
-                    gp -= sp * (lb & 1);
-                    const int p = x[i] - D0;
-                    const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
-                    bsum -= sp * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
-                    lb0 = lb;  // the next group starts its walk here
-                }
+                const int d = qq - x[i];
+                if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
+            }
+            qq = qn;
+        }
+#pragma unroll
+        for (int i = 0; i < RUNS_PC; ++i) {
+            if (kc + i < k1) {
+                const int lb = lb0 + cnt[i];
+                const int sp = (i & 1) ? -1 : 1;  // db[p]: groups start at even indices
+                int ones = CQg[lb];
+                if (lb & 1) ones -= Q[lb] - x[i];  // inside a run: the run's ones from x on are not in front of x
+                n11p -= sp * ones;
+                gp -= sp * (lb & 1);
+                const int p = x[i] - D0;
+                const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
+                bsum -= sp * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
             }
         }
     };
-    if (staged)
-        accumulate((const int*)q_lds);
-    else
-        accumulate(Qg);
+    // Rounds of 256 groups (2048 consecutive candidate boundaries).  A reference list that does not fit the staging area
+    // is staged slice by slice: the q's a round can meet are one stretch [first q >= P[first] + D0, first q beyond
+    // P[last] + D1], found by two wave-wide 64-ary searches; only a round whose stretch is still too long (a reference
+    // far denser than the candidate) walks the list in global memory.
+    constexpr int ROUND = 256 * RUNS_PC;
+    int st_lo = 0, st_hi = n_q;
+    bool staged_ok = whole;
+    for (int rs = 0; rs < n_p; rs += ROUND) {
+        const int re = (rs + ROUND) < n_p ? (rs + ROUND) : n_p;
+        if (!whole) {
+            __syncthreads();  // the previous round is done with the staged slice
+            if (tid < 128) {
+                const int xq = (tid < 64) ? Pg[rs] + D0 : Pg[re - 1] + D0 + (int)wlim + 1;
+                const int v = wave_lower_bound_i32(Qg, n_q, xq);
+                if ((tid & 63) == 0) s_tmp[tid >> 6] = v;
+            }
+            __syncthreads();
+            st_lo = s_tmp[0], st_hi = s_tmp[1];
+            staged_ok = st_hi - st_lo <= RUNS_QCAP;
+            if (staged_ok)
+                for (int k = st_lo + tid; k <= st_hi; k += 256) q_lds[k - st_lo] = Qg[k];
+            __syncthreads();
+        }
+        const int kc = rs + tid * RUNS_PC;
+        if (kc < re) {
+            if (staged_ok)
+                group((const int*)q_lds - st_lo, kc, re, st_lo, st_hi);
+            else
+                group(Qg, kc, re, 0, n_q);
+        }
+    }
     // block sums of (n11p, gp, bsum, rsum)
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
