@@ -49,10 +49,7 @@ struct RunsBest {  // best lag of one (candidate, tile)
 FFS_HD bool runs_over_budget(int n_p, int n_q, long long W, long long R, int cap, long long budget) {
     if (n_p >= cap || n_q >= cap) return true;
     const long long pairs = (long long)n_p * (long long)n_q;  // < 2^30
-    // a reference list that does not fit the LDS staging area is walked in global memory: measured twice the time per
-    // coincidence (2.5e-4 instead of 1.2e-4 us*CU, profiles/r04_runs_experiments.json)
-    const long long weight = n_q > RUNS_QCAP ? 2 : 1;
-    return weight * (pairs * W / (R > 0 ? R : 1)) > budget;
+    return pairs * W / (R > 0 ? R : 1) > budget;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -205,7 +205,7 @@ struct ffs_plan {
     // transforms; FFS_ALGO_FFT never uses it; FFS_ALGO_RUNS ignores the coincidence budget (truncated lists still go
     // through the transforms).  Buffers grown on demand.
     int algo = FFS_ALGO_AUTO;
-    long long runs_budget = 0;          // boundary coincidences per candidate above which the transforms are cheaper (ffs_plan_create)
+    long long runs_budget = -1;         // FFS_RUNS_BUDGET: boundary coincidences per candidate above which the transforms take over (-1: the rule in ffs_plan_create)
     int* runs_q = nullptr;              // [vectors][RUNS_CAP] boundary positions
     int* runs_c = nullptr;              // [vectors][RUNS_CAP] ones in front of each boundary
     int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
@@ -927,10 +927,12 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
             if (!strcmp(ea, "fft")) p->algo = FFS_ALGO_FFT;
             else if (!strcmp(ea, "runs")) p->algo = FFS_ALGO_RUNS;
         }
-        // Measured break-even (profiles/r04_runs_experiments.json): k_runs_corr spends ~1.2e-4 us*CU per boundary
-        // coincidence, the transform pipeline 6-9e-4 us*CU per point of the plan length and candidate -> five
-        // coincidences per transform point (3.9 M for the window-shortened 2 h plan, 7.9 M for the windowless one).
-        p->runs_budget = 5 * n_fft;
+        // Measured break-even (profiles/r04_runs_experiments.json): k_runs_corr spends 1.2-1.6e-4 us*CU per boundary
+        // coincidence, the transform pipeline 6-9e-4 us*CU per point of the plan length and packed transform slot -> six
+        // coincidences per transform point and slot; a candidate's share of the slots is (n_cand + 1) / (2 n_cand) (two
+        // candidates per complex transform + the reference's half slot): 2.7 M for seven candidates on the
+        // window-shortened 2 h plan, 4.7 M for a single candidate.  FFS_RUNS_BUDGET=<coincidences> overrides it.
+        p->runs_budget = -1;
         if (const char* eb = getenv("FFS_RUNS_BUDGET")) p->runs_budget = atoll(eb);
         if (const char* et = getenv("FFS_HOST_TIMING")) p->host_timing = et[0] == '1';
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
@@ -1091,6 +1093,21 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
     if (n_pairs == 0) return FFS_OK;
+    {
+        // The boundary lists of the run-boundary path take 256 KiB per vector: a call with more than 65 536 vectors of
+        // bit-packed two-level samples is solved as consecutive sub-calls (results land where one call would put them).
+        const int64_t stride = 1 + (int64_t)n_cand, max_pairs = (int64_t(1) << 16) / stride > 0 ? (int64_t(1) << 16) / stride : 1;
+        if (p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U1 && ref_dt == FFS_DTYPE_U1 && n_pairs > max_pairs) {
+            for (int64_t p0 = 0; p0 < n_pairs; p0 += max_pairs) {
+                const int np = (int)((n_pairs - p0) < max_pairs ? (n_pairs - p0) : max_pairs);
+                const int rc_sub = align_impl(p, np, n_cand, ref_dt, dtype, vec_ptr + p0 * stride, vec_len + p0 * stride,
+                                              vec_lo + p0 * stride, vec_hi + p0 * stride, max_offset_samples, filter_max_offset,
+                                              cand_out_dev + p0 * n_cand, pair_out_dev + p0, hip_stream);
+                if (rc_sub) return rc_sub;
+            }
+            return FFS_OK;
+        }
+    }
     static_assert(sizeof(CandResult) == sizeof(ffs_cand_result), "ABI struct mismatch");
     static_assert(sizeof(PairResult) == sizeof(ffs_pair_result), "ABI struct mismatch");
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1321,7 +1338,9 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         bool any_fft = !runs_ok;
         if (runs_ok) {
             if ((rc = ensure_runs(p, n_vec, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0))) return rc;
-            const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4 : p->runs_budget;
+            const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4
+                                     : p->runs_budget >= 0 ? p->runs_budget
+                                                           : 6 * (long long)p->N * (n_cand + 1) / (2 * n_cand);
             {
                 ProfSpan span(p, st, FFS_K_RUNS_CORR);
                 hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(256), 0, st, dc, n_cand, p->runs_q,

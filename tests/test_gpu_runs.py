@@ -270,3 +270,33 @@ def test_host_batch_entry_equals_one_call_per_problem(torch):
     for f in ("best_cand", "offset"):
         assert np.array_equal(p3[f][1:], pres[f][1:])
     assert np.allclose(p3["score"][1:], pres["score"][1:], rtol=1e-12)
+
+
+def test_calls_beyond_65536_vectors_are_split(torch):
+    """8200 seven-candidate problems = 65 600 vectors in one ffs_align_batch call: the run-boundary path solves them as two
+    consecutive sub-calls (boundary-list workspace bounded at 65 536 vectors); records equal the transform path's."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.batch import DeviceBatch
+
+    rng = np.random.RandomState(11)
+    n_pairs, n_cand, R = 8200, 7, 4608
+    base = np.repeat(rng.rand(n_pairs, R // 64) < 0.4, 64, axis=1)                      # runs of 64 samples
+    shifts = rng.randint(-300, 300, size=(n_pairs, n_cand))
+    words_per = R // 32
+    stride_b = (words_per * 4 + 63) // 64 * 64
+    host = np.zeros((n_pairs, 1 + n_cand, stride_b), np.uint8)
+    host[:, 0, : words_per * 4] = np.packbits(base, axis=1, bitorder="little")
+    for j in range(n_cand):
+        idx = (np.arange(R)[None, :] + shifts[:, j:j + 1]) % R
+        c = np.take_along_axis(base, idx, axis=1)
+        c[:, : 50 * j] ^= True if j == 3 else False
+        host[:, 1 + j, : words_per * 4] = np.packbits(c, axis=1, bitorder="little")
+    data = torch.from_numpy(host.reshape(-1)).cuda()
+    offs = (np.arange(n_pairs * (1 + n_cand), dtype=np.int64) * stride_b).reshape(n_pairs, 1 + n_cand)
+    lens = np.full((n_pairs, 1 + n_cand), R, np.int64)
+    db = DeviceBatch(data, offs, lens, np.zeros(offs.shape), np.ones(offs.shape), _native.FFS_DTYPE_U1)
+    n_fft = db.required_fft_length(600)
+    a, st = _solve(db, n_fft, 600, "auto", pairs_in_flight=512)
+    b, _ = _solve(db, n_fft, 600, "fft", pairs_in_flight=512)
+    assert st[0] == 2 and st[2] == 0  # two sub-calls, nothing through the transforms
+    _same_records(a, b)
