@@ -736,6 +736,10 @@ def main():
     def kernel_table(ktimes, steps, n_fft, seg, cands=n_cand, ref_bytes_per_sample=None):
         mm = must_move(n_fft, seg, cands, ref_bytes_per_sample)
         last_info = dict(info_now)  # of the timed() call these kernel times belong to
+        work_pmc = {}
+        tpath_w = os.path.join(ROOT, "profiles", "traffic_per_pair.json")
+        if os.path.exists(tpath_w) and cands == n_cand:
+            work_pmc = json.load(open(tpath_w)).get("%d_work" % n_fft, {})
         per_kernel = {}
         for k, (ms, n) in ktimes.items():
             if n == 0:
@@ -752,6 +756,8 @@ def main():
                 entry["boundaries_per_vector"] = last_info["boundaries_last_call"] / (last_info["pairs_per_call"] * (1.0 + cands))
             if k == "runs_corr":
                 entry["bound"] = "LDS atomics (one ds_add_u32 per boundary coincidence inside the lag window) -- not an HBM kernel"
+            if k in work_pmc:  # wave-instructions and LDS-array cycles per pair from the PMC passes (profiles/make_traffic.py)
+                entry["pmc_work_per_pair"] = work_pmc[k]
             if k in mm:
                 entry["must_move_bytes_per_launch"] = mm[k] * pairs_per_launch
                 entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9

@@ -44,6 +44,40 @@ struct RunsBest {  // best lag of one (candidate, tile)
     int32_t pad[2];
 };
 
+struct PackVec {  // one 0/1 byte vector of the call and where its bit-packed image goes
+    const unsigned char* src;
+    unsigned* dst;
+    int32_t len;
+    int32_t pad;
+};
+
+// FFS_DTYPE_U8 vectors of a call -> bit-packed images (bit = byte != 0), all vectors in one launch: grid =
+// vectors * chunks_per_vec workgroups, a thread makes one word from 32 bytes.  The packed copy then takes the same
+// path as FFS_DTYPE_U1 input (an eighth of the bytes for every later pass).
+__global__ __launch_bounds__(256) void k_pack_bytes_batch(const PackVec* __restrict__ vecs, int chunks_per_vec) {
+    const int v = blockIdx.x / chunks_per_vec, c = blockIdx.x - v * chunks_per_vec;
+    const PackVec pv = vecs[v];
+    const long long n = pv.len;
+    const long long w = (long long)c * 256 + threadIdx.x;
+    const long long n_words = (n + 31) >> 5;
+    if (w >= n_words) return;
+    const long long i0 = w * 32;
+    const unsigned char* __restrict__ p = pv.src + i0;
+    unsigned out = 0;
+    if (i0 + 32 <= n) {
+        unsigned wd[8];
+        __builtin_memcpy(wd, p, 32);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned t = nz_flags(wd[k]) >> 7;  // non-zero flags of four bytes at bits 0, 8, 16, 24
+            out |= (((t * 0x00204081u) >> 21) & 0xfu) << (4 * k);
+        }
+    } else {
+        for (int k = 0; k < 32 && i0 + k < n; ++k) out |= (unsigned)(p[k] != 0) << k;
+    }
+    pv.dst[w] = out;
+}
+
 // True when a candidate stays with the transform path: a truncated boundary list, or more expected boundary
 // coincidences inside its lag window than `budget`.  Integer arithmetic only -- host and device must agree.
 FFS_HD bool runs_over_budget(int n_p, int n_q, long long W, long long R, int cap, long long budget) {
@@ -251,6 +285,26 @@ FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
     a = pa, b = pb, c = pc;
 }
 
+// One workgroup per sub-batch (pairs_per_chunk pairs): flag[chunk] = some candidate of it is over budget -- the host
+// reaches the same verdict from the list lengths and sends the whole sub-batch through the transforms, so k_runs_corr
+// leaves every candidate of a flagged sub-batch alone (no work that would be thrown away).
+__global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
+                                                          int pairs_per_chunk, const int2* __restrict__ rn, int cap,
+                                                          long long budget, int* __restrict__ flags) {
+    const int ch = blockIdx.x;
+    const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
+    int over = 0;
+    for (int i = p0 * n_cand + (int)threadIdx.x; i < p1 * n_cand; i += 256) {
+        const CandDesc& cd = cands[i];
+        if (cd.flags & CAND_NO_LAGS) continue;
+        const int pair = i / n_cand;
+        const int vr = pair * (n_cand + 1), vs = vr + 1 + (i - pair * n_cand);
+        over |= runs_over_budget(rn[vs].x, rn[vr].x, (long long)cd.d_hi - cd.d_lo + 1, cd.R, cap, budget) ? 1 : 0;
+    }
+    over = __syncthreads_or(over);
+    if (threadIdx.x == 0) flags[ch] = over;
+}
+
 // grid = (candidates of the call, tiles_max); block = 256 threads; tile t of a candidate covers the lags
 // [d_lo + t*RUNS_T, ...] of its window.
 //   1. zero the tile's second-difference array (16 bits per lag in 32-bit LDS words: the sum of all additions to a
@@ -268,7 +322,8 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
                                                    const int* __restrict__ rq, const int* __restrict__ rc,
                                                    const int2* __restrict__ rn, int cap, long long budget,
                                                    NomList* __restrict__ noms, RescoreAcc* __restrict__ acc,
-                                                   RunsBest* __restrict__ best, int tiles_max) {
+                                                   RunsBest* __restrict__ best, int tiles_max,
+                                                   const int* __restrict__ chunk_flags, int pairs_per_chunk) {
     __shared__ unsigned hist[RUNS_T / 2 + 2];  // second difference h of the tile's lags, 16 bits per lag
     __shared__ int q_lds[RUNS_QCAP + 2];
     __shared__ int s_tmp[16];
@@ -284,9 +339,9 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
     const int n_tiles = (W + RUNS_T - 1) / RUNS_T;
     if (tile >= n_tiles) return;
     const int pair = ci / n_cand;
+    if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
     const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
     const int2 ns = rn[vs], nr = rn[vr];
-    if (runs_over_budget(ns.x, nr.x, W, cd.R, cap, budget)) return;  // this sub-batch goes through the transforms
     const int n_p = ns.x, n_q = nr.x, S = cd.S, R = cd.R;
     const int D0 = cd.d_lo + tile * RUNS_T;
     const int Wt = (cd.d_hi - D0 + 1) < RUNS_T ? (cd.d_hi - D0 + 1) : RUNS_T;
@@ -518,9 +573,9 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
 }
 
 // candidates whose window spans several tiles: best tile result (larger score, then larger lag = later tile)
-__global__ void k_runs_pick(const CandDesc* __restrict__ cands, int n, int n_cand, const int2* __restrict__ rn, int cap,
-                            long long budget, const RunsBest* __restrict__ best, int tiles_max,
-                            NomList* __restrict__ noms, RescoreAcc* __restrict__ acc) {
+__global__ void k_runs_pick(const CandDesc* __restrict__ cands, int n, int n_cand, const RunsBest* __restrict__ best,
+                            int tiles_max, NomList* __restrict__ noms, RescoreAcc* __restrict__ acc,
+                            const int* __restrict__ chunk_flags, int pairs_per_chunk) {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= n) return;
     const CandDesc& cd = cands[ci];
@@ -528,9 +583,7 @@ __global__ void k_runs_pick(const CandDesc* __restrict__ cands, int n, int n_can
     const int W = cd.d_hi - cd.d_lo + 1;
     const int n_tiles = (W + RUNS_T - 1) / RUNS_T;
     if (n_tiles <= 1) return;
-    const int pair = ci / n_cand;
-    const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
-    if (runs_over_budget(rn[vs].x, rn[vr].x, W, cd.R, cap, budget)) return;
+    if (chunk_flags[(ci / n_cand) / pairs_per_chunk]) return;
     RunsBest b = best[(size_t)ci * tiles_max];
     for (int t = 1; t < n_tiles; ++t) {
         const RunsBest& o = best[(size_t)ci * tiles_max + t];

@@ -211,6 +211,10 @@ struct ffs_plan {
     int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
     int2* runs_n_host = nullptr;        // pinned copy of runs_n
     size_t runs_vecs = 0;               // vectors the four buffers above have room for
+    unsigned* pack_buf = nullptr;       // bit-packed images of a call's FFS_DTYPE_U8 vectors
+    size_t pack_bytes = 0;
+    int* runs_flags = nullptr;          // [sub-batches] 1 = goes through the transforms (k_runs_chunk_flags)
+    size_t runs_flags_n = 0;
     RunsBest* runs_best = nullptr;      // [candidates][tiles] (windows wider than one tile)
     size_t runs_best_n = 0;
     hipEvent_t runs_ev = nullptr;
@@ -927,11 +931,12 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
             if (!strcmp(ea, "fft")) p->algo = FFS_ALGO_FFT;
             else if (!strcmp(ea, "runs")) p->algo = FFS_ALGO_RUNS;
         }
-        // Measured break-even (profiles/r04_runs_experiments.json): k_runs_corr spends 1.2-1.6e-4 us*CU per boundary
-        // coincidence, the transform pipeline 6-9e-4 us*CU per point of the plan length and packed transform slot -> six
-        // coincidences per transform point and slot; a candidate's share of the slots is (n_cand + 1) / (2 n_cand) (two
-        // candidates per complex transform + the reference's half slot): 2.7 M for seven candidates on the
-        // window-shortened 2 h plan, 4.7 M for a single candidate.  FFS_RUNS_BUDGET=<coincidences> overrides it.
+        // Measured break-even (profiles/r04_runs_experiments.json, `boundary_density` / `windowless` in the bench line):
+        // k_runs_corr spends 1.2-1.6e-4 us*CU per boundary coincidence, the transform pipeline 6-9e-4 us*CU per point of
+        // the plan length and packed transform slot -> eight coincidences per transform point and slot; a candidate's
+        // share of the slots is (n_cand + 1) / (2 n_cand) (two candidates per complex transform + the reference's half
+        // slot): 3.6 M for seven candidates on the window-shortened 2 h plan, 7.2 M on the windowless one.  Either path is
+        // within ~10 % of the other around the threshold.  FFS_RUNS_BUDGET=<coincidences> overrides it.
         p->runs_budget = -1;
         if (const char* eb = getenv("FFS_RUNS_BUDGET")) p->runs_budget = atoll(eb);
         if (const char* et = getenv("FFS_HOST_TIMING")) p->host_timing = et[0] == '1';
@@ -1063,6 +1068,8 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->runs_c);
     (void)hipFree(p->runs_n);
     (void)hipFree(p->runs_best);
+    (void)hipFree(p->runs_flags);
+    (void)hipFree(p->pack_buf);
     if (p->runs_n_host) (void)hipHostFree(p->runs_n_host);
     if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
     (void)hipFree(p->dev_desc);
@@ -1093,6 +1100,52 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
     if (n_pairs == 0) return FFS_OK;
+    if (p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U8 && ref_dt == FFS_DTYPE_U8) {
+        // 0/1 BYTES (the north star's literal input format): one pass packs every vector of the call to bits (bit =
+        // byte != 0, exactly the two-level reading the byte kernels apply), then the call continues as FFS_DTYPE_U1 --
+        // run-boundary path where the lists are short, transforms on an eighth of the input bytes otherwise.  Identical
+        // records (tests/test_gpu_headline.py::test_byte_inputs_give_the_same_records; FFS_ALGO_FFT keeps the byte kernels).
+        const size_t nv = (size_t)n_pairs * (1 + (size_t)n_cand);
+        std::vector<size_t> off(nv + 1, 0);
+        int64_t len_max = 1;
+        for (size_t i = 0; i < nv; ++i) {
+            if (vec_len[i] <= 0)
+                return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
+                            (long long)vec_len[i / (1 + n_cand) * (1 + n_cand)], (long long)vec_len[i]);
+            if (!vec_ptr[i]) return fail(FFS_E_INVALID, "null device pointer for pair %d", (int)(i / (1 + n_cand)));
+            off[i + 1] = off[i] + (((size_t)(vec_len[i] + 31) / 32 * 4 + 63) & ~(size_t)63);
+            if (vec_len[i] > len_max) len_max = vec_len[i];
+        }
+        hipStream_t st0 = (hipStream_t)hip_stream;
+        HIP_TRY(hipSetDevice(p->device));
+        int rc0;
+        if ((rc0 = enter_stream(p, st0))) return rc0;
+        if (off[nv] > p->pack_bytes) {
+            if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+            (void)hipFree(p->pack_buf);
+            p->pack_buf = nullptr;
+            p->pack_bytes = 0;
+            HIP_TRY(hipMalloc((void**)&p->pack_buf, off[nv] + off[nv] / 4));
+            p->pack_bytes = off[nv] + off[nv] / 4;
+        }
+        if ((rc0 = ensure_desc(p, nv * sizeof(PackVec) + 4096))) return rc0;
+        HIP_TRY(hipEventSynchronize(p->upload_done));
+        PackVec* hp = (PackVec*)p->host_desc;
+        std::vector<const void*> packed(nv);
+        for (size_t i = 0; i < nv; ++i) {
+            unsigned* dst = (unsigned*)((char*)p->pack_buf + off[i]);
+            hp[i] = PackVec{(const unsigned char*)vec_ptr[i], dst, (int32_t)vec_len[i], 0};
+            packed[i] = dst;
+        }
+        HIP_TRY(hipMemcpyAsync(p->dev_desc, hp, nv * sizeof(PackVec), hipMemcpyHostToDevice, st0));
+        HIP_TRY(hipEventRecord(p->upload_done, st0));
+        const int chunks_per_vec = (int)(((len_max + 31) / 32 + 255) / 256);
+        hipLaunchKernelGGL(k_pack_bytes_batch, dim3((unsigned)(nv * chunks_per_vec)), dim3(256), 0, st0, (const PackVec*)p->dev_desc,
+                           chunks_per_vec);
+        HIP_TRY(hipGetLastError());
+        return align_impl(p, n_pairs, n_cand, FFS_DTYPE_U1, FFS_DTYPE_U1, packed.data(), vec_len, vec_lo, vec_hi, max_offset_samples,
+                          filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+    }
     {
         // The boundary lists of the run-boundary path take 256 KiB per vector: a call with more than 65 536 vectors of
         // bit-packed two-level samples is solved as consecutive sub-calls (results land where one call would put them).
@@ -1340,14 +1393,25 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             if ((rc = ensure_runs(p, n_vec, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0))) return rc;
             const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4
                                      : p->runs_budget >= 0 ? p->runs_budget
-                                                           : 6 * (long long)p->N * (n_cand + 1) / (2 * n_cand);
+                                                           : 8 * (long long)p->N * (n_cand + 1) / (2 * n_cand);
+            if ((size_t)n_chunks > p->runs_flags_n) {
+                if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+                (void)hipFree(p->runs_flags);
+                p->runs_flags = nullptr;
+                p->runs_flags_n = 0;
+                HIP_TRY(hipMalloc((void**)&p->runs_flags, ((size_t)n_chunks + 64) * sizeof(int)));
+                p->runs_flags_n = (size_t)n_chunks + 64;
+            }
             {
                 ProfSpan span(p, st, FFS_K_RUNS_CORR);
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
+                                   p->pairs_in_flight, p->runs_n, RUNS_CAP, budget, p->runs_flags);
                 hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(256), 0, st, dc, n_cand, p->runs_q,
-                                   p->runs_c, p->runs_n, RUNS_CAP, budget, dn, da, p->runs_best, tiles_max);
+                                   p->runs_c, p->runs_n, RUNS_CAP, budget, dn, da, p->runs_best, tiles_max, p->runs_flags,
+                                   p->pairs_in_flight);
                 if (tiles_max > 1)
                     hipLaunchKernelGGL(k_runs_pick, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, (int)n_cands, n_cand,
-                                       p->runs_n, RUNS_CAP, budget, p->runs_best, tiles_max, dn, da);
+                                       p->runs_best, tiles_max, dn, da, p->runs_flags, p->pairs_in_flight);
             }
             HIP_TRY(hipGetLastError());
             if (p->host_timing) ht2 = now_ns();

@@ -149,7 +149,7 @@ int ffs_align_batch_typed(ffs_plan* plan, int n_pairs, int n_cand, const int32_t
  *     window, no transform (csrc/ffs_runs.h) -- and the call waits once (an event, not the stream) for the lengths of the
  *     boundary lists; sub-batches (pairs_in_flight pairs) holding a vector with 32 767 boundaries or more, or a candidate
  *     whose expected number of boundary coincidences inside its lag window (boundaries of the candidate x boundaries of
- *     the reference x window lags / reference length) exceeds the budget -- by default six per point of the plan's
+ *     the reference x window lags / reference length) exceeds the budget -- by default eight per point of the plan's
  *     transform length and packed transform slot the candidate occupies, (n_cand + 1) / (2 n_cand) of one: the measured
  *     break-even -- are solved by the transforms instead.  Every other element type goes through the transforms.
  *   FFS_ALGO_FFT: transforms only (the path of rounds 1-3).

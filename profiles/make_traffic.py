@@ -17,6 +17,10 @@ import sys
 
 pmc_dir, n_dev, ppl = sys.argv[1], sys.argv[2], float(sys.argv[3])
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+# wave-instruction and LDS-array counters (summed over the device by rocprofv3), reported per pair next to the bytes
+SQ_NAMES = ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_LDS_IDX_ACTIVE",
+            "SQ_LDS_BANK_CONFLICT", "SQ_WAVES")
 for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         kn = row["Kernel_Name"]
@@ -26,6 +30,10 @@ for f in glob.glob(pmc_dir + "/*/*_counter_collection.csv"):
             continue
         if "k_pass_c<" in kn and ", 2>" in kn:
             continue
+        if "ffsa::k_" in kn and row["Counter_Name"] in SQ_NAMES:
+            k = kn.split("ffsa::k_")[1].split("<")[0].split("(")[0]
+            k = k.replace("pass_a3", "pass_a").replace("pass_c3", "pass_c").replace("pass_c_pruned", "pass_c").replace("mid_seg_one", "mid").replace("mid_seg_pipe", "mid").replace("mid_seg", "mid")
+            sq[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
         if "ffsa::k_" in kn and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
             k = row["Kernel_Name"].split("ffsa::k_")[1].split("<")[0].split("(")[0]
             k = k.replace("pass_a3", "pass_a").replace("pass_c3", "pass_c").replace("pass_c_pruned", "pass_c").replace("mid_seg_one", "mid").replace("mid_seg_pipe", "mid").replace("mid_seg", "mid")  # bench.py's kernel ids
@@ -41,8 +49,12 @@ for k, c in acc.items():
         out[k] = (fmul * fetch + write) * 1024 / ppl
         if k.startswith("runs_"):  # raw counters next to the corrected figure (k_runs_extract's read volume is known: the bits)
             out[k + "_raw_fetch_KB_write_KB_per_launch"] = [fetch, write]
+work = {k: {c.replace("SQ_", "").lower() + "_per_pair": sum(v) / len(v) / ppl for c, v in cs.items()} for k, cs in sq.items()
+        if k in ("pass_a", "mid", "pass_c", "nominees", "rescore", "runs_extract", "runs_corr")}
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic_per_pair.json")
 data = json.load(open(path)) if os.path.exists(path) else {}
 data.setdefault(n_dev, {}).update(out)  # (the run-boundary and the transform kernels come from separate passes)
+if work:
+    data.setdefault(n_dev + "_work", {}).update(work)
 json.dump(data, open(path, "w"), indent=1, sort_keys=True)
 print(json.dumps({n_dev: out}, indent=1))

@@ -300,3 +300,22 @@ def test_calls_beyond_65536_vectors_are_split(torch):
     b, _ = _solve(db, n_fft, 600, "fft", pairs_in_flight=512)
     assert st[0] == 2 and st[2] == 0  # two sub-calls, nothing through the transforms
     _same_records(a, b)
+
+
+def test_byte_inputs_are_packed_on_the_device_and_take_the_same_path(headline):
+    """FFS_DTYPE_U8 batches (one 0/1 byte per frame, the north star's literal input format): auto packs every vector to
+    bits in one launch and continues as FFS_DTYPE_U1 -- same records as the bit-packed batch and as the byte transform
+    kernels (FFS_ALGO_FFT), run-boundary path taken."""
+    from workloads import synth
+
+    specs, db, gold = headline
+    n = 24
+    db8 = synth.build_device_batch(specs[:n], packed=False)
+    db1 = synth.build_device_batch(specs[:n])
+    n_fft = db8.required_fft_length(6000)
+    a, st = _solve(db8, n_fft, 6000, "auto", pairs_in_flight=8)
+    b, _ = _solve(db1, n_fft, 6000, "auto", pairs_in_flight=8)
+    c, st_c = _solve(db8, n_fft, 6000, "fft", pairs_in_flight=8)
+    assert st == (1, 3, 0) and st_c == (0, 0, 0)
+    _same_records(a, b)
+    _same_records(a, c)
