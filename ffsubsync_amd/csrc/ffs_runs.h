@@ -103,6 +103,7 @@ FFS_DEV unsigned wave_incl_scan_u32(unsigned v) {  // inclusive prefix sum over 
     FFS_DPP_ADD(0x118, 0xf);  // row_shr:8   -> inclusive inside every row of 16 lanes
     FFS_DPP_ADD(0x142, 0xa);  // row_bcast:15 -> rows 1 and 3 add the total of the row in front
     FFS_DPP_ADD(0x143, 0xc);  // row_bcast:31 -> rows 2 and 3 add the total of rows 0 + 1
+    // (the same six steps as one inline-asm v_add_u32_dpp each -- with the s_nop the DPP hazard needs -- measured 10 % slower)
 #undef FFS_DPP_ADD
     return v;
 }
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
     const int len = vecs[v].len;
     int* __restrict__ q = rq + (size_t)v * cap;
     int* __restrict__ cq = rc + (size_t)v * cap;
+    const gptr qb = (gptr)q, cqb = (gptr)cq;
     const int nw = (len + 31) >> 5;     // words that hold samples
     const int n_proc = (len >> 5) + 1;  // word len/32 holds position `len`, where a run that reaches the end closes
     const unsigned tail = (len & 31) ? ((1u << (len & 31)) - 1u) : 0xffffffffu;  // valid bits of word nw - 1
@@ -197,9 +199,9 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
                     unsigned ee = e[g][k];
                     while (ee) {
                         const int b = __builtin_ctz(ee);
-                        if (k_out < cap) {
-                            q[k_out] = 32 * (w0 + k) + b;
-                            cq[k_out] = ones + __popc(x[g][k] & ((1u << b) - 1u));
+                        if (k_out < cap) {  // (scalar list base + 32-bit byte offset: no 64-bit address arithmetic per store)
+                            *(__attribute__((address_space(1))) int*)(qb + 4u * (unsigned)k_out) = 32 * (w0 + k) + b;
+                            *(__attribute__((address_space(1))) int*)(cqb + 4u * (unsigned)k_out) = ones + __popc(x[g][k] & ((1u << b) - 1u));
                         }
                         ++k_out;
                         ee &= ee - 1;
