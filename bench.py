@@ -311,7 +311,7 @@ def drop_in_figures(torch, specs, n=12):
     out["recovered_ratio"] = "%d/%d" % (sum(a[2] == sp.true_ratio_index for a, sp in zip(answers["device_rasters"], specs)), n)
     out["what"] = ("MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform, one 2 h x 7-ratio problem per call, %d problems; "
                    "the unmodified reference needs ~2.9 s for the same call in the build container "
-                   "(profiles/r02_cpu_reference_baseline.json)" % n)
+                   "(profiles/r04_cpu_reference_baseline.json)" % n)
     return out
 
 
@@ -1163,7 +1163,7 @@ def main():
                       "aligners.py:50-167 (oracle/aligners_oracle.py, golden-pinned to the unmodified reference), single "
                       "thread" % (n_s, n_s - 1, len(runs), "/".join("%.1f" % r for r in runs)),
             "host_cpus": os.cpu_count(),
-            "unmodified_reference_in_build_container": "profiles/r02_cpu_reference_baseline.json",
+            "unmodified_reference_in_build_container": "profiles/r04_cpu_reference_baseline.json (0.36 solves/s on one process)",
         }
         result["offset_match"]["gpu_equals_cpu_oracle_on_sample"] = bool(agree)
         # SURVEY 8(d) baseline (ii): the same restatement on many host cores at once (separate process: it
