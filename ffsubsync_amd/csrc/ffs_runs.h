@@ -13,10 +13,11 @@
 // so all lags of a tile [D0, D1] follow from n11(D0), g(D0) and the sparse second difference h by two running sums.
 // Everything is integer arithmetic: the counts are exact, the scores are the same fp64 expression the transform path
 // evaluates for its nominees, the maximum is taken over EVERY lag of the window (ties to the largest lag = the first
-// k of np.argmax, aligners.py:45-48).  Work ~ |P| * |Q| * W / R boundary coincidences per candidate (W lags): 1e5 for
+// k of np.argmax, aligners.py:45-48).  Work ~ |P| * |Q| * W / R boundary coincidences per candidate (W lags): 5e4 for
 // subtitle-like vectors under the production window of +-60 s, against ~2e8 flops of the transform path.  Dense vectors
-// (more than RUNS_CAP - 1 boundaries, or a coincidence count above the budget) go through the transforms as before;
-// the rule is evaluated identically on the host and on the device (runs_over_budget).
+// (more than RUNS_CAP - 1 boundaries, or a coincidence count above the budget) go through the transforms as before,
+// a whole sub-batch at a time; the rule is evaluated identically on the host and on the device (runs_over_budget,
+// k_runs_chunk_flags).
 //
 // Index arithmetic modelled in oracle/runs_model.py (CPU-tested against a direct evaluation).
 #pragma once
@@ -26,7 +27,7 @@ namespace ffsa {
 
 constexpr int RUNS_T = 12288;            // lags per tile = per workgroup (the +-6000-lag production window is one tile)
 constexpr int RUNS_LPT = RUNS_T / 256;   // consecutive lags per thread in the scan phase
-constexpr int RUNS_QCAP = 3580;          // reference boundaries staged in LDS (longer lists are read from global memory)
+constexpr int RUNS_QCAP = 3580;          // reference boundaries staged in LDS at a time (longer lists: slice by slice)
 constexpr int RUNS_PC = 8;               // candidate boundaries a thread holds in registers per walk
 constexpr int RUNS_CAP = 32768;          // boundary-list entries per vector incl. the sentinel: also keeps |h(d)| < 2^15
 static_assert(RUNS_LPT % 2 == 0 && RUNS_LPT <= 64, "two lags per LDS word, one 64-bit mask per chunk");
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
 //   4. every lag is scored with exact_score()'s expression; block argmax, ties to the largest lag.
 __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ cands, int n_cand,
                                                    const int* __restrict__ rq, const int* __restrict__ rc,
-                                                   const int2* __restrict__ rn, int cap, long long budget,
+                                                   const int2* __restrict__ rn, int cap,
                                                    NomList* __restrict__ noms, RescoreAcc* __restrict__ acc,
                                                    RunsBest* __restrict__ best, int tiles_max,
                                                    const int* __restrict__ chunk_flags, int pairs_per_chunk) {

@@ -1407,7 +1407,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
                                    p->pairs_in_flight, p->runs_n, RUNS_CAP, budget, p->runs_flags);
                 hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(256), 0, st, dc, n_cand, p->runs_q,
-                                   p->runs_c, p->runs_n, RUNS_CAP, budget, dn, da, p->runs_best, tiles_max, p->runs_flags,
+                                   p->runs_c, p->runs_n, RUNS_CAP, dn, da, p->runs_best, tiles_max, p->runs_flags,
                                    p->pairs_in_flight);
                 if (tiles_max > 1)
                     hipLaunchKernelGGL(k_runs_pick, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, (int)n_cands, n_cand,
