@@ -12,7 +12,9 @@ resident in HBM (bit-packed, FFS_DTYPE_U1), plus the RCCL all-gather of the 24-b
 N > 1.  Pairs are sharded by rank, no data exchange during solves.  `--scaling weak` (default): every
 rank owns --pairs problems; `--scaling strong`: the same --pairs problems are split over the ranks
 (BASELINE configs[3]).  With --gpus N > 1 and no launcher in the environment the script starts itself
-under torch.distributed.run (one process per GPU).  Prints ONE JSON line on rank 0.
+under torch.distributed.run (one process per GPU).  Rank 0 prints the full record on a `# detail:` line (and writes
+bench_detail.json), then -- LAST -- one compact JSON line below 4 KB: the bench contract's fields, `roofline`,
+`cpu_baseline` and the scalars of the secondary legs (the driver parses the last line of an 8 KB tail).
 """
 import argparse
 import json
@@ -62,6 +64,127 @@ def parse():
                     help="force the reference's transform length N=2^ceil(log2(R+S)) instead of the shorter "
                          "alias-free length the lag window allows")
     return ap.parse_args()
+
+
+def _num(x, digits=6):
+    """Shorten a float for the compact line (the full precision stays in the detail record)."""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def _pick(d, *path):
+    for p in path:
+        if not isinstance(d, dict) or p not in d:
+            return None
+        d = d[p]
+    return _num(d)
+
+
+COMPACT_LIMIT = 4096  # bytes: the driver keeps the last 8 KB of stdout and parses the last line (VERDICT r4, item 1)
+
+
+def compact_record(result, detail_path=None):
+    """The LAST stdout line: the bench contract's fields, `roofline` of the dominant kernel, `cpu_baseline`, and the
+    scalars of the secondary legs -- always below COMPACT_LIMIT bytes.  The full record (kernel tables, notes, every
+    secondary leg) goes to `bench_detail.json` and to an earlier `# detail:` line."""
+    cfg = result.get("config", {})
+    out = {k: _num(result.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    if "error" in result:
+        out["error"] = str(result["error"])[:300]
+    out["config"] = {k: cfg.get(k) for k in ("workload", "algorithm", "path", "pairs_per_gpu", "pairs_in_flight", "n_fft_reference",
+                                             "n_fft_device", "input_format", "parallelism", "gather_fallback", "devices_used")
+                     if k in cfg}
+    for k in ("workload", "input_format", "parallelism", "path"):
+        if isinstance(out["config"].get(k), str):
+            out["config"][k] = out["config"][k][:200]
+    om = result.get("offset_match", {})
+    out["offset_match"] = {k: om.get(k) for k in ("pairs_matching_reference_golden", "pairs", "pairs_matching_ground_truth",
+                                                  "gpu_equals_cpu_oracle_on_sample", "ambiguous_flags") if k in om}
+
+    def slim_roofline(r):
+        if not isinstance(r, dict):
+            return None
+        keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "wasted", "avg_launch_ms",
+                "share_of_kernel_time", "per_launch", "peak_source", "lds_conflict_frac")
+        return {k: _num(r[k]) for k in keep if k in r}
+
+    out["roofline"] = slim_roofline(result.get("roofline"))
+    if result.get("roofline_hbm") is not None:
+        out["roofline_hbm"] = slim_roofline(result.get("roofline_hbm"))
+    if isinstance(result.get("kernels"), dict):
+        out["kernels_us_per_pair"] = {k: _num(v.get("us_per_pair"), 4) for k, v in result["kernels"].items()}
+    cb = result.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: (_num(cb[k]) if not isinstance(cb[k], str) else cb[k][:160])
+                               for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        if isinstance(cb.get("parallel"), dict) and "value" in cb["parallel"]:
+            out["cpu_baseline"]["parallel"] = {"value": _num(cb["parallel"]["value"]), "cores": cb["parallel"].get("cores")}
+    # the legs a reader of the headline needs next to it: the north star's transform kernels on the same pairs, the
+    # reference's own transform length, the windowless solve
+    out["fft_path_value"] = _pick(result, "fft_path", "value")
+    out["fft_path_roofline"] = slim_roofline((result.get("fft_path") or {}).get("roofline"))
+    out["reference_length_value"] = _pick(result, "reference_length", "value")
+    out["windowless_value"] = _pick(result, "windowless", "value")
+    detail = {
+        "fft_path_identical_records": _pick(result, "fft_path", "identical_candidate_results"),
+        "single_ratio_6000": _pick(result, "single_ratio", "max_offset_6000", "solves_per_s"),
+        "single_ratio_none": _pick(result, "single_ratio", "max_offset_none", "solves_per_s"),
+        "byte_inputs": _pick(result, "byte_inputs", "value"),
+        "float_inputs": _pick(result, "float_inputs", "value"),
+        "float_inputs_path": _pick(result, "float_inputs", "path"),
+        "float_inputs_golden": _pick(result, "float_inputs", "pairs_matching_reference_golden"),
+        "gss_files_per_s": _pick(result, "gss", "files_per_s"),
+        "gss_all_files_equal_per_file_search": _pick(result, "gss", "all_files_equal_per_file_search"),
+        "ingest_cold_pairs_per_s": _pick(result, "ingest_inclusive", "solves_per_s"),
+        "ingest_warm_plan_stream_pairs_per_s": _pick(result, "ingest_inclusive", "warm_plan_stream", "solves_per_s"),
+        "ingest_lists_warm_pairs_per_s": _pick(result, "ingest_inclusive", "boundary_lists", "solves_per_s"),
+        "drop_in_ms_device_rasters": _pick(result, "drop_in", "device_rasters", "ms_per_solve_median"),
+        "drop_in_ms_host_arrays": _pick(result, "drop_in", "host_float64_arrays", "ms_per_solve_median"),
+        "vad_GBps": _pick(result, "vad", "roofline", "achieved"),
+        "vad_frac": _pick(result, "vad", "roofline", "frac"),
+        "vad_parity": _pick(result, "vad", "parity"),
+        "end_to_end_files_per_s": _pick(result, "end_to_end", "files_per_s"),
+        "normaliser_frac_of_8TBps": _pick(result, "normaliser", "frac_of_8TBps_per_gpu"),
+    }
+    ss = result.get("strong_scaling") or result.get("strong_scaling_proxy")
+    if isinstance(ss, dict):
+        detail["strong_proxy" if "strong_scaling_proxy" in result else "strong"] = {
+            k: _num(ss[k]) for k in ("pairs_per_rank_per_step", "ms_per_step", "solves_per_s_this_gpu", "value",
+                                     "efficiency_vs_headline_batch", "predicted_8_gpu_strong_solves_per_s") if k in ss}
+    bd = (result.get("boundary_density") or {}).get("sweep")
+    if bd:  # [boundaries per vector, auto solves/s, transforms solves/s, path initial]
+        detail["boundary_density"] = [[int(s["boundaries_per_vector"]), int(s["auto_solves_per_s"]), int(s["transforms_solves_per_s"]),
+                                       s["auto_path"][:1]] for s in bd]
+    out["detail"] = {k: v for k, v in detail.items() if v is not None}
+    if detail_path:
+        out["detail_file"] = detail_path
+    line = json.dumps(out, separators=(",", ":"))
+    # never let the line outgrow the driver's tail: drop optional blocks, least important first
+    for victim in ("detail", "kernels_us_per_pair", "fft_path_roofline", "roofline_hbm"):
+        if len(line) < COMPACT_LIMIT:
+            break
+        out.pop(victim, None)
+        line = json.dumps(out, separators=(",", ":"))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(result):
+    """Full record -> bench_detail.json (+ gpurun_out/, + an earlier `# detail:` stdout line); compact record LAST."""
+    full = json.dumps(result)
+    written = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(full + "\n")
+                written = written or "bench_detail.json"
+        except OSError:
+            pass
+    print("# detail: " + full, flush=True)
+    print(compact_record(result, written), flush=True)
 
 
 def fail_line(args, message, world=None):
@@ -1226,7 +1349,7 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
-        print(json.dumps(result), flush=True)
+        emit(result)
 
 
 if __name__ == "__main__":
