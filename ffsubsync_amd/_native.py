@@ -19,6 +19,7 @@ FFS_DTYPE_U8 = 0
 FFS_DTYPE_F32 = 1
 FFS_DTYPE_F64 = 3  # float64 samples (fp32 transforms nominate, fp64 re-evaluation of the caller's own samples)
 FFS_DTYPE_U1 = 2  # one bit per sample, numpy.packbits(..., bitorder="little") order, 32-bit words
+FFS_DTYPE_RUNS = 5  # the vector's boundary list (an `ffs_runs_list` device block: 16-byte header + 8-byte entries)
 FLAG_EMPTY_WINDOW = 1
 FLAG_AMBIGUOUS = 2
 FLAG_FILTERED = 4
@@ -43,6 +44,11 @@ EXPORTED_SYMBOLS = (
     "ffs_plan_workspace_bytes",
     "ffs_align_batch",
     "ffs_align_batch_typed",
+    "ffs_align_batch_runs",
+    "ffs_runs_list_bytes",
+    "ffs_runs_from_bits",
+    "ffs_runs_to_bits",
+    "ffs_rasterize_batch_runs",
     "ffs_correlate_full",
     "ffs_vad_energy",
     "ffs_vad_energy_bits",
@@ -71,6 +77,26 @@ EXPORTED_SYMBOLS = (
 KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore", "runs_extract", "runs_corr")
 FFS_ALGO_AUTO, FFS_ALGO_FFT, FFS_ALGO_RUNS = 0, 1, 2
 ALGORITHMS = {"auto": FFS_ALGO_AUTO, "fft": FFS_ALGO_FFT, "runs": FFS_ALGO_RUNS}
+
+
+def algorithm_code(algorithm) -> int:
+    """FFS_ALGO_* code of "auto" / "fft" / "runs" (any case, surrounding blanks ignored) or of a code itself."""
+    if isinstance(algorithm, str):
+        name = algorithm.strip().lower()
+        if name not in ALGORITHMS:
+            raise ValueError("unknown algorithm %r: expected one of %s" % (algorithm, ", ".join(sorted(ALGORITHMS))))
+        return ALGORITHMS[name]
+    if isinstance(algorithm, (int, np.integer)) and int(algorithm) in ALGORITHMS.values():
+        return int(algorithm)
+    raise ValueError("unknown algorithm %r: expected one of %s or an FFS_ALGO_* code" % (algorithm, ", ".join(sorted(ALGORITHMS))))
+
+
+def env_algorithm() -> str:
+    """FFS_ALGORITHM of the environment, validated ("auto" when unset or empty)."""
+    name = os.environ.get("FFS_ALGORITHM", "").strip().lower() or "auto"
+    if name not in ALGORITHMS:
+        raise ValueError("FFS_ALGORITHM=%r: expected one of %s" % (os.environ.get("FFS_ALGORITHM"), ", ".join(sorted(ALGORITHMS))))
+    return name
 
 
 class NativeError(RuntimeError):
@@ -132,6 +158,22 @@ def load():
             c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
             c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p,
         ]
+        lib.ffs_align_batch_runs.restype = c.c_int
+        lib.ffs_align_batch_runs.argtypes = [
+            c.c_void_p, c.c_int, c.c_int, c.c_void_p,
+            c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p,
+            c.c_int64, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p,
+        ]
+        lib.ffs_runs_list_bytes.restype = c.c_int64
+        lib.ffs_runs_list_bytes.argtypes = [c.c_int64]
+        lib.ffs_runs_from_bits.restype = c.c_int
+        lib.ffs_runs_from_bits.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_void_p]
+        lib.ffs_runs_to_bits.restype = c.c_int
+        lib.ffs_runs_to_bits.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+        lib.ffs_rasterize_batch_runs.restype = c.c_int
+        lib.ffs_rasterize_batch_runs.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p,
+                                                 c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_double,
+                                                 c.c_double, c.c_void_p, c.c_int64, c.c_void_p]
         lib.ffs_correlate_full.restype = c.c_int
         lib.ffs_correlate_full.argtypes = [
             c.c_void_p, c.c_int,
@@ -245,10 +287,14 @@ class Plan:
     def workspace_bytes(self) -> int:
         return int(self.lib.ffs_plan_workspace_bytes(self.handle))
 
-    def set_algorithm(self, algorithm) -> None:
+    def set_algorithm(self, algorithm, _from_env: bool = False) -> None:
         """"auto" (default: run-boundary path for short boundary lists, transforms otherwise), "fft" (transforms only) or
-        "runs" (run-boundary path without the coincidence budget); identical results either way."""
-        check(self.lib.ffs_plan_set_algorithm(self.handle, ALGORITHMS.get(algorithm, algorithm)))
+        "runs" (run-boundary path without the coincidence budget); identical results either way.  A plan whose algorithm
+        was set through this method keeps it: ``get_plan`` only re-applies FFS_ALGORITHM to plans that were never set
+        explicitly."""
+        check(self.lib.ffs_plan_set_algorithm(self.handle, algorithm_code(algorithm)))
+        if not _from_env:
+            self._algorithm_explicit = True
 
     def runs_stats(self):
         """(calls that tried the run-boundary path, their sub-batches, sub-batches that went through the transforms)."""
@@ -285,11 +331,15 @@ class Plan:
 
     def align_batch(self, n_pairs: int, n_cand: int, dtype, vec_ptr: np.ndarray, vec_len: np.ndarray,
                     vec_lo: np.ndarray, vec_hi: np.ndarray, max_offset_samples: Optional[int],
-                    filter_max_offset: Optional[int], cand_out, pair_out, stream: Optional[int] = None) -> None:
+                    filter_max_offset: Optional[int], cand_out, pair_out, stream: Optional[int] = None,
+                    vec_max_boundaries: Optional[np.ndarray] = None) -> None:
         """Asynchronous batched solve; ``cand_out``/``pair_out`` are uint8 CUDA tensors of
         n_pairs*n_cand*24 and n_pairs*24 bytes.  Host arrays are consumed before returning.
         ``dtype``: one FFS_DTYPE_* for every vector, or a (reference type, candidate type) tuple / an array with one
-        entry per vector (``ffs_align_batch_typed``: e.g. a float64 reference against bit-packed candidates)."""
+        entry per vector (``ffs_align_batch_runs``: e.g. a float64 reference against bit-packed candidates, or
+        boundary lists, FFS_DTYPE_RUNS).  ``vec_max_boundaries``: host-known upper bounds of the lists' lengths (int32 per
+        vector, 0 = unknown): with all of them known and within the coincidence budget the call does not wait for the
+        device."""
         torch = require_gpu()
         n_vec = n_pairs * (1 + n_cand)
         vec_ptr = np.ascontiguousarray(vec_ptr, dtype=np.uint64)
@@ -308,9 +358,15 @@ class Plan:
             vec_dtype = np.ascontiguousarray(dtype, dtype=np.int32)
             if vec_dtype.size != n_vec:
                 raise ValueError("one element type per vector")
-            check(self.lib.ffs_align_batch_typed(
+            bound = None
+            if vec_max_boundaries is not None:
+                bound = np.ascontiguousarray(vec_max_boundaries, dtype=np.int32)
+                if bound.size != n_vec:
+                    raise ValueError("one boundary bound per vector")
+            check(self.lib.ffs_align_batch_runs(
                 self.handle, n_pairs, n_cand, vec_dtype.ctypes.data,
                 vec_ptr.ctypes.data, vec_len.ctypes.data, vec_lo.ctypes.data, vec_hi.ctypes.data,
+                None if bound is None else bound.ctypes.data,
                 -1 if max_offset_samples is None else int(max_offset_samples),
                 -1 if filter_max_offset is None else int(filter_max_offset),
                 cand_out.data_ptr(), pair_out.data_ptr(), st,
@@ -375,8 +431,10 @@ def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Op
     else:
         cache.order.remove(key)
     cache.order.append(key)
-    # cached plans follow FFS_ALGORITHM like new ones do (auto | fft | runs; results are identical either way)
-    plan.set_algorithm(os.environ.get("FFS_ALGORITHM", "auto"))
+    # cached plans follow FFS_ALGORITHM like new ones do (auto | fft | runs; results are identical either way) -- unless
+    # the caller chose an algorithm for this plan through Plan.set_algorithm
+    if not getattr(plan, "_algorithm_explicit", False):
+        plan.set_algorithm(env_algorithm(), _from_env=True)
     # evict least recently used plans beyond the budget (never the one just asked for)
     total = sum(p.workspace_bytes for p in cache.plans.values())
     while total > PLAN_CACHE_BYTES and len(cache.order) > 1:
@@ -519,6 +577,60 @@ def rasterize_batch_bits(start_us, end_us, is_metadata, vec_sub_first, vec_sub_c
                                           start_us.size, first.ctypes.data, count.ctypes.data, ratio.ctypes.data,
                                           word.ctypes.data, length.ctypes.data, n_vec, float(sample_rate),
                                           float(start_seconds), out.data_ptr(), out_words, current_stream_ptr(torch)))
+
+
+def runs_list_bytes(cap: int) -> int:
+    """Bytes of an ``ffs_runs_list`` block with room for ``cap`` entries (16-byte header + 8 bytes per entry)."""
+    return 16 + 8 * int(cap)
+
+
+def rasterize_batch_runs(start_us, end_us, is_metadata, vec_sub_first, vec_sub_count, vec_ratio, vec_out_off, vec_cap,
+                         vec_len, out, sample_rate=100.0, start_seconds=0.0) -> None:
+    """``ffs_rasterize_batch_runs``: every vector of a batch as its BOUNDARY LIST (FFS_DTYPE_RUNS), no bitmap.  Vector v
+    covers subtitles [vec_sub_first[v], +vec_sub_count[v]) scaled by vec_ratio[v]; its list block starts at byte
+    vec_out_off[v] of ``out`` (CUDA tensor; offsets multiples of 8) and holds up to vec_cap[v] >= 2 * count + 1 entries."""
+    torch = require_gpu()
+    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    first, count, off, cap, length = i64(vec_sub_first), i64(vec_sub_count), i64(vec_out_off), i64(vec_cap), i64(vec_len)
+    ratio = np.ascontiguousarray(vec_ratio, dtype=np.float64)
+    n_vec = first.size
+    if not (count.size == off.size == cap.size == length.size == ratio.size == n_vec):
+        raise ValueError("the vector tables must have the same length")
+    check(load().ffs_rasterize_batch_runs(start_us.ctypes.data, end_us.ctypes.data, None if meta is None else meta.ctypes.data,
+                                          start_us.size, first.ctypes.data, count.ctypes.data, ratio.ctypes.data,
+                                          off.ctypes.data, cap.ctypes.data, length.ctypes.data, n_vec, float(sample_rate),
+                                          float(start_seconds), out.data_ptr(), out.numel() * out.element_size(),
+                                          current_stream_ptr(torch)))
+
+
+def runs_from_bits(words, n: int, cap: Optional[int] = None, out=None):
+    """Boundary list (``ffs_runs_list`` block, int32 CUDA tensor of 4 + 2 * cap words) of a FFS_DTYPE_U1 vector of ``n``
+    samples: one pass over the bits.  ``cap`` defaults to room for every possible boundary count below 32 768."""
+    torch = require_gpu()
+    cap = 32768 if cap is None else int(cap)
+    if out is None:
+        out = torch.empty(4 + 2 * cap, dtype=torch.int32, device=words.device)
+    elif out.numel() * out.element_size() < runs_list_bytes(cap):
+        raise ValueError("list block too small")
+    check(load().ffs_runs_from_bits(words.data_ptr(), int(n), out.data_ptr(), cap, current_stream_ptr(torch)))
+    return out
+
+
+def runs_to_bits(block, n: int):
+    """FFS_DTYPE_U1 words (int32 CUDA tensor) of the ``n``-sample vector an ``ffs_runs_list`` block describes."""
+    torch = require_gpu()
+    out = torch.empty(packed_words(n), dtype=torch.int32, device=block.device)
+    check(load().ffs_runs_to_bits(block.data_ptr(), int(n), out.data_ptr(), current_stream_ptr(torch)))
+    return out
+
+
+def runs_list_host(block) -> Tuple[np.ndarray, np.ndarray, int]:
+    """(positions, ones_before, ones) of a list block, on the host (tests, diagnostics)."""
+    raw = block.view(require_gpu().int32).cpu().numpy()
+    n, ones = int(raw[0]), int(raw[1])
+    e = raw[4:4 + 2 * n].reshape(n, 2)
+    return e[:, 0].copy(), e[:, 1].copy(), ones
 
 
 def two_level_pack(values: np.ndarray):

@@ -26,6 +26,9 @@ class DeviceBatch:
     hi: np.ndarray
     dtype: int = _native.FFS_DTYPE_U8
     ref_dtype: Optional[int] = None  # element type of the references when it differs from the candidates' (`dtype`)
+    # FFS_DTYPE_RUNS vectors: host-known upper bounds of the boundary lists' lengths ([n_pairs, 1+n_cand] int32, 0 =
+    # unknown).  With all of them known a solve within the coincidence budget never waits for the device.
+    bounds: Optional[np.ndarray] = None
 
     @property
     def call_dtype(self):
@@ -46,7 +49,8 @@ class DeviceBatch:
         rows = np.arange(self.n_pairs)
         cols = 1 + np.asarray(index, dtype=np.int64)
         pick = lambda a: np.ascontiguousarray(np.stack([a[:, 0], a[rows, cols]], axis=1))
-        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi), self.dtype, self.ref_dtype)
+        return DeviceBatch(self.data, pick(self.offs), pick(self.lens), pick(self.lo), pick(self.hi), self.dtype, self.ref_dtype,
+                           None if self.bounds is None else pick(self.bounds))
 
     def required_fft_length(self, max_offset_samples: Optional[int] = None, reference_length: bool = False) -> int:
         """Plan length for the whole batch: the shortest alias-free transform for the lags the solve has
@@ -69,6 +73,23 @@ class DeviceBatch:
         assert not (self.offs % 64).any() and self.data.numel() % 64 == 0
         words = _native.pack_bits(self.data)
         return DeviceBatch(words.view(self.data.dtype), self.offs // 8, self.lens, self.lo, self.hi, _native.FFS_DTYPE_U1)
+
+    def to_runs(self, cap: int = 32768) -> "DeviceBatch":
+        """The same batch as boundary lists (FFS_DTYPE_RUNS): one ``ffs_runs_from_bits`` pass per vector over a bit-packed
+        batch.  Conversions pay off when the vectors are solved more than once (a reference against many subtitle
+        files, the steps of a golden-section search); ``cap`` entries per list."""
+        torch = _native.require_gpu()
+        if self.dtype == _native.FFS_DTYPE_RUNS and self.ref_dtype in (None, self.dtype):
+            return self
+        if self.dtype != _native.FFS_DTYPE_U1 or self.ref_dtype not in (None, self.dtype):
+            raise ValueError("only bit-packed batches can be converted to boundary lists")
+        block = (_native.runs_list_bytes(cap) + 63) // 64 * 64
+        n = self.offs.size
+        data = torch.empty(n * block, dtype=torch.uint8, device=self.data.device)
+        offs = (np.arange(n, dtype=np.int64) * block).reshape(self.offs.shape)
+        for o_src, o_dst, ln in zip(self.offs.ravel(), offs.ravel(), self.lens.ravel()):
+            _native.runs_from_bits(self.data[int(o_src):], int(ln), cap, out=data[int(o_dst): int(o_dst) + block])
+        return DeviceBatch(data, offs, self.lens, self.lo, self.hi, _native.FFS_DTYPE_RUNS)
 
 
 def _layout(lens: np.ndarray, bytes_per_vec: np.ndarray):
@@ -134,27 +155,52 @@ class TrackSet:
                                      offs // 4, lens, data, sample_rate, start_seconds)
         return data, offs, lens
 
+    def rasterize_runs(self, track_of, ratio, sample_rate: int = 100):
+        """The same vectors as BOUNDARY LISTS (FFS_DTYPE_RUNS; ``ffs_rasterize_batch_runs``): no bitmap is written, the
+        merged intervals are the list.  Returns (uint8 CUDA buffer, byte offset of every vector's list block, length of
+        every vector in samples, upper bound of every list's length: two entries per subtitle)."""
+        torch = _native.require_gpu()
+        track_of = np.asarray(track_of, dtype=np.int64).ravel()
+        ratio = np.ascontiguousarray(ratio, dtype=np.float64).ravel()
+        lens = _native.raster_lengths(self.end_max[track_of], ratio, sample_rate)
+        counts = self.counts[track_of]
+        caps = 2 * counts + 2
+        offs, total = _layout(lens, 16 + 8 * caps)
+        data = torch.empty(max(total, 64), dtype=torch.uint8, device="cuda")
+        _native.rasterize_batch_runs(self.start_us, self.end_us, self.meta, self.firsts[track_of], counts, ratio, offs, caps,
+                                     lens, data, sample_rate, 0.0)
+        return data, offs, lens, np.maximum(2 * counts, 2).astype(np.int32)
+
 
 def rasterize_vectors(tracks, track_of, ratio, sample_rate: int = 100, start_seconds: float = 0):
     """``TrackSet(tracks).rasterize(track_of, ratio)``."""
     return TrackSet(tracks).rasterize(track_of, ratio, sample_rate, start_seconds)
 
 
-def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 100, start_seconds: float = 0) -> DeviceBatch:
+def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 100, start_seconds: float = 0,
+                         lists: bool = False) -> DeviceBatch:
     """Bit-packed DeviceBatch straight from subtitle interval lists: ``records`` is a list of
     (reference_track, candidate_track), a track being (start_us, end_us, is_metadata) arrays
     (``subtitle_raster.subtitle_records``).  The reference track is rasterised as it is, the candidate track once per
     framerate ratio (``SubtitleScaler`` + ``SubtitleSpeechTransformer``: times scaled by the ratio, amplitude
     min(1/ratio, 1)) -- all of it by ONE ``ffs_rasterize_batch_bits`` call that writes into the batch buffer (interval
     arithmetic on the device; no per-vector tensors, no pack copy).  Same vectors as ``pack_pairs`` over
-    ``subtitle_raster.rasterize_candidates``."""
+    ``subtitle_raster.rasterize_candidates``.  ``lists``: the vectors as boundary lists (FFS_DTYPE_RUNS,
+    ``ffs_rasterize_batch_runs``) -- no bitmap at all, and the solve needs no pass over one either; needs
+    ``start_seconds <= 0``."""
     ratios = [float(r) for r in ratios]
     n_pairs, n_vec = len(records), 1 + len(ratios)
     tracks = [t for rec in records for t in rec]  # track 2p: pair p's reference, 2p + 1: its candidates
     track_of = np.tile(np.array([0] + [1] * len(ratios)), (n_pairs, 1)) + 2 * np.arange(n_pairs)[:, None]
     ratio = np.tile(np.array([1.0] + ratios), (n_pairs, 1))
-    data, offs, lens = rasterize_vectors(tracks, track_of.ravel(), ratio.ravel(), sample_rate, start_seconds)
     hi = np.minimum(1.0 / ratio, 1.0)
+    if lists:
+        if start_seconds > 0:
+            raise ValueError("boundary lists need start_seconds <= 0 (negative start samples wrap around in Python slices)")
+        data, offs, lens, bounds = TrackSet(tracks).rasterize_runs(track_of.ravel(), ratio.ravel(), sample_rate)
+        return DeviceBatch(data, offs.reshape(n_pairs, n_vec), lens.reshape(n_pairs, n_vec), np.zeros_like(hi), hi,
+                           _native.FFS_DTYPE_RUNS, None, bounds.reshape(n_pairs, n_vec))
+    data, offs, lens = rasterize_vectors(tracks, track_of.ravel(), ratio.ravel(), sample_rate, start_seconds)
     return DeviceBatch(data, offs.reshape(n_pairs, n_vec), lens.reshape(n_pairs, n_vec), np.zeros_like(hi), hi,
                        _native.FFS_DTYPE_U1)
 
@@ -214,9 +260,13 @@ class BatchAligner:
             sl = slice(lo, hi)
             ptrs = (batch.data.data_ptr() + batch.offs[sl]).astype(np.uint64)
             c0, p0 = (lo - pair_lo) * self.n_cand * 24, (lo - pair_lo) * 24
-            plan.align_batch(hi - lo, self.n_cand, batch.call_dtype, ptrs.ravel(), batch.lens[sl].ravel(),
+            dt = batch.call_dtype
+            if batch.bounds is not None and isinstance(dt, (int, np.integer)):
+                dt = (dt, dt)  # (the bounds travel through the per-vector-type entry point)
+            plan.align_batch(hi - lo, self.n_cand, dt, ptrs.ravel(), batch.lens[sl].ravel(),
                              batch.lo[sl].ravel(), batch.hi[sl].ravel(), self.max_offset_samples,
-                             self.max_offset_samples, cand_out[c0:], pair_out[p0:])
+                             self.max_offset_samples, cand_out[c0:], pair_out[p0:],
+                             vec_max_boundaries=None if batch.bounds is None else batch.bounds[sl].ravel())
 
         if n > 0 and (self.streams == 1 or n < 2 * self.streams):
             run(self.plan, pair_lo, pair_hi)

@@ -1,5 +1,5 @@
-// ffs_runs.h -- run-boundary correlation: the EXACT correlation of two bit-packed two-level activity vectors from their
-// run boundaries, no transform (gfx950).
+// ffs_runs.h -- run-boundary correlation: the EXACT correlation of two two-level activity vectors from their run
+// boundaries, no transform (gfx950).
 //
 // A speech-activity vector is a few thousand runs of ones in ~720 000 samples (2 h at 100 Hz).  For 0/1 vectors
 // b (candidate, length S) and rho (reference, length R) the count n11(d) = sum_i b[i] * rho[i+d] -- the one
@@ -14,10 +14,14 @@
 // Everything is integer arithmetic: the counts are exact, the scores are the same fp64 expression the transform path
 // evaluates for its nominees, the maximum is taken over EVERY lag of the window (ties to the largest lag = the first
 // k of np.argmax, aligners.py:45-48).  Work ~ |P| * |Q| * W / R boundary coincidences per candidate (W lags): 5e4 for
-// subtitle-like vectors under the production window of +-60 s, against ~2e8 flops of the transform path.  Dense vectors
-// (more than RUNS_CAP - 1 boundaries, or a coincidence count above the budget) go through the transforms as before,
-// a whole sub-batch at a time; the rule is evaluated identically on the host and on the device (runs_over_budget,
-// k_runs_chunk_flags).
+// subtitle-like vectors under the production window of +-60 s, against ~2e8 flops of the transform path.
+//
+// Round 5: a vector reaches the kernels as a BOUNDARY LIST (RunsRef): either extracted here from its bit-packed samples
+// (k_runs_extract) or handed over by its producer -- the subtitle rasteriser knows its intervals (k_rasterize_runs: no
+// bitmap is ever written or read), a bit-packed label vector is converted once (ffs_runs_from_bits) and reused by
+// every later solve.  Dense vectors (a list of RUNS_CAP or more entries, or a coincidence count above the budget) go
+// through the transforms, a whole sub-batch at a time (k_runs_chunk_flags decides on the device, the host reads one int
+// per sub-batch); list-only vectors are expanded to bits for that (k_runs_expand).
 //
 // Index arithmetic modelled in oracle/runs_model.py (CPU-tested against a direct evaluation).
 #pragma once
@@ -25,24 +29,44 @@
 
 namespace ffsa {
 
-constexpr int RUNS_T = 12288;            // lags per tile = per workgroup (the +-6000-lag production window is one tile)
-constexpr int RUNS_LPT = RUNS_T / 256;   // consecutive lags per thread in the scan phase
-constexpr int RUNS_QCAP = 3580;          // reference boundaries staged in LDS at a time (longer lists: slice by slice)
-constexpr int RUNS_PC = 8;               // candidate boundaries a thread holds in registers per walk
-constexpr int RUNS_CAP = 32768;          // boundary-list entries per vector incl. the sentinel: also keeps |h(d)| < 2^15
-static_assert(RUNS_LPT % 2 == 0 && RUNS_LPT <= 64, "two lags per LDS word, one 64-bit mask per chunk");
+constexpr int RUNS_THREADS = 512;                 // k_runs_corr workgroup
+constexpr int RUNS_WAVES = RUNS_THREADS / 64;
+constexpr int RUNS_T = 12288;                     // lags per tile = per workgroup (the +-6000-lag production window is one tile)
+constexpr int RUNS_LPT = RUNS_T / RUNS_THREADS;   // consecutive lags per thread in the scan phase
+constexpr int RUNS_QCAP = 3070;                   // reference boundaries staged in LDS at a time (longer lists: slice by slice)
+constexpr int RUNS_CAP = 32768;                   // boundary-list entries per vector incl. the sentinel (plan-owned lists)
+#ifndef FFS_RUNS_TPW
+#define FFS_RUNS_TPW 4
+#endif
+constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate boundaries each) a wave advances together
+constexpr int RUNS_QSENT = 0x3fffffff;            // staged sentinel: beyond every position (vectors are shorter than 2^30)
+static_assert(RUNS_LPT <= 32 && RUNS_LPT % 8 == 0 && RUNS_QCAP % 2 == 0, "one 32-bit mask per thread, 16-byte histogram loads");
 
-struct RunsVec {  // one vector of the call
-    const unsigned* words;  // bit-packed samples (bit i = (words[i >> 5] >> (i & 31)) & 1)
-    int32_t len;
-    int32_t pad;
+// One vector of a call as the run-boundary kernels see it.  e[k] = (position of boundary k, ones of the vector in front of
+// it), k < n, sorted; e[n] = (INT32_MAX, all ones); n is even (a run that reaches the end closes at position len).
+// hdr->x = n (>= the list's capacity when it was truncated), hdr->y = ones.
+struct RunsRef {
+    const int2* e;
+    const int2* hdr;
+    const unsigned* bits;  // the bit-packed samples (bit i = (bits[i >> 5] >> (i & 31)) & 1); null: the list is all there is
+    int32_t len;           // samples
+    int32_t cap;           // entries e[] has room for (incl. the sentinel)
 };
+
+// The kernels read lists and bitmaps through GLOBAL-address-space pointers: a pointer fetched from a RunsRef in memory is
+// generic to the compiler, and generic (flat) loads may alias LDS -- they would be ordered against every histogram
+// atomic and staging store, one load latency at a time.
+struct RunEntry {
+    int pos, ones;
+};
+typedef const __attribute__((address_space(1))) RunEntry* GEntries;
+typedef const __attribute__((address_space(1))) int* GInts;
+typedef const __attribute__((address_space(1))) unsigned* GWords;
 
 struct RunsBest {  // best lag of one (candidate, tile)
     double score;
     int32_t d;
-    unsigned n11, n1x, nx1;
-    int32_t pad[2];
+    int32_t pad;
 };
 
 struct PackVec {  // one 0/1 byte vector of the call and where its bit-packed image goes
@@ -81,21 +105,22 @@ __global__ __launch_bounds__(256) void k_pack_bytes_batch(const PackVec* __restr
 
 // True when a candidate stays with the transform path: a truncated boundary list, or more expected boundary
 // coincidences inside its lag window than `budget`.  Integer arithmetic only -- host and device must agree.
-FFS_HD bool runs_over_budget(int n_p, int n_q, long long W, long long R, int cap, long long budget) {
-    if (n_p >= cap || n_q >= cap) return true;
-    const long long pairs = (long long)n_p * (long long)n_q;  // < 2^30
+FFS_HD bool runs_over_budget(long long n_p, long long n_q, long long cap_p, long long cap_q, long long W, long long R, long long budget) {
+    if (n_p >= cap_p || n_q >= cap_q) return true;
+    const long long pairs = n_p * n_q;  // < 2^30
     return pairs * W / (R > 0 ? R : 1) > budget;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Boundary lists.  One workgroup per vector; per sweep every thread takes two 16-byte groups, group g of thread t =
-// words base + (256 g + t) * 4 .. + 3 -- a wave's load instruction reads 1 KB of consecutive bytes -- and the loads of
-// the NEXT sweep are issued before the current one is scanned (a sweep is load latency + scan + writes; eight resident
-// blocks per CU in different phases keep the HBM reads going).  Boundary bits e = x ^ (x << 1 | previous bit) (the
-// previous word comes from the neighbouring lane), one block scan per sweep of the per-group (boundaries, ones) counts
-// packed 2 x 16 bits (a field sums to at most 256 * 128; DPP row shifts + row broadcasts inside a wave, the four wave
-// totals through LDS), then every thread writes its own boundaries: q[k] = position, cq[k] = ones of the vector in front
-// of it.  q[n] = INT_MAX, cq[n] = all ones.
+// Boundary lists from bit-packed samples.  One workgroup per vector; per sweep every thread takes two 16-byte groups,
+// group g of thread t = words base + (256 g + t) * 4 .. + 3 -- a wave's load instruction reads 1 KB of consecutive bytes
+// -- and the loads of the NEXT sweep are issued before the current one is scanned (a sweep is load latency + scan +
+// writes; eight resident blocks per CU in different phases keep the HBM reads going).  Boundary bits e = x ^ (x << 1 |
+// previous bit) (the previous word comes from the neighbouring lane), one block scan per sweep of the per-group
+// (boundaries, ones) counts packed 2 x 16 bits (a field sums to at most 256 * 128; DPP row shifts + row broadcasts inside
+// a wave, the four wave totals through LDS), then every thread writes its own boundaries, ONE 8-byte store each:
+// e[k] = (position, ones of the vector in front of it).  The sweep loop stops as soon as the list is full (a vector that
+// dense goes through the transforms anyway -- its remaining words are never read).
 FFS_DEV unsigned wave_incl_scan_u32(unsigned v) {  // inclusive prefix sum over the 64 lanes
 #define FFS_DPP_ADD(ctrl, rows) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
     FFS_DPP_ADD(0x111, 0xf);  // row_shr:1
@@ -109,15 +134,12 @@ FFS_DEV unsigned wave_incl_scan_u32(unsigned v) {  // inclusive prefix sum over 
     return v;
 }
 
-__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restrict__ vecs, int* __restrict__ rq,
-                                                         int* __restrict__ rc, int2* __restrict__ rn, int cap) {
+FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int len, int2* __restrict__ e, int2* __restrict__ hdr,
+                               const int cap) {
+    const GWords w = (GWords)w_generic;
     constexpr int G = 2, SWEEP = 256 * 4 * G;  // words per sweep
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned* __restrict__ w = vecs[v].words;
-    const int len = vecs[v].len;
-    int* __restrict__ q = rq + (size_t)v * cap;
-    int* __restrict__ cq = rc + (size_t)v * cap;
-    const gptr qb = (gptr)q, cqb = (gptr)cq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gptr eb = (gptr)e;
     const int nw = (len + 31) >> 5;     // words that hold samples
     const int n_proc = (len >> 5) + 1;  // word len/32 holds position `len`, where a run that reaches the end closes
     const unsigned tail = (len & 31) ? ((1u << (len & 31)) - 1u) : 0xffffffffu;  // valid bits of word nw - 1
@@ -129,8 +151,8 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
         for (int g = 0; g < G; ++g) {
             const int w0 = base + (g * 256 + tid) * 4;
             if (w0 + 4 < nw) {  // in front of the (masked) last word
-                uint4 t;
-                __builtin_memcpy(&t, w + w0, 16);
+                typedef unsigned v4u __attribute__((ext_vector_type(4), aligned(4)));
+                const v4u t = *(const __attribute__((address_space(1))) v4u*)(w + w0);
                 xn[g][0] = t.x, xn[g][1] = t.y, xn[g][2] = t.z, xn[g][3] = t.w;
             } else {
 #pragma unroll
@@ -150,8 +172,8 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
     };
     request(0);
     int buf = 0;
-    for (int base = 0; base < n_proc; base += SWEEP, buf ^= 1) {
-        unsigned x[G][4], e[G][4], pv[G];
+    for (int base = 0; base < n_proc && n_bound < (unsigned)cap; base += SWEEP, buf ^= 1) {
+        unsigned x[G][4], ee[G][4], pv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             pv[g] = pn[g];
@@ -168,9 +190,9 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
             unsigned ne = 0, no = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                e[g][k] = x[g][k] ^ ((x[g][k] << 1) | prev);
+                ee[g][k] = x[g][k] ^ ((x[g][k] << 1) | prev);
                 prev = x[g][k] >> 31;
-                ne += __popc(e[g][k]);
+                ne += __popc(ee[g][k]);
                 no += __popc(x[g][k]);
             }
             pe |= ne << (16 * g);
@@ -197,15 +219,16 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
                 const int w0 = base + (g * 256 + tid) * 4;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    unsigned ee = e[g][k];
-                    while (ee) {
-                        const int b = __builtin_ctz(ee);
+                    unsigned eb_k = ee[g][k];
+                    while (eb_k) {
+                        const int b = __builtin_ctz(eb_k);
                         if (k_out < cap) {  // (scalar list base + 32-bit byte offset: no 64-bit address arithmetic per store)
-                            *(__attribute__((address_space(1))) int*)(qb + 4u * (unsigned)k_out) = 32 * (w0 + k) + b;
-                            *(__attribute__((address_space(1))) int*)(cqb + 4u * (unsigned)k_out) = ones + __popc(x[g][k] & ((1u << b) - 1u));
+                            typedef int v2i __attribute__((ext_vector_type(2)));
+                            *(__attribute__((address_space(1))) v2i*)(eb + 8u * (unsigned)k_out) =
+                                (v2i){32 * (w0 + k) + b, ones + (int)__popc(x[g][k] & ((1u << b) - 1u))};
                         }
                         ++k_out;
-                        ee &= ee - 1;
+                        eb_k &= eb_k - 1;
                     }
                     ones += __popc(x[g][k]);
                 }
@@ -214,53 +237,70 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsVec* __restri
         n_bound = gb, n_ones = go;
     }
     if (tid == 0) {
-        rn[v] = make_int2((int)n_bound, (int)n_ones);
-        if ((int)n_bound < cap) {
-            q[n_bound] = INT32_MAX;
-            cq[n_bound] = (int)n_ones;
-        }
+        *hdr = make_int2((int)n_bound, (int)n_ones);
+        if ((int)n_bound < cap) e[n_bound] = make_int2(INT32_MAX, (int)n_ones);
     }
 }
 
+// every vector of a call that arrived as bits (list-only vectors are skipped)
+__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs) {
+    const RunsRef r = refs[blockIdx.x];
+    if (!r.bits) return;
+    runs_extract_body(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+}
+
+// one vector into a caller-owned list (ffs_runs_from_bits)
+__global__ __launch_bounds__(256, 8) void k_runs_extract_one(const unsigned* __restrict__ bits, int len, int2* __restrict__ e,
+                                                             int2* __restrict__ hdr, int cap) {
+    if (threadIdx.x == 0) hdr[1] = make_int2(len, cap);
+    runs_extract_body(bits, len, e, hdr, cap);
+}
+
 // ---------------------------------------------------------------------------------------------------------------
-// bits [start, start + 64) of a bit-packed vector, zero outside [0, len)
-FFS_DEV unsigned long long fetch64(const unsigned* __restrict__ w, int len, long long start) {
+// 32 bits [start, start + 32) of a bit-packed vector, zero outside [0, len)
+FFS_DEV unsigned fetch32(GWords w, int len, long long start) {
     const int nw = (len + 31) >> 5;
     const long long wi = start >> 5;  // floor
-    unsigned v[3];
+    unsigned v[2];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < 2; ++k) {
         const long long i = wi + k;
         unsigned t = (i >= 0 && i < nw) ? w[i] : 0u;
         if (i == nw - 1 && (len & 31)) t &= (1u << (len & 31)) - 1u;
         v[k] = t;
     }
-    const unsigned sh = (unsigned)(start & 31);
-    const unsigned lo = __builtin_amdgcn_alignbit(v[1], v[0], sh), hi = __builtin_amdgcn_alignbit(v[2], v[1], sh);
-    return ((unsigned long long)hi << 32) | lo;
+    return __builtin_amdgcn_alignbit(v[1], v[0], (unsigned)(start & 31));
 }
 
-FFS_DEV int lower_bound_i32(const int* a, int n, int x) {  // first k with a[k] >= x
-    int lo = 0, hi = n;
+// the same 32 samples from the vector's boundary list: the value at position x is the parity of the boundaries <= x
+FFS_DEV unsigned list_bits32(GEntries e, int n, long long start) {
+    if (start + 32 <= 0 || n <= 0) return 0u;
+    int lo = 0, hi = n;  // boundaries at positions <= start
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (a[mid] < x)
+        if ((long long)e[mid].pos <= start)
             lo = mid + 1;
         else
             hi = mid;
     }
-    return lo;
+    unsigned m = (lo & 1) ? 0xffffffffu : 0u;
+    for (int k = lo; k < n; ++k) {
+        const long long off = (long long)e[k].pos - start;  // >= 1
+        if (off >= 32) break;
+        m ^= 0xffffffffu << (int)off;
+    }
+    return m;
 }
 
-// the same search by a whole wave (every lane passes the same arguments): 64 probes per step, three dependent loads
-// for a list of 32 768 entries instead of fifteen
-FFS_DEV int wave_lower_bound_i32(const int* __restrict__ a, int n, int x) {
+// first k in [0, n] with e[k].x >= x, by a whole wave (every lane passes the same arguments): 64 probes per step, three
+// dependent loads for a list of 32 768 entries instead of fifteen
+FFS_DEV int wave_lower_bound_e(GEntries a, int n, int x) {
     const int lane = threadIdx.x & 63;
     int lo = 0, len = n;  // the answer lies in [lo, lo + len]
     while (len > 0) {
         const int step = (len + 63) >> 6;
         const int idx = lo + (lane + 1) * step - 1;  // last element of this lane's sub-range
-        const bool below = idx < lo + len && a[idx] < x;
+        const bool below = idx < lo + len && a[idx].pos < x;
         const int c = __popcll(__ballot(below));  // sub-ranges that lie entirely below x (a prefix of the lanes)
         const int end = lo + len;
         lo += c * step;
@@ -269,7 +309,8 @@ FFS_DEV int wave_lower_bound_i32(const int* __restrict__ a, int n, int x) {
     return lo;
 }
 
-// exclusive scan over the 256 threads of a block of three ints at once (s_tmp: 4 x 3 ints); wrap-around arithmetic
+// exclusive scan over the NW * 64 threads of a block of three ints at once (s_tmp: NW x 3 ints); wrap-around arithmetic
+template <int NW>
 FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int ia = a, ib = b, ic = c;
@@ -283,267 +324,527 @@ FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
     __syncthreads();
     int pa = ia - a, pb = ib - b, pc = ic - c;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NW - 1; ++i)
         if (i < wave) pa += s_tmp[i * 3], pb += s_tmp[i * 3 + 1], pc += s_tmp[i * 3 + 2];
     a = pa, b = pb, c = pc;
 }
 
-// One workgroup per sub-batch (pairs_per_chunk pairs): flag[chunk] = some candidate of it is over budget -- the host
-// reaches the same verdict from the list lengths and sends the whole sub-batch through the transforms, so k_runs_corr
-// leaves every candidate of a flagged sub-batch alone (no work that would be thrown away).
+// One workgroup per sub-batch (pairs_per_chunk pairs): flags[chunk] = 1 when some candidate of it is over budget (the
+// whole sub-batch then goes through the transforms and k_runs_corr leaves it alone), 2 when a list-only vector of it is
+// truncated (nothing can solve it: the host reports the error).  stats[0] += boundaries of the sub-batch's vectors.
 __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
-                                                          int pairs_per_chunk, const int2* __restrict__ rn, int cap,
-                                                          long long budget, int* __restrict__ flags) {
+                                                          int pairs_per_chunk, const RunsRef* __restrict__ refs, long long budget,
+                                                          int* __restrict__ flags, unsigned long long* __restrict__ stats) {
     const int ch = blockIdx.x;
     const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
-    int over = 0;
+    int over = 0, bad = 0;
+    unsigned long long nb = 0;
     for (int i = p0 * n_cand + (int)threadIdx.x; i < p1 * n_cand; i += 256) {
         const CandDesc& cd = cands[i];
+        const int pair = i / n_cand, j = i - pair * n_cand;
+        const int vr = pair * (n_cand + 1), vs = vr + 1 + j;
+        const RunsRef rr = refs[vr], rs = refs[vs];
+        const GInts hq = (GInts)rr.hdr, hp = (GInts)rs.hdr;
+        const int n_q = hq[0], n_p = hp[0];
+        // (a caller's block carries its capacity in the header: n, ones, len, cap)
+        const int cap_q = rr.cap > 0 ? rr.cap : hq[3], cap_p = rs.cap > 0 ? rs.cap : hp[3];
+        nb += (unsigned)n_p + (j == 0 ? (unsigned)n_q : 0u);
+        bad |= (!rs.bits && n_p >= cap_p) || (!rr.bits && n_q >= cap_q);
         if (cd.flags & CAND_NO_LAGS) continue;
-        const int pair = i / n_cand;
-        const int vr = pair * (n_cand + 1), vs = vr + 1 + (i - pair * n_cand);
-        over |= runs_over_budget(rn[vs].x, rn[vr].x, (long long)cd.d_hi - cd.d_lo + 1, cd.R, cap, budget) ? 1 : 0;
+        over |= runs_over_budget(n_p, n_q, cap_p, cap_q, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget) ? 1 : 0;
     }
     over = __syncthreads_or(over);
-    if (threadIdx.x == 0) flags[ch] = over;
+    bad = __syncthreads_or(bad);
+    __shared__ unsigned long long s_nb[4];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) nb += __shfl_xor(nb, s, 64);
+    if ((threadIdx.x & 63) == 0) s_nb[threadIdx.x >> 6] = nb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        flags[ch] = bad ? 2 : over;
+        atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
+    }
 }
 
-// grid = (candidates of the call, tiles_max); block = 256 threads; tile t of a candidate covers the lags
-// [d_lo + t*RUNS_T, ...] of its window.
+// ---------------------------------------------------------------------------------------------------------------
+// The candidate's record, written by the kernel itself (k_finalize_cands is for the transform path's nominee lists).  The
+// pair records stay with k_finalize_pairs, one tiny launch behind the kernel: finishing a pair inside k_runs_corr -- the
+// last of its candidates to arrive reads the others' records -- needs a device-scope release per workgroup, which on this
+// chip (eight XCDs, one L2 each) is an L2 write-back: measured 0.35 us per pair, more than the rest of the kernel.
+FFS_DEV void runs_write_cand(const CandDesc& cd, CandResult* __restrict__ cres, int ci, double score, int d, bool none) {
+    CandResult r;
+    if (none) {  // every lag masked: np.argmax of all -inf is k=0 (aligners.py:45-48)
+        r.score = -INFINITY;
+        r.offset = (long long)cd.n_ref - 1 - cd.S;
+        r.score_f32 = -INFINITY;
+        r.flags = 1;
+    } else {
+        r.score = score;
+        r.offset = d;
+        r.score_f32 = (float)score;
+        r.flags = 0;
+    }
+    apply_zero_rule(cd, r);
+    cres[ci] = r;
+}
+
+// reference boundaries as the walk reads them: staged in LDS (pointer already moved back by the slice's first index) ...
+struct QLds {
+    const int* p;
+    FFS_DEV int one(int k) const { return p[k]; }
+    FFS_DEV int2 two(int k) const { return *reinterpret_cast<const int2*>(p + k); }  // k even
+};
+// ... or straight from the list in global memory (a reference far denser than the candidate)
+struct QGlb {
+    GEntries e;
+    int n;
+    FFS_DEV int one(int k) const {
+        const int v = k <= n ? e[k].pos : RUNS_QSENT;
+        return v < RUNS_QSENT ? v : RUNS_QSENT;
+    }
+    FFS_DEV int2 two(int k) const { return make_int2(one(k), one(k + 1)); }
+};
+
+// inclusive prefix sum over the 64 lanes of three ints at once, DPP only (no LDS round trips)
+FFS_DEV void wave_incl_scan3(int& a, int& b, int& c) {
+    a = (int)wave_incl_scan_u32((unsigned)a);
+    b = (int)wave_incl_scan_u32((unsigned)b);
+    c = (int)wave_incl_scan_u32((unsigned)c);
+}
+
+// exclusive scan over the NW * 64 threads of a block of three ints at once (s_tmp: NW x 3 ints); wrap-around arithmetic;
+// ONE barrier (the caller alternates between two s_tmp buffers, so a second scan cannot overwrite totals still being read)
+template <int NW>
+FFS_DEV void block_excl_scan3_dpp(int& a, int& b, int& c, int* s_tmp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ia = a, ib = b, ic = c;
+    wave_incl_scan3(ia, ib, ic);
+    if (lane == 63) s_tmp[wave * 3] = ia, s_tmp[wave * 3 + 1] = ib, s_tmp[wave * 3 + 2] = ic;
+    __syncthreads();
+    int pa = ia - a, pb = ib - b, pc = ic - c;
+#pragma unroll
+    for (int i = 0; i < NW - 1; ++i)
+        if (i < wave) pa += s_tmp[i * 3], pb += s_tmp[i * 3 + 1], pc += s_tmp[i * 3 + 2];
+    a = pa, b = pb, c = pc;
+}
+
+// 32 samples [start, start + 32) of a vector from (a stretch of) its boundary list held in LDS: ent[0 .. cnt) = the
+// positions of the list's entries k0 .. k0 + cnt - 1 (ascending); every entry of the list in [start, start + 32) must
+// be among them, and entries in front of k0 lie in front of `start`.
+FFS_DEV unsigned lds_list_bits32(const int* ent, int k0, int cnt, long long start) {
+    if (start + 32 <= 0) return 0u;
+    int lo = 0, hi = cnt;  // staged entries at positions <= start
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)ent[mid] <= start)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    unsigned m = ((k0 + lo) & 1) ? 0xffffffffu : 0u;
+    for (int k = lo; k < cnt; ++k) {
+        const long long off = (long long)ent[k] - start;  // >= 1
+        if (off >= 32) break;
+        m ^= 0xffffffffu << (int)off;
+    }
+    return m;
+}
+
+// grid = (candidates of the call, tiles_max); block = 512 threads, four workgroups per CU (<= 64 VGPRs, 39 KB of LDS);
+// tile t of a candidate covers the lags [d_lo + t*RUNS_T, ...] of its window.
+//   0. the four 32-sample windows of the two vectors a thread needs for the one-sided counts (the samples that enter /
+//      leave the overlap at its RUNS_LPT lags) are requested first -- from the bits, or, for a vector that exists as a
+//      list only, from the stretch of its list that the tile's lags can touch (four waves stage one stretch each);
 //   1. zero the tile's second-difference array (16 bits per lag in 32-bit LDS words: the sum of all additions to a
-//      word is v_lo + 65536 * v_hi as an integer, so both halves are recovered exactly whatever the borrows did; one
-//      word per lag was measured slower -- 64 KB of LDS leave two blocks per CU instead of four, and the kernel lives
-//      off the LDS atomic rate), stage the reference's boundary list in LDS;
-//   2. every thread takes a contiguous share of the candidate's boundaries p: one lower-bound search (then linear
-//      steps) into the reference's list gives the first boundary q >= p + D0 AND the ones of the reference in front of
-//      p + D0 -- summed over p that is n11(D0), and g(D0) is the sum of the parities -- then a walk over the q's up to
-//      p + D1 adds +-1 at lag q - p (ds_add_u32);
-//   3. two block scans turn h into g and n11 for the thread's RUNS_LPT consecutive lags; the one-sided counts follow
-//      from their values at D0 and four 64-bit windows of the two bit vectors (the bits that enter / leave the overlap);
-//   4. every lag is scored with exact_score()'s expression; block argmax, ties to the largest lag.
-__global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ cands, int n_cand,
-                                                   const int* __restrict__ rq, const int* __restrict__ rc,
-                                                   const int2* __restrict__ rn, int cap,
-                                                   NomList* __restrict__ noms, RescoreAcc* __restrict__ acc,
-                                                   RunsBest* __restrict__ best, int tiles_max,
-                                                   const int* __restrict__ chunk_flags, int pairs_per_chunk) {
-    __shared__ unsigned hist[RUNS_T / 2 + 2];  // second difference h of the tile's lags, 16 bits per lag
-    __shared__ int q_lds[RUNS_QCAP + 2];
-    __shared__ int s_tmp[16];
-    __shared__ double s_sc[4];
-    __shared__ int s_d[4];
-    const int ci = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
+//      word is v_lo + 65536 * v_hi as an integer, so both halves are recovered exactly whatever the borrows did), stage
+//      the reference's boundary list in LDS (all global loads of a thread in flight together);
+//   2. ONE candidate boundary p per lane, 64 consecutive ones per wave task, RUNS_TPW tasks of a wave advanced together:
+//      a binary search into the staged list gives the first boundary q >= p + D0 AND (through the list's ones-in-front
+//      column) the ones of the reference in front of p + D0 -- summed over p that is n11(D0), and g(D0) is the sum of
+//      the parities -- then the lane walks the q's up to p + D1 two at a time (an aligned 8-byte LDS read = one run of
+//      the reference: start +, end -) and adds +-1 at lag q - p (ds_add_u32, fire and forget).  An LDS atomic costs the
+//      same ~7.5 cycles per wave-instruction whatever its active lanes or banks (profiles/lds_atomic_ceiling.hip), so
+//      what matters is that the lanes of a wave have windows of similar length -- consecutive p's do;
+//   3. two block scans (DPP inside a wave, one barrier each) turn h into g and n11 for the thread's RUNS_LPT consecutive
+//      lags; the one-sided counts follow from their values at D0 and the windows of step 0;
+//   4. every lag is scored in fp32 (4 fused multiply-adds, branch-free); lags within the rounding-error bound of the
+//      block's best fp32 value are re-evaluated with exact_score()'s fp64 expression; block argmax over those, ties to the
+//      largest lag;
+//   5. the winning thread writes the candidate's record.
+constexpr int RUNS_EDGE = 96;  // list entries staged per edge window stretch (denser: read from global memory)
+#ifndef FFS_RUNS_WPS
+#define FFS_RUNS_WPS 8
+#endif
+__global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
+    const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
+    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk) {
+    __shared__ __attribute__((aligned(16))) unsigned hist[RUNS_T / 2 + 4];  // second difference h of the tile's lags, 16 bits per lag
+    __shared__ __attribute__((aligned(16))) int q_lds[RUNS_QCAP + 4];
+    __shared__ int s_edge[4][RUNS_EDGE];
+    __shared__ int s_ek0[4], s_ecnt[4];
+    __shared__ int s_tmp[2][RUNS_WAVES * 4];
+    __shared__ double s_sc[RUNS_WAVES];
+    __shared__ int s_d[RUNS_WAVES];
+    __shared__ float s_m[RUNS_WAVES];
+    const int ci = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pair = ci / n_cand;
+    if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
+    const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
+    const RunsRef rr = refs[vr], rs_ = refs[vs];  // (independent of the descriptor: the three loads travel together)
     const CandDesc cd = cands[ci];
     if (cd.flags & CAND_NO_LAGS) {
-        if (tile == 0 && tid == 0) noms[ci].count = 0, noms[ci].flags = 1, noms[ci].gmax = -INFINITY;
+        if (tile == 0 && tid == 0) {
+            runs_write_cand(cd, cres, ci, 0.0, 0, true);
+        }
         return;
     }
     const int W = cd.d_hi - cd.d_lo + 1;
     const int n_tiles = (W + RUNS_T - 1) / RUNS_T;
     if (tile >= n_tiles) return;
-    const int pair = ci / n_cand;
-    if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
-    const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
-    const int2 ns = rn[vs], nr = rn[vr];
-    const int n_p = ns.x, n_q = nr.x, S = cd.S, R = cd.R;
+    const int S = cd.S, R = cd.R;
     const int D0 = cd.d_lo + tile * RUNS_T;
     const int Wt = (cd.d_hi - D0 + 1) < RUNS_T ? (cd.d_hi - D0 + 1) : RUNS_T;
-    const int* __restrict__ Pg = rq + (size_t)vs * cap;
-    const int* __restrict__ Qg = rq + (size_t)vr * cap;
-    const int* __restrict__ CQg = rc + (size_t)vr * cap;
+    const GEntries Pe = (GEntries)rs_.e, Qe = (GEntries)rr.e;
+    const GWords sbits = (GWords)rs_.bits, rbits = (GWords)rr.bits;
+    const int n_p = ((GInts)rs_.hdr)[0], n_q = ((GInts)rr.hdr)[0];
+    const int c = tid * RUNS_LPT;  // this thread's lags: D0 + c .. D0 + c + RUNS_LPT - 1
+    // the samples that enter (+) and leave (-) the two one-sided counts when the lag grows by one, lag c + i = bit i:
+    //   n1x(d+1) = n1x(d) + b[-d-1] - b[R-d-1],   nx1(d+1) = nx1(d) - rho[d] + rho[S+d]   (zero outside the vectors)
+    const long long dc = (long long)D0 + c;
+    unsigned m_in1x = 0, m_out1x = 0, m_outx1 = 0, m_inx1 = 0;
+    if (sbits) {
+        m_in1x = __brev(fetch32(sbits, S, -dc - 32));
+        m_out1x = __brev(fetch32(sbits, S, (long long)R - dc - 32));
+    }
+    if (rbits) {
+        m_outx1 = fetch32(rbits, R, dc);
+        m_inx1 = fetch32(rbits, R, (long long)S + dc);
+    }
+    if ((!sbits || !rbits) && wave < 4) {
+        // list-only vectors: wave w stages the stretch of the list that window w of ANY thread of the tile can touch
+        // (windows: 0 b[-d-1], 1 b[R-d-1], 2 rho[d], 3 rho[S+d] over the tile's lags D0 .. D0 + RUNS_T - 1)
+        const bool of_b = wave < 2;
+        if (of_b ? !sbits : !rbits) {
+            const GEntries E = of_b ? Pe : Qe;
+            const int n_e = of_b ? n_p : n_q;
+            const long long t0 = (long long)D0, t1 = (long long)D0 + RUNS_T - 1;  // lags of the tile
+            const long long lo_pos = wave == 0 ? -t1 - 32 : wave == 1 ? (long long)R - t1 - 32 : wave == 2 ? t0 : (long long)S + t0;
+            const long long hi_pos = wave == 0 ? -t0 : wave == 1 ? (long long)R - t0 : wave == 2 ? t1 + 32 : (long long)S + t1 + 32;
+            const int clo = lo_pos < 0 ? 0 : (lo_pos > 0x3fffffff ? 0x3fffffff : (int)lo_pos);
+            const int chi = hi_pos < 0 ? 0 : (hi_pos > 0x3fffffff ? 0x3fffffff : (int)hi_pos);
+            const int k0 = wave_lower_bound_e(E, n_e, clo), k1 = wave_lower_bound_e(E, n_e, chi + 1);
+            const int cnt = k1 - k0;
+            for (int k = lane; k < cnt && k < RUNS_EDGE; k += 64) s_edge[wave][k] = E[k0 + k].pos;
+            if (lane == 0) s_ek0[wave] = k0, s_ecnt[wave] = cnt;
+        }
+    }
     const bool whole = n_q <= RUNS_QCAP;  // the reference's whole list fits the staging area
     // ones of rho in [0, x) = sum_k sgn_k * min(x, Q[k]) (sgn = -1 at run starts, +1 at run ends): the two positions
     // that bound the overlap at lag D0
     const int r_lo = D0 > 0 ? D0 : 0, r_hi = (S + D0) < R ? (S + D0) : R;
     int rsum = 0;
-    for (int k = tid; k <= n_q; k += 256) {
-        const int qv = Qg[k];
-        if (whole) q_lds[k] = qv;
-        if (k < n_q) {
-            const int m_hi = qv < r_hi ? qv : r_hi, m_lo = qv < r_lo ? qv : r_lo;
+    if (whole) {
+        constexpr int NST = (RUNS_QCAP + 2 + RUNS_THREADS - 1) / RUNS_THREADS;
+        int qv[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int k = tid + u * RUNS_THREADS;
+            qv[u] = k <= n_q ? Qe[k].pos : RUNS_QSENT;
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int k = tid + u * RUNS_THREADS;
+            const int q1 = qv[u] < RUNS_QSENT ? qv[u] : RUNS_QSENT;
+            if (k <= n_q + 1) q_lds[k] = q1;
+            if (k < n_q) {
+                const int m_hi = q1 < r_hi ? q1 : r_hi, m_lo = q1 < r_lo ? q1 : r_lo;
+                rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
+            }
+        }
+    } else {
+        for (int k = tid; k < n_q; k += RUNS_THREADS) {
+            const int q1 = Qe[k].pos;
+            const int m_hi = q1 < r_hi ? q1 : r_hi, m_lo = q1 < r_lo ? q1 : r_lo;
             rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
         }
     }
-    for (int i = tid; i < RUNS_T / 2 + 2; i += 256) hist[i] = 0u;
+    {
+        uint4* hz = reinterpret_cast<uint4*>(hist);
+        for (int i = tid; i < (RUNS_T / 2 + 4) / 4; i += RUNS_THREADS) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
+#if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 1
+    if (n_q >= 0) return;
+#endif
+    if (!sbits) {
+        if (s_ecnt[0] <= RUNS_EDGE && s_ecnt[1] <= RUNS_EDGE) {
+            m_in1x = __brev(lds_list_bits32(s_edge[0], s_ek0[0], s_ecnt[0], -dc - 32));
+            m_out1x = __brev(lds_list_bits32(s_edge[1], s_ek0[1], s_ecnt[1], (long long)R - dc - 32));
+        } else {
+            m_in1x = __brev(list_bits32(Pe, n_p, -dc - 32));
+            m_out1x = __brev(list_bits32(Pe, n_p, (long long)R - dc - 32));
+        }
+    }
+    if (!rbits) {
+        if (s_ecnt[2] <= RUNS_EDGE && s_ecnt[3] <= RUNS_EDGE) {
+            m_outx1 = lds_list_bits32(s_edge[2], s_ek0[2], s_ecnt[2], dc);
+            m_inx1 = lds_list_bits32(s_edge[3], s_ek0[3], s_ecnt[3], (long long)S + dc);
+        } else {
+            m_outx1 = list_bits32(Qe, n_q, dc);
+            m_inx1 = list_bits32(Qe, n_q, (long long)S + dc);
+        }
+    }
     const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
-    const int wmax = Wt - 2;                                 // h is needed for the lags D0 .. D1 - 1
-    const unsigned wlim = wmax >= 0 ? (unsigned)wmax : 0u;  // (a one-lag tile never reads h: a stray add at 0 is harmless)
+    const int wmax = Wt - 2;                      // h is needed for the lags D0 .. D1 - 1
+    const int wlim = wmax >= 0 ? wmax : 0;        // (a one-lag tile never reads h: a stray add at 0 is harmless)
     int n11p = 0, gp = 0, bsum = 0;
-    // One group = RUNS_PC consecutive boundaries p of the candidate, positions in registers: the boundaries q that any of
-    // them can meet inside the tile form ONE stretch of the reference's list, so every q is read once per group and tested
-    // against the RUNS_PC positions without a dependent load in between; the additions are fire-and-forget LDS atomics.
-    // The same walk counts, for every p, the q's in front of p + D0 -- its lower bound, which gives the ones of the
-    // reference in front of p + D0 (n11(D0)) and their parity (g(D0)).  Q is indexed absolutely; [lo, hi] is the stretch
-    // that is readable through it (the staged slice, or the whole list in global memory).
-    auto group = [&](auto Q, int kc, int k1, int lo, int hi) {
-        int x[RUNS_PC], cnt[RUNS_PC];
-        int x_last = 0;
+    // RUNS_TPW wave tasks at a time -- 64 consecutive candidate boundaries each, one per lane, task t of a wave = boundaries
+    // r0 + (t * RUNS_WAVES + wave) * 64 + lane -- advanced TOGETHER: every step of the binary searches and of the walks
+    // issues the tasks' LDS reads back to back and waits once, so a wave is stalled for one LDS latency per step instead of
+    // one per task and step.  [lo, hi] = stretch of the reference's list readable through Q.
+    auto tasks = [&](auto Q, int r0, int r1, int lo, int hi) {
+        int x[RUNS_TPW], j[RUNS_TPW], sa[RUNS_TPW], lb[RUNS_TPW], a[RUNS_TPW], b[RUNS_TPW], ones[RUNS_TPW];
+        bool valid[RUNS_TPW], more[RUNS_TPW];
 #pragma unroll
-        for (int i = 0; i < RUNS_PC; ++i) {
-            const bool valid = kc + i < k1;
-            x[i] = valid ? Pg[kc + i] + D0 : 0x3fffffff;  // never met: q - x < 0 for every real boundary
-            cnt[i] = 0;
-            if (valid) x_last = x[i];
+        for (int t = 0; t < RUNS_TPW; ++t) {
+            const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
+            valid[t] = i < r1;
+            x[t] = valid[t] ? Pe[i].pos + D0 : 0;
+            a[t] = lo, b[t] = valid[t] ? hi : lo;  // first k in [lo, hi] with Q(k) >= x
+            sa[t] = (i & 1) ? -1 : 1;              // db[p]
         }
-        const int lb0 = lo + lower_bound_i32(Q + lo, hi - lo, x[0]);
-        const int xe = x_last + wmax;
-        int qq = Q[lb0];
-        int j = lb0;
-        // boundaries in front of the group's last position also count towards the lower bounds of its members
-        for (; qq < x_last; ++j) {
-            const int qn = Q[j + 1];
-            const int sq = (j & 1) ? -1 : 1;
+        for (;;) {
+            bool any = false;
+            int m[RUNS_TPW], qm[RUNS_TPW];
 #pragma unroll
-            for (int i = 0; i < RUNS_PC; ++i) {
-                const int d = qq - x[i];
-                cnt[i] += d < 0;
-                if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
+            for (int t = 0; t < RUNS_TPW; ++t) {
+                m[t] = (a[t] + b[t]) >> 1;
+                qm[t] = a[t] < b[t] ? Q.one(m[t]) : 0;
             }
-            qq = qn;
-        }
-        for (; qq <= xe; ++j) {
-            const int qn = Q[j + 1];
-            const int sq = (j & 1) ? -1 : 1;
 #pragma unroll
-            for (int i = 0; i < RUNS_PC; ++i) {
-                const int d = qq - x[i];
-                if ((unsigned)d <= wlim) atomicAdd(&hist[d >> 1], (unsigned)((i & 1) ? -sq : sq) << ((d & 1) * 16));
+            for (int t = 0; t < RUNS_TPW; ++t) {
+                if (a[t] < b[t]) {
+                    if (qm[t] < x[t])
+                        a[t] = m[t] + 1;
+                    else
+                        b[t] = m[t];
+                    any |= a[t] < b[t];
+                }
             }
-            qq = qn;
+            if (!__any(any)) break;
         }
 #pragma unroll
-        for (int i = 0; i < RUNS_PC; ++i) {
-            if (kc + i < k1) {
-                const int lb = lb0 + cnt[i];
-                const int sp = (i & 1) ? -1 : 1;  // db[p]: groups start at even indices
-                int ones = CQg[lb];
-                if (lb & 1) ones -= Q[lb] - x[i];  // inside a run: the run's ones from x on are not in front of x
-                n11p -= sp * ones;
-                gp -= sp * (lb & 1);
-                const int p = x[i] - D0;
+        for (int t = 0; t < RUNS_TPW; ++t) {
+            lb[t] = a[t];
+            ones[t] = valid[t] ? Qe[lb[t]].ones : 0;  // (the sentinel entry holds all ones); consumed after the walks
+            j[t] = lb[t] & ~1;  // the reference's run that contains or follows x: (start, end) = entries (j, j + 1)
+            more[t] = valid[t];
+        }
+        for (;;) {
+            int2 qq[RUNS_TPW];
+#pragma unroll
+            for (int t = 0; t < RUNS_TPW; ++t) qq[t] = more[t] ? Q.two(j[t]) : make_int2(0, 0);
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < RUNS_TPW; ++t) {
+                if (more[t]) {
+                    const int da = qq[t].x - x[t], db = qq[t].y - x[t];
+                    // + at run starts (even entries), - at run ends; lag d = bits 16 (d & 1) .. of word d >> 1
+                    if ((unsigned)da <= (unsigned)wlim) atomicAdd(&hist[da >> 1], (unsigned)sa[t] << ((da & 1) * 16));
+                    if ((unsigned)db <= (unsigned)wlim) atomicAdd(&hist[db >> 1], (unsigned)(-sa[t]) << ((db & 1) * 16));
+                    more[t] = db <= wlim;  // an end beyond the window: so is everything behind it
+                    j[t] += 2;
+                    any |= more[t];
+                }
+            }
+            if (!__any(any)) break;
+        }
+#pragma unroll
+        for (int t = 0; t < RUNS_TPW; ++t) {
+            if (valid[t]) {
+                int o = ones[t];
+                if (lb[t] & 1) o -= Q.one(lb[t]) - x[t];  // inside a run: the run's ones from x on are not in front of x
+                n11p -= sa[t] * o;
+                gp -= sa[t] * (lb[t] & 1);
+                const int p = x[t] - D0;
                 const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
-                bsum -= sp * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
+                bsum -= sa[t] * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
             }
         }
     };
-    // Rounds of 256 groups (2048 consecutive candidate boundaries).  A reference list that does not fit the staging area
-    // is staged slice by slice: the q's a round can meet are one stretch [first q >= P[first] + D0, first q beyond
-    // P[last] + D1], found by two wave-wide 64-ary searches; only a round whose stretch is still too long (a reference
-    // far denser than the candidate) walks the list in global memory.
-    constexpr int ROUND = 256 * RUNS_PC;
+    // Rounds of RUNS_ROUND consecutive candidate boundaries.  A reference list that does not fit the staging area is staged
+    // slice by slice: the q's a round can meet are one stretch [first q >= P[first] + D0, first q beyond P[last] + D1],
+    // found by two wave-wide 64-ary searches; only a round whose stretch is still too long (a reference far denser than
+    // the candidate) walks the list in global memory.
+    constexpr int RUNS_ROUND = RUNS_THREADS * RUNS_TPW;
     int st_lo = 0, st_hi = n_q;
     bool staged_ok = whole;
-    for (int rs = 0; rs < n_p; rs += ROUND) {
-        const int re = (rs + ROUND) < n_p ? (rs + ROUND) : n_p;
+    for (int r0 = 0; r0 < n_p; r0 += RUNS_ROUND) {
+        const int r1 = (r0 + RUNS_ROUND) < n_p ? (r0 + RUNS_ROUND) : n_p;
         if (!whole) {
             __syncthreads();  // the previous round is done with the staged slice
             if (tid < 128) {
-                const int xq = (tid < 64) ? Pg[rs] + D0 : Pg[re - 1] + D0 + (int)wlim + 1;
-                const int v = wave_lower_bound_i32(Qg, n_q, xq);
-                if ((tid & 63) == 0) s_tmp[tid >> 6] = v;
+                const int xq = (tid < 64) ? Pe[r0].pos + D0 : Pe[r1 - 1].pos + D0 + wlim + 1;
+                const int v = wave_lower_bound_e(Qe, n_q, xq);
+                if ((tid & 63) == 0) s_tmp[0][tid >> 6] = v;
             }
             __syncthreads();
-            st_lo = s_tmp[0], st_hi = s_tmp[1];
+            st_lo = s_tmp[0][0] & ~1, st_hi = s_tmp[0][1];
             staged_ok = st_hi - st_lo <= RUNS_QCAP;
             if (staged_ok)
-                for (int k = st_lo + tid; k <= st_hi; k += 256) q_lds[k - st_lo] = Qg[k];
+                for (int k = st_lo + tid; k <= st_hi + 1; k += RUNS_THREADS) {
+                    const int qv = k <= n_q ? Qe[k].pos : RUNS_QSENT;
+                    q_lds[k - st_lo] = qv < RUNS_QSENT ? qv : RUNS_QSENT;
+                }
             __syncthreads();
         }
-        const int kc = rs + tid * RUNS_PC;
-        if (kc < re) {
-            if (staged_ok)
-                group((const int*)q_lds - st_lo, kc, re, st_lo, st_hi);
-            else
-                group(Qg, kc, re, 0, n_q);
-        }
+        if (staged_ok)
+            tasks(QLds{q_lds - st_lo}, r0, r1, st_lo, st_hi);
+        else
+            tasks(QGlb{Qe, n_q}, r0, r1, 0, n_q);
     }
+#if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 2
+    if (n_q >= 0) return;
+#endif
     // block sums of (n11p, gp, bsum, rsum)
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        n11p += __shfl_xor(n11p, s, 64);
-        gp += __shfl_xor(gp, s, 64);
-        bsum += __shfl_xor(bsum, s, 64);
-        rsum += __shfl_xor(rsum, s, 64);
+    {
+        int z = 0;
+        wave_incl_scan3(n11p, gp, bsum);
+        wave_incl_scan3(rsum, z, z);
     }
-    if ((tid & 63) == 0) {
-        const int wv = tid >> 6;
-        s_tmp[wv * 4] = n11p, s_tmp[wv * 4 + 1] = gp, s_tmp[wv * 4 + 2] = bsum, s_tmp[wv * 4 + 3] = rsum;
-    }
+    if (!whole) __syncthreads();  // (s_tmp[0] held the slice bounds)
+    if (lane == 63) s_tmp[0][wave * 4] = n11p, s_tmp[0][wave * 4 + 1] = gp, s_tmp[0][wave * 4 + 2] = bsum, s_tmp[0][wave * 4 + 3] = rsum;
     __syncthreads();  // also: every addition to hist has landed
-    const int n11_0 = s_tmp[0] + s_tmp[4] + s_tmp[8] + s_tmp[12];
-    const int g_0 = s_tmp[1] + s_tmp[5] + s_tmp[9] + s_tmp[13];
-    const int n1x_0 = s_tmp[2] + s_tmp[6] + s_tmp[10] + s_tmp[14];
-    const int nx1_0 = s_tmp[3] + s_tmp[7] + s_tmp[11] + s_tmp[15];
-    __syncthreads();  // s_tmp is reused by the scans
+    int n11_0 = 0, g_0 = 0, n1x_0 = 0, nx1_0 = 0;
+#pragma unroll
+    for (int wv = 0; wv < RUNS_WAVES; ++wv)
+        n11_0 += s_tmp[0][wv * 4], g_0 += s_tmp[0][wv * 4 + 1], n1x_0 += s_tmp[0][wv * 4 + 2], nx1_0 += s_tmp[0][wv * 4 + 3];
 
-    const int c = tid * RUNS_LPT;  // this thread's lags: D0 + c .. D0 + c + RUNS_LPT - 1
-    auto h_pair = [&](int i, int& h0, int& h1) {
-        const unsigned wv = hist[(c >> 1) + i];
-        h0 = (int)(short)(wv & 0xffffu);
-        h1 = (int)(wv - (unsigned)h0) >> 16;
+    // The thread's lags are walked four at a time (one aligned 8-byte LDS read = two words = four lags) in ROLLED loops:
+    // unrolled, the four passes below keep dozens of unpacked values alive and the kernel spills at 64 registers.
+    const uint2* hq = reinterpret_cast<const uint2*>(hist + (c >> 1));
+    auto unpack4 = [&](int q4, int (&h)[4]) {
+        const uint2 w = hq[q4];
+        const int a0 = (int)(short)(w.x & 0xffffu), b0 = (int)(short)(w.y & 0xffffu);
+        h[0] = a0, h[1] = (int)(w.x - (unsigned)a0) >> 16, h[2] = b0, h[3] = (int)(w.y - (unsigned)b0) >> 16;
     };
     int hs = 0;
-#pragma unroll 4
-    for (int i = 0; i < RUNS_LPT / 2; ++i) {
-        int h0, h1;
-        h_pair(i, h0, h1);
-        hs += h0 + h1;
+#pragma unroll 1
+    for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
+        int h[4];
+        unpack4(q4, h);
+        hs += (h[0] + h[1]) + (h[2] + h[3]);
     }
-    // the bits that enter (+) and leave (-) the two one-sided counts when the lag grows by one, lag c + i = bit i:
-    //   n1x(d+1) = n1x(d) + b[-d-1] - b[R-d-1],   nx1(d+1) = nx1(d) - rho[d] + rho[S+d]   (zero outside the vectors)
-    const long long dc = (long long)D0 + c;
-    const unsigned* sw = reinterpret_cast<const unsigned*>(cd.s);
-    const unsigned* rw = reinterpret_cast<const unsigned*>(cd.r);
-    const unsigned long long m_in1x = __brevll(fetch64(sw, S, -dc - 64));
-    const unsigned long long m_out1x = __brevll(fetch64(sw, S, (long long)R - dc - 64));
-    const unsigned long long m_outx1 = fetch64(rw, R, dc);
-    const unsigned long long m_inx1 = fetch64(rw, R, (long long)S + dc);
-    const unsigned long long lpt_mask = RUNS_LPT == 64 ? ~0ull : ((1ull << RUNS_LPT) - 1ull);
-    int d1x = __popcll(m_in1x & lpt_mask) - __popcll(m_out1x & lpt_mask);
-    int dx1 = __popcll(m_inx1 & lpt_mask) - __popcll(m_outx1 & lpt_mask);
-    int hpre = hs, z0 = 0, z1 = 0;
-    block_excl_scan3(hpre, z0, z1, s_tmp);
+    constexpr unsigned lpt_mask = RUNS_LPT == 32 ? 0xffffffffu : ((1u << RUNS_LPT) - 1u);
+    int d1x = __popc(m_in1x & lpt_mask) - __popc(m_out1x & lpt_mask);
+    int dx1 = __popc(m_inx1 & lpt_mask) - __popc(m_outx1 & lpt_mask);
+    int hpre = hs;
+    block_excl_scan3_dpp<RUNS_WAVES>(hpre, d1x, dx1, s_tmp[1]);  // exclusive prefixes
     const int g_c = g_0 - hpre;  // g at the thread's first lag
     int gs = 0;
     {
         int g = g_c;
-#pragma unroll 4
-        for (int i = 0; i < RUNS_LPT / 2; ++i) {
-            int h0, h1;
-            h_pair(i, h0, h1);
-            g -= h0;
-            gs += g;
-            g -= h1;
-            gs += g;
-        }
-    }
-    block_excl_scan3(gs, d1x, dx1, s_tmp);  // now exclusive prefixes
-    int n11 = n11_0 + gs, n1x = n1x_0 + d1x, nx1 = nx1_0 + dx1;
-    double bs = -INFINITY;
-    int bd = INT32_MIN;
-    unsigned b11 = 0, b1x = 0, bx1 = 0;
-    if (c < Wt) {
-        int g = g_c;
-        const int lim = (Wt - c) < RUNS_LPT ? (Wt - c) : RUNS_LPT;
-        for (int i = 0; i < lim; i += 2) {
-            int h0, h1;
-            h_pair(i >> 1, h0, h1);
+#pragma unroll 1
+        for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
+            int h[4];
+            unpack4(q4, h);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int ii = i + e;
-                if (ii < lim) {
-                    const int d = D0 + c + ii;
-                    const double sc = two_level_score(cd, n11, n1x, nx1, d);
-                    if (sc >= bs) bs = sc, bd = d, b11 = (unsigned)n11, b1x = (unsigned)n1x, bx1 = (unsigned)nx1;
-                    g -= e ? h1 : h0;
-                    n11 += g;
-                    n1x += (int)((m_in1x >> ii) & 1ull) - (int)((m_out1x >> ii) & 1ull);
-                    nx1 += (int)((m_inx1 >> ii) & 1ull) - (int)((m_outx1 >> ii) & 1ull);
-                }
+            for (int e = 0; e < 4; ++e) {
+                g -= h[e];
+                gs += g;
             }
         }
     }
+    {
+        int z0 = 0, z1 = 0;
+        block_excl_scan3_dpp<RUNS_WAVES>(gs, z0, z1, s_tmp[0]);
+    }
+    const int n11_c = n11_0 + gs, n1x_c = n1x_0 + d1x, nx1_c = nx1_0 + dx1;  // the counts at the thread's first lag
+#if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 4
+    if (n_q >= 0) {
+        if (n11_c == 0x7fffffff) best[0].d = n1x_c + nx1_c;
+        return;
+    }
+#endif
+    const int lim = (Wt - c) < RUNS_LPT ? (Wt - c) : RUNS_LPT;               // lags of this thread inside the tile (<= 0: none)
+    // score(d) = c0 ov + c1x n1x + cx1 nx1 + c11 n11 (two_level_score() multiplied out); fp32 first
+    const float f0 = (float)(cd.s0 * cd.r0), f1x = (float)(cd.r0 * (cd.s1 - cd.s0)), fx1 = (float)(cd.s0 * (cd.r1 - cd.r0)),
+                f11 = (float)((cd.s1 - cd.s0) * (cd.r1 - cd.r0));
+    // |fp32 value - exact| <= 12 roundings of 2^-24 on sums of at most (|k0|+|k1x|+|kx1|+|k11|) * max(R, S); twice that
+    // separates "cannot be the maximum" from "may be": 24 * 2^-24, used with a factor 2 to spare
+    const float margin = 24.0f * 1.1920929e-7f * (fabsf(f0) + fabsf(f1x) + fabsf(fx1) + fabsf(f11)) * (float)(R > S ? R : S) * 1.01f + 1e-3f;
+    auto score32 = [&](int a11, int a1x, int ax1, int d) -> float {
+        const int j0 = d < 0 ? -d : 0;
+        const int j1 = (R - d) < S ? (R - d) : S;
+        const int ov = j1 > j0 ? (j1 - j0) : 0;
+        return fmaf(f11, (float)a11, fmaf(f1x, (float)a1x, fmaf(fx1, (float)ax1, f0 * (float)ov)));
+    };
+    float tmax = -INFINITY;
+    {
+        int g = g_c, a11 = n11_c, a1x = n1x_c, ax1 = nx1_c;
+        unsigned mi1 = m_in1x, mo1 = m_out1x, mix = m_inx1, mox = m_outx1;
+#pragma unroll 1
+        for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
+            int h[4];
+            unpack4(q4, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q4 + e;
+                const float f = score32(a11, a1x, ax1, D0 + c + i);
+                tmax = fmaxf(tmax, i < lim ? f : -INFINITY);
+                g -= h[e];
+                a11 += g;
+                a1x += (int)((mi1 >> e) & 1u) - (int)((mo1 >> e) & 1u);
+                ax1 += (int)((mix >> e) & 1u) - (int)((mox >> e) & 1u);
+            }
+            mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
+        }
+    }
+    float wm = tmax;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) wm = fmaxf(wm, __shfl_xor(wm, s, 64));
+    if (lane == 0) s_m[wave] = wm;
+    __syncthreads();
+    float bm = s_m[0];
+#pragma unroll
+    for (int wv = 1; wv < RUNS_WAVES; ++wv) bm = fmaxf(bm, s_m[wv]);
+    const float thr = bm - margin;
+#if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 5
+    if (n_q >= 0) {
+        if (thr == 123.25f) best[0].d = 1;
+        return;
+    }
+#endif
+    double bs = -INFINITY;
+    int bd = INT32_MIN;
+    if (tmax >= thr) {  // exact re-evaluation of the lags that may hold the maximum
+        int g = g_c, a11 = n11_c, a1x = n1x_c, ax1 = nx1_c;
+        unsigned mi1 = m_in1x, mo1 = m_out1x, mix = m_inx1, mox = m_outx1;
+#pragma unroll 1
+        for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
+            int h[4];
+            unpack4(q4, h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 4 * q4 + e, d = D0 + c + i;
+                if (i < lim && score32(a11, a1x, ax1, d) >= thr) {
+                    const double sc = two_level_score(cd, a11, a1x, ax1, d);
+                    if (sc >= bs) bs = sc, bd = d;
+                }
+                g -= h[e];
+                a11 += g;
+                a1x += (int)((mi1 >> e) & 1u) - (int)((mo1 >> e) & 1u);
+                ax1 += (int)((mix >> e) & 1u) - (int)((mox >> e) & 1u);
+            }
+            mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
+        }
+    }
+#if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 6
+    if (n_q >= 0) {
+        if (bs == 123.25) best[0].d = bd;
+        return;
+    }
+#endif
     // block argmax: larger score, then larger lag
     double ws = bs;
     int wd = bd;
@@ -553,53 +854,180 @@ __global__ __launch_bounds__(256) void k_runs_corr(const CandDesc* __restrict__ 
         const int od = __shfl_xor(wd, s, 64);
         if (os > ws || (os == ws && od > wd)) ws = os, wd = od;
     }
-    if ((tid & 63) == 0) s_sc[tid >> 6] = ws, s_d[tid >> 6] = wd;
+    if (lane == 0) s_sc[wave] = ws, s_d[wave] = wd;
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < RUNS_WAVES; ++i)
         if (s_sc[i] > ws || (s_sc[i] == ws && s_d[i] > wd)) ws = s_sc[i], wd = s_d[i];
     if (bd == wd && wd != INT32_MIN) {  // the one thread that owns the winning lag
         if (n_tiles == 1) {
-            NomList& nl = noms[ci];
-            nl.count = 1;
-            nl.flags = 0;
-            nl.gmax = (float)bs;
-            nl.d[0] = bd;
-            nl.val[0] = (float)bs;
-            RescoreAcc& a = acc[(size_t)ci * KNOM];
-            a.n11 = b11, a.n1x = b1x, a.nx1 = bx1;
+            runs_write_cand(cd, cres, ci, bs, bd, false);
         } else {
             RunsBest& o = best[(size_t)ci * tiles_max + tile];
-            o.score = bs, o.d = bd, o.n11 = b11, o.n1x = b1x, o.nx1 = bx1;
+            o.score = bs, o.d = bd;
         }
     }
 }
 
 // candidates whose window spans several tiles: best tile result (larger score, then larger lag = later tile)
 __global__ void k_runs_pick(const CandDesc* __restrict__ cands, int n, int n_cand, const RunsBest* __restrict__ best,
-                            int tiles_max, NomList* __restrict__ noms, RescoreAcc* __restrict__ acc,
-                            const int* __restrict__ chunk_flags, int pairs_per_chunk) {
+                            int tiles_max, CandResult* __restrict__ cres, const int* __restrict__ chunk_flags, int pairs_per_chunk) {
     const int ci = blockIdx.x * blockDim.x + threadIdx.x;
     if (ci >= n) return;
     const CandDesc& cd = cands[ci];
+    if (chunk_flags[(ci / n_cand) / pairs_per_chunk]) return;
     if (cd.flags & CAND_NO_LAGS) return;
     const int W = cd.d_hi - cd.d_lo + 1;
     const int n_tiles = (W + RUNS_T - 1) / RUNS_T;
     if (n_tiles <= 1) return;
-    if (chunk_flags[(ci / n_cand) / pairs_per_chunk]) return;
     RunsBest b = best[(size_t)ci * tiles_max];
     for (int t = 1; t < n_tiles; ++t) {
         const RunsBest& o = best[(size_t)ci * tiles_max + t];
         if (o.score >= b.score) b = o;
     }
-    NomList& nl = noms[ci];
-    nl.count = 1;
-    nl.flags = 0;
-    nl.gmax = (float)b.score;
-    nl.d[0] = b.d;
-    nl.val[0] = (float)b.score;
-    RescoreAcc& a = acc[(size_t)ci * KNOM];
-    a.n11 = b.n11, a.n1x = b.n1x, a.nx1 = b.nx1;
+    runs_write_cand(cd, cres, ci, b.score, b.d, false);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// List-only vectors of a sub-batch that goes through the transforms after all: their samples as bits.
+struct ExpandVec {
+    const int2* e;
+    const int2* hdr;
+    unsigned* dst;
+    int32_t len;
+    int32_t pad;
+};
+__global__ __launch_bounds__(256) void k_runs_expand(const ExpandVec* __restrict__ vecs, int chunks_per_vec) {
+    const int v = blockIdx.x / chunks_per_vec, c = blockIdx.x - v * chunks_per_vec;
+    const ExpandVec ev = vecs[v];
+    if (!ev.dst) return;
+    const int n_words = (ev.len + 31) >> 5;
+    const int w = c * 256 + (int)threadIdx.x;
+    if (w >= n_words) return;
+    unsigned m = list_bits32((GEntries)ev.e, ((GInts)ev.hdr)[0], (long long)w * 32);
+    if (w == n_words - 1 && (ev.len & 31)) m &= (1u << (ev.len & 31)) - 1u;
+    ev.dst[w] = m;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Subtitle rasteriser that never makes a bitmap (SubtitleScaler + SubtitleSpeechTransformer, subtitle_transformers.py:
+// 35-47, speech_transformers.py:957-980): the union of a track's scaled [start, end) sample intervals IS the boundary
+// list.  One workgroup per vector; the track's subtitles arrive sorted by start time (the entry point sorts a copy when
+// they are not), the scaling is monotone and -- start_seconds <= 0, checked by the entry point -- no start sample is
+// negative, so the rasterised starts are non-decreasing and a run begins exactly where a start lies beyond every earlier
+// end (touching intervals merge: a boundary that closes and opens at the same sample is none).  Per chunk of 1024
+// subtitles: interval arithmetic (raster_interval, shared with the host), a block-wide running maximum of the ends, a
+// block scan of (new runs, their starts, the ends in front of them) -- ones in front of run r = ends of runs < r minus
+// starts of runs < r -- and every run start writes its own entry and the end entry of the run in front of it.
+struct RasterRunsVec {
+    long long sub_first, out_off;  // first subtitle of the track in the concatenated arrays; byte offset of the list block
+    double ratio;
+    int32_t sub_count, len, cap, pad;  // cap: entries the block has room for (>= 2 * sub_count + 1)
+};
+__global__ __launch_bounds__(256) void k_rasterize_runs(const long long* __restrict__ start_us, const long long* __restrict__ end_us,
+                                                        const unsigned char* __restrict__ meta, const RasterRunsVec* __restrict__ vecs,
+                                                        double sample_rate, double start_seconds, char* __restrict__ out) {
+    constexpr int IT = 4, CHUNK = 256 * IT;
+    const RasterRunsVec rv = vecs[blockIdx.x];
+    int2* hdr = reinterpret_cast<int2*>(out + rv.out_off);
+    int2* e = reinterpret_cast<int2*>(out + rv.out_off + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_max[4];
+    __shared__ unsigned s_cnt[4], s_sa[4], s_se[4];
+    int cmax = -1;                             // largest end so far (-1: none yet)
+    unsigned n_runs = 0, sum_a = 0, sum_e = 0;  // runs begun so far, sum of their starts, sum of the ends in front of them
+    for (int base = 0; base < rv.sub_count; base += CHUNK) {
+        int a[IT], b[IT];
+        bool ok[IT];
+        int tmax = -1;
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = base + tid * IT + k;
+            ok[k] = false;
+            a[k] = b[k] = 0;
+            if (i < rv.sub_count && !(meta && meta[rv.sub_first + i])) {  // speech_transformers.py:966-967
+                long long la, lb;
+                if (raster_interval(start_us[rv.sub_first + i], end_us[rv.sub_first + i], rv.ratio, sample_rate, start_seconds, rv.len,
+                                    &la, &lb)) {
+                    ok[k] = true;
+                    a[k] = (int)la, b[k] = (int)lb;
+                    tmax = tmax > b[k] ? tmax : b[k];
+                }
+            }
+        }
+        // exclusive running maximum of the ends over the threads of the block
+        int im = tmax;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int o = __shfl_up(im, s, 64);
+            if (lane >= s) im = im > o ? im : o;
+        }
+        int pm = __shfl_up(im, 1, 64);
+        if (lane == 0) pm = -1;
+        __syncthreads();  // (the previous chunk's readers of s_* are done)
+        if (lane == 63) s_max[wave] = im;
+        __syncthreads();
+        int run_max = cmax;
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wv < wave) pm = pm > s_max[wv] ? pm : s_max[wv];
+            run_max = run_max > s_max[wv] ? run_max : s_max[wv];
+        }
+        pm = pm > cmax ? pm : cmax;  // largest end in front of this thread's first subtitle
+        // runs that begin in this thread
+        unsigned cnt = 0, sa = 0, se = 0;
+        bool flag[IT];
+        int em[IT];
+        {
+            int m = pm;
+#pragma unroll
+            for (int k = 0; k < IT; ++k) {
+                em[k] = m;
+                flag[k] = ok[k] && a[k] > m;
+                if (flag[k]) {
+                    cnt += 1;
+                    sa += (unsigned)a[k];
+                    se += m >= 0 ? (unsigned)m : 0u;
+                }
+                if (ok[k]) m = m > b[k] ? m : b[k];
+            }
+        }
+        unsigned ic = cnt, ia = sa, ie = se;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const unsigned oc = __shfl_up(ic, s, 64), oa = __shfl_up(ia, s, 64), oe = __shfl_up(ie, s, 64);
+            if (lane >= s) ic += oc, ia += oa, ie += oe;
+        }
+        if (lane == 63) s_cnt[wave] = ic, s_sa[wave] = ia, s_se[wave] = ie;
+        __syncthreads();
+        unsigned r = n_runs + ic - cnt, xa = sum_a + ia - sa, xe = sum_e + ie - se;  // exclusive prefixes incl. earlier chunks
+        unsigned tc = 0, ta = 0, te = 0;
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wv < wave) r += s_cnt[wv], xa += s_sa[wv], xe += s_se[wv];
+            tc += s_cnt[wv], ta += s_sa[wv], te += s_se[wv];
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            if (flag[k]) {
+                const unsigned endp = em[k] >= 0 ? (unsigned)em[k] : 0u;
+                xe += endp;  // ends of the runs in front of run r, the one that closes here included
+                const int ones = (int)(xe - xa);
+                if (2 * r < (unsigned)rv.cap) e[2 * r] = make_int2(a[k], ones);
+                if (r >= 1 && 2 * r - 1 < (unsigned)rv.cap) e[2 * r - 1] = make_int2(em[k], ones);
+                xa += (unsigned)a[k];
+                r += 1;
+            }
+        }
+        n_runs += tc, sum_a += ta, sum_e += te;
+        cmax = run_max;
+    }
+    if (tid == 0) {
+        const unsigned n = 2 * n_runs;
+        const int ones = n_runs ? (int)(sum_e + (unsigned)cmax - sum_a) : 0;
+        if (n_runs && n - 1 < (unsigned)rv.cap) e[n - 1] = make_int2(cmax, ones);
+        if (n < (unsigned)rv.cap) e[n] = make_int2(INT32_MAX, ones);
+        hdr[0] = make_int2((int)n, ones);
+        hdr[1] = make_int2(rv.len, rv.cap);
+    }
 }
 
 }  // namespace ffsa

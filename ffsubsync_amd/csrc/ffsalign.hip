@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <string>
 #include <mutex>
@@ -200,23 +201,27 @@ struct ffs_plan {
     hipStream_t last_stream = nullptr;
     bool has_last = false;
     int64_t workspace_bytes = 0;
+    bool radix3_off = false;                  // FFS_DISABLE_RADIX3=1 when the plan was created (ffs_plan_length)
+    bool workspace_ready = false;             // every buffer of ensure_workspace is allocated (all or nothing)
     // Run-boundary path (ffs_runs.h): FFS_ALGO_AUTO sends every sub-batch of bit-packed two-level vectors whose boundary
     // lists are short enough through it (one event wait per call to read the list lengths), the others through the
     // transforms; FFS_ALGO_FFT never uses it; FFS_ALGO_RUNS ignores the coincidence budget (truncated lists still go
     // through the transforms).  Buffers grown on demand.
     int algo = FFS_ALGO_AUTO;
     long long runs_budget = -1;         // FFS_RUNS_BUDGET: boundary coincidences per candidate above which the transforms take over (-1: the rule in ffs_plan_create)
-    int* runs_q = nullptr;              // [vectors][RUNS_CAP] boundary positions
-    int* runs_c = nullptr;              // [vectors][RUNS_CAP] ones in front of each boundary
+    int2* runs_e = nullptr;             // [vectors][RUNS_CAP] (boundary position, ones in front of it) of the vectors that arrive as bits
     int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
-    int2* runs_n_host = nullptr;        // pinned copy of runs_n
-    size_t runs_vecs = 0;               // vectors the four buffers above have room for
-    unsigned* pack_buf = nullptr;       // bit-packed images of a call's FFS_DTYPE_U8 vectors
+    size_t runs_vecs = 0;               // vectors the two buffers above have room for
+    unsigned* pack_buf = nullptr;       // bit-packed images of a call's FFS_DTYPE_U8 vectors / of list-only vectors that need the transforms
     size_t pack_bytes = 0;
-    int* runs_flags = nullptr;          // [sub-batches] 1 = goes through the transforms (k_runs_chunk_flags)
+    int* runs_flags = nullptr;          // [sub-batches] 1 = goes through the transforms, 2 = unusable list (k_runs_chunk_flags); then the
+                                        // 8-byte boundary counter of the call
+    int* runs_zero_flags = nullptr;     // [sub-batches] zeros: calls whose host-known list bounds rule the transforms out
+    int* runs_flags_host = nullptr;     // pinned copy of runs_flags
     size_t runs_flags_n = 0;
     RunsBest* runs_best = nullptr;      // [candidates][tiles] (windows wider than one tile)
     size_t runs_best_n = 0;
+    bool runs_prev_fft = false;         // the previous run-boundary call needed the transforms for some sub-batch
     hipEvent_t runs_ev = nullptr;
     int64_t runs_calls = 0, runs_fft_chunks = 0, runs_chunks = 0, runs_last_boundaries = 0;  // statistics (ffs_plan_runs_stats)
     // FFS_HOST_TIMING=1: host nanoseconds of the run-boundary calls by section, printed when the plan is destroyed
@@ -265,45 +270,91 @@ int ensure_lds(const ffs_plan* p, const void* fn, size_t bytes) {
     return FFS_OK;
 }
 
-// Transform workspace of a plan (and of its block-segmented sub-plan), allocated on first use.
+// Transform workspace of a plan (and of its block-segmented sub-plan), allocated on first use.  All or nothing: a failed
+// allocation frees what this call had obtained, so a later call tries again instead of launching on null buffers.
 int ensure_workspace(ffs_plan* p) {
-    if (p->direct_only || p->work) return FFS_OK;
+    if (p->direct_only || p->workspace_ready) return FFS_OK;
     const size_t work_bytes = (size_t)p->pairs_in_flight * p->max_slots * p->N * sizeof(cf);
-    HIP_TRY(hipMalloc((void**)&p->work, work_bytes));
     const size_t bn_bytes = (size_t)p->pairs_in_flight * (p->max_slots - 1) * 2 * (p->N2 / p->C) * sizeof(BlockNom);
-    HIP_TRY(hipMalloc((void**)&p->bnom, bn_bytes));
-    HIP_TRY(hipMalloc((void**)&p->xlist, (1 + (size_t)p->pairs_in_flight * p->max_cand) * sizeof(int)));
-    HIP_TRY(hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)));
-    if (p->seg) return ensure_workspace(p->seg);
+    bool ok = hipMalloc((void**)&p->work, work_bytes) == hipSuccess;
+    ok = ok && hipMalloc((void**)&p->bnom, bn_bytes) == hipSuccess;
+    ok = ok && hipMalloc((void**)&p->xlist, (1 + (size_t)p->pairs_in_flight * p->max_cand) * sizeof(int)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&p->pool_entries, (size_t)kPoolCapacity * sizeof(PoolEntry)) == hipSuccess;
+    int rc = FFS_OK;
+    if (!ok) {
+        (void)hipGetLastError();
+        rc = fail(FFS_E_NOMEM, "transform workspace of %zu bytes could not be allocated", work_bytes + bn_bytes);
+    } else if (p->seg) {
+        rc = ensure_workspace(p->seg);
+    }
+    if (rc) {
+        (void)hipFree(p->work);
+        (void)hipFree(p->bnom);
+        (void)hipFree(p->xlist);
+        (void)hipFree(p->pool_entries);
+        p->work = nullptr;
+        p->bnom = nullptr;
+        p->xlist = nullptr;
+        p->pool_entries = nullptr;
+        return rc;
+    }
+    p->workspace_ready = true;
     return FFS_OK;
 }
 
-// Boundary-list buffers of the run-boundary path for `n_vec` vectors (and `n_best` tile records).
-int ensure_runs(ffs_plan* p, size_t n_vec, size_t n_best) {
+// Buffers of the run-boundary path: boundary lists for `n_vec` vectors that arrive as bits (0: every vector of the call
+// brings its own list), `n_best` tile records, per-sub-batch flags.  Counted in
+// ffs_plan_workspace_bytes (the Python plan cache budgets HBM by it).
+int ensure_runs(ffs_plan* p, size_t n_vec, size_t n_best, size_t n_chunks) {
     if (!p->runs_ev) HIP_TRY(hipEventCreateWithFlags(&p->runs_ev, hipEventDisableTiming));
+    auto quiesce = [&]() -> int {
+        if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));  // the previous call may still be using them
+        return FFS_OK;
+    };
+    int rc;
     if (n_vec > p->runs_vecs) {
-        if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));  // the previous call may still be reading them
-        (void)hipFree(p->runs_q);
-        (void)hipFree(p->runs_c);
+        if ((rc = quiesce())) return rc;
+        (void)hipFree(p->runs_e);
         (void)hipFree(p->runs_n);
-        if (p->runs_n_host) (void)hipHostFree(p->runs_n_host);
-        p->runs_q = p->runs_c = nullptr;
-        p->runs_n = p->runs_n_host = nullptr;
+        p->workspace_bytes -= (int64_t)(p->runs_vecs * (RUNS_CAP * sizeof(int2) + sizeof(int2)));
+        p->runs_e = nullptr;
+        p->runs_n = nullptr;
         p->runs_vecs = 0;
         const size_t cap = n_vec + n_vec / 4 + 64;
-        HIP_TRY(hipMalloc((void**)&p->runs_q, cap * RUNS_CAP * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&p->runs_c, cap * RUNS_CAP * sizeof(int)));
-        HIP_TRY(hipMalloc((void**)&p->runs_n, cap * sizeof(int2)));
-        HIP_TRY(hipHostMalloc((void**)&p->runs_n_host, cap * sizeof(int2), hipHostMallocDefault));
+        if (hipMalloc((void**)&p->runs_e, cap * RUNS_CAP * sizeof(int2)) != hipSuccess ||
+            hipMalloc((void**)&p->runs_n, cap * sizeof(int2)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p->runs_e);
+            p->runs_e = nullptr;
+            return fail(FFS_E_NOMEM, "boundary lists for %zu vectors (%zu bytes) could not be allocated", cap, cap * RUNS_CAP * sizeof(int2));
+        }
         p->runs_vecs = cap;
+        p->workspace_bytes += (int64_t)(cap * (RUNS_CAP * sizeof(int2) + sizeof(int2)));
     }
     if (n_best > p->runs_best_n) {
-        if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+        if ((rc = quiesce())) return rc;
         (void)hipFree(p->runs_best);
+        p->workspace_bytes -= (int64_t)(p->runs_best_n * sizeof(RunsBest));
         p->runs_best = nullptr;
         p->runs_best_n = 0;
         HIP_TRY(hipMalloc((void**)&p->runs_best, n_best * sizeof(RunsBest)));
         p->runs_best_n = n_best;
+        p->workspace_bytes += (int64_t)(n_best * sizeof(RunsBest));
+    }
+    if (n_chunks > p->runs_flags_n) {
+        if ((rc = quiesce())) return rc;
+        (void)hipFree(p->runs_flags);
+        (void)hipFree(p->runs_zero_flags);
+        if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
+        p->runs_flags = p->runs_zero_flags = p->runs_flags_host = nullptr;
+        p->runs_flags_n = 0;
+        const size_t cap = n_chunks + 64;  // (the 8-byte boundary counter sits behind the flags, 8-byte aligned)
+        const size_t bytes = ((cap * sizeof(int) + 7) & ~(size_t)7) + 8;
+        HIP_TRY(hipMalloc((void**)&p->runs_flags, bytes));
+        HIP_TRY(hipMalloc((void**)&p->runs_zero_flags, bytes));
+        HIP_TRY(hipMemset(p->runs_zero_flags, 0, bytes));
+        HIP_TRY(hipHostMalloc((void**)&p->runs_flags_host, bytes, hipHostMallocDefault));
+        p->runs_flags_n = cap;
     }
     return FFS_OK;
 }
@@ -781,9 +832,25 @@ int64_t next_pow2(int64_t x) {
     return n;
 }
 
-// Fill the candidate descriptor for (ref, sub); returns a negative code on error.  What only the transform path needs
-// (the plan-length check and the fp32 tie margin) is added by finish_cand_for_transforms.
-int fill_cand(const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd, int ref_dt, int cand_dt) {
+// Transform length a (R, S) pair needs under its lag window [d_lo, d_hi] (ffs_plan_length without the window arithmetic
+// the caller has already done, and without reading the environment).
+int64_t plan_length_core(int64_t R, int64_t S, int64_t n_ref, int64_t d_lo, int64_t d_hi, bool radix3_off) {
+    int64_t s_eff, r_eff;
+    effective_lengths(R, S, d_lo, d_hi, &s_eff, &r_eff);
+    int64_t need = s_eff + d_hi + 1;
+    if (r_eff - d_lo + 1 > need) need = r_eff - d_lo + 1;
+    if (s_eff > need) need = s_eff;
+    if (r_eff > need) need = r_eff;
+    int64_t n = next_pow2(need);
+    if (!radix3_off && n / 4 * 3 >= need && radix3_length(n / 4 * 3)) n = n / 4 * 3;
+    return n < n_ref ? n : n_ref;
+}
+
+// Fill the candidate descriptor for (ref, sub); returns a negative code on error -- including FFS_E_TOO_LONG when the
+// plan's transform length cannot hold the pair, on EVERY path (the run-boundary kernels would not need the transform,
+// but whether a call is accepted must not depend on how dense its vectors are).  The fp32 tie margin, which only the
+// transform path needs, is added by finish_cand_for_transforms.
+int fill_cand(const ffs_plan* p, const VecView& ref, const VecView& sub, int64_t max_off, CandDesc* cd, int ref_dt, int cand_dt) {
     const int64_t R = ref.len, S = sub.len;
     if (R <= 0 || S <= 0)
         return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
@@ -804,6 +871,12 @@ int fill_cand(const VecView& ref, const VecView& sub, int64_t max_off, CandDesc*
     } else {
         cd->d_lo = (int32_t)d_lo;
         cd->d_hi = (int32_t)d_hi;
+        if (!p->direct_only) {
+            const int64_t n_need = plan_length_core(R, S, n_ref, d_lo, d_hi, p->radix3_off);
+            if (n_need > p->N)
+                return fail(FFS_E_TOO_LONG, "R=%lld S=%lld needs transform length %lld > plan length %lld", (long long)R,
+                            (long long)S, (long long)n_need, (long long)p->N);
+        }
     }
     if (has_zero) {
         cd->flags |= CAND_HAS_ZERO;
@@ -818,11 +891,8 @@ int fill_cand(const VecView& ref, const VecView& sub, int64_t max_off, CandDesc*
 }
 
 int finish_cand_for_transforms(const ffs_plan* p, int64_t max_off, CandDesc* cd) {
+    (void)max_off;
     const int64_t R = cd->R, S = cd->S;
-    const int64_t n_need = ffs_plan_length(R, S, max_off);
-    if (n_need > p->N)
-        return fail(FFS_E_TOO_LONG, "R=%lld S=%lld needs transform length %lld > plan length %lld", (long long)R,
-                    (long long)S, (long long)n_need, (long long)p->N);
     const double as = fmax(fabs(cd->s0), fabs(cd->s1)), ar = fmax(fabs(cd->r0), fabs(cd->r1));
     const double lg = (double)ilog2(p->N > 2 ? p->N : 2);
     // measured max fp32 error of the pipeline: ~0.02 (activity density 0.5) to ~0.2 (density 0.2) of
@@ -911,6 +981,10 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         }
     } guard{p};
     p->device = device;
+    {
+        const char* e3 = getenv("FFS_DISABLE_RADIX3");
+        p->radix3_off = e3 && e3[0] == '1';
+    }
     p->N = n_fft;
     p->pairs_in_flight = pairs_in_flight;
     p->max_cand = max_cand;
@@ -1064,13 +1138,13 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->pool_entries);
     (void)hipFree(p->xlist);
     if (p->seg) (void)ffs_plan_destroy(p->seg);
-    (void)hipFree(p->runs_q);
-    (void)hipFree(p->runs_c);
+    (void)hipFree(p->runs_e);
     (void)hipFree(p->runs_n);
     (void)hipFree(p->runs_best);
     (void)hipFree(p->runs_flags);
+    (void)hipFree(p->runs_zero_flags);
     (void)hipFree(p->pack_buf);
-    if (p->runs_n_host) (void)hipHostFree(p->runs_n_host);
+    if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
     if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
     (void)hipFree(p->dev_desc);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
@@ -1083,16 +1157,40 @@ int ffs_plan_destroy(ffs_plan* p) {
 
 int64_t ffs_plan_workspace_bytes(const ffs_plan* p) { return p ? p->workspace_bytes : 0; }
 
+// Leaves the plan's stream bookkeeping consistent on every exit once work has been queued (an error return after a
+// kernel launch must still record the call's last event: the next call on another stream waits for it).
+struct StreamLeave {
+    ffs_plan* p;
+    hipStream_t st;
+    bool armed = false;
+    ~StreamLeave() {
+        if (armed) (void)leave_stream(p, st);
+    }
+};
+
+int grow_pack_buf(ffs_plan* p, size_t bytes) {
+    if (bytes <= p->pack_bytes) return FFS_OK;
+    if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+    (void)hipFree(p->pack_buf);
+    p->pack_buf = nullptr;
+    p->pack_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&p->pack_buf, bytes + bytes / 4));
+    p->pack_bytes = bytes + bytes / 4;
+    return FFS_OK;
+}
+
+// vec_bound (may be null): FFS_DTYPE_RUNS vectors only -- a host-known upper bound of the list's length (0: unknown).
 static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtype, const void* const* vec_ptr,
-                      const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
-                      int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
-                      void* hip_stream) {
+                      const int64_t* vec_len, const double* vec_lo, const double* vec_hi, const int32_t* vec_bound,
+                      int64_t max_offset_samples, int64_t filter_max_offset, ffs_cand_result* cand_out_dev,
+                      ffs_pair_result* pair_out_dev, void* hip_stream) {
     // `dtype` = the candidates' element type, `ref_dt` = the references'; `mixed` when they differ: the first pass
     // runs once per role (row_sel) and the exact re-evaluation goes through the type-generic instantiations (DT 4)
-    const bool mixed = ref_dt != dtype;
-    auto known = [](int dt) { return dt == FFS_DTYPE_U8 || dt == FFS_DTYPE_F32 || dt == FFS_DTYPE_U1 || dt == FFS_DTYPE_F64; };
+    auto known = [](int dt) {
+        return dt == FFS_DTYPE_U8 || dt == FFS_DTYPE_F32 || dt == FFS_DTYPE_U1 || dt == FFS_DTYPE_F64 || dt == FFS_DTYPE_RUNS;
+    };
     auto esz_of = [](int dt) -> size_t { return dt == FFS_DTYPE_U8 ? 1 : (dt == FFS_DTYPE_F32 ? 4 : (dt == FFS_DTYPE_F64 ? 8 : 0)); };
-    auto amask_of = [](int dt) -> uintptr_t { return dt == FFS_DTYPE_U8 ? 0 : (dt == FFS_DTYPE_F64 ? 7 : 3); };
+    auto amask_of = [](int dt) -> uintptr_t { return dt == FFS_DTYPE_U8 ? 0 : (dt == FFS_DTYPE_F64 || dt == FFS_DTYPE_RUNS ? 7 : 3); };
     if (!p) return fail(FFS_E_INVALID, "plan is null");
     if (n_pairs < 0 || n_cand < 1 || n_cand > p->max_cand)
         return fail(FFS_E_INVALID, "n_cand=%d outside [1, plan max_cand=%d]", n_cand, p->max_cand);
@@ -1100,62 +1198,117 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!vec_ptr || !vec_len || !vec_lo || !vec_hi || !cand_out_dev || !pair_out_dev)
         return fail(FFS_E_INVALID, "null argument");
     if (n_pairs == 0) return FFS_OK;
+    const int stride = 1 + n_cand;
+    const size_t n_vec = (size_t)n_pairs * (size_t)stride;
+    // ---- one contract for every path, checked before anything is queued: no empty vector (aligners.py:58-66), no null
+    // or misaligned pointer, no vector of 2^30 samples or more (positions are 32-bit; 0x3fffffff is the run-boundary
+    // kernels' "beyond everything").  The plan-length check (FFS_E_TOO_LONG whichever path would have served the pair) is
+    // part of fill_cand, which every path runs for every candidate.
+    for (int pi = 0; pi < n_pairs; ++pi) {
+        const size_t b = (size_t)pi * stride;
+        for (int v = 0; v < stride; ++v) {
+            const int dt = v ? dtype : ref_dt;
+            if (vec_len[b] <= 0 || vec_len[b + v] <= 0)
+                return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
+                            (long long)vec_len[b], (long long)vec_len[b + (v ? v : 1)]);
+            if (!vec_ptr[b + v]) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
+            if ((uintptr_t)vec_ptr[b + v] & amask_of(dt))
+                return fail(FFS_E_INVALID, "float / bit-packed vectors and boundary lists must be aligned to their element (pair %d)", pi);
+            if (vec_len[b + v] >= (int64_t(1) << 30))
+                return fail(FFS_E_TOO_LONG, "vector of %lld samples (pair %d): at most 2^30 - 1", (long long)vec_len[b + v], pi);
+        }
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    const bool lists_in = dtype == FFS_DTYPE_RUNS || ref_dt == FFS_DTYPE_RUNS;
+    auto runs_able = [](int dt) { return dt == FFS_DTYPE_U1 || dt == FFS_DTYPE_RUNS; };
     if (p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U8 && ref_dt == FFS_DTYPE_U8) {
         // 0/1 BYTES (the north star's literal input format): one pass packs every vector of the call to bits (bit =
         // byte != 0, exactly the two-level reading the byte kernels apply), then the call continues as FFS_DTYPE_U1 --
         // run-boundary path where the lists are short, transforms on an eighth of the input bytes otherwise.  Identical
         // records (tests/test_gpu_headline.py::test_byte_inputs_give_the_same_records; FFS_ALGO_FFT keeps the byte kernels).
-        const size_t nv = (size_t)n_pairs * (1 + (size_t)n_cand);
-        std::vector<size_t> off(nv + 1, 0);
+        std::vector<size_t> off(n_vec + 1, 0);
         int64_t len_max = 1;
-        for (size_t i = 0; i < nv; ++i) {
-            if (vec_len[i] <= 0)
-                return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
-                            (long long)vec_len[i / (1 + n_cand) * (1 + n_cand)], (long long)vec_len[i]);
-            if (!vec_ptr[i]) return fail(FFS_E_INVALID, "null device pointer for pair %d", (int)(i / (1 + n_cand)));
+        for (size_t i = 0; i < n_vec; ++i) {
             off[i + 1] = off[i] + (((size_t)(vec_len[i] + 31) / 32 * 4 + 63) & ~(size_t)63);
             if (vec_len[i] > len_max) len_max = vec_len[i];
         }
-        hipStream_t st0 = (hipStream_t)hip_stream;
         HIP_TRY(hipSetDevice(p->device));
         int rc0;
-        if ((rc0 = enter_stream(p, st0))) return rc0;
-        if (off[nv] > p->pack_bytes) {
-            if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
-            (void)hipFree(p->pack_buf);
-            p->pack_buf = nullptr;
-            p->pack_bytes = 0;
-            HIP_TRY(hipMalloc((void**)&p->pack_buf, off[nv] + off[nv] / 4));
-            p->pack_bytes = off[nv] + off[nv] / 4;
-        }
-        if ((rc0 = ensure_desc(p, nv * sizeof(PackVec) + 4096))) return rc0;
+        if ((rc0 = enter_stream(p, st))) return rc0;
+        if ((rc0 = grow_pack_buf(p, off[n_vec]))) return rc0;
+        if ((rc0 = ensure_desc(p, n_vec * sizeof(PackVec) + 4096))) return rc0;
         HIP_TRY(hipEventSynchronize(p->upload_done));
         PackVec* hp = (PackVec*)p->host_desc;
-        std::vector<const void*> packed(nv);
-        for (size_t i = 0; i < nv; ++i) {
+        std::vector<const void*> packed(n_vec);
+        for (size_t i = 0; i < n_vec; ++i) {
             unsigned* dst = (unsigned*)((char*)p->pack_buf + off[i]);
             hp[i] = PackVec{(const unsigned char*)vec_ptr[i], dst, (int32_t)vec_len[i], 0};
             packed[i] = dst;
         }
-        HIP_TRY(hipMemcpyAsync(p->dev_desc, hp, nv * sizeof(PackVec), hipMemcpyHostToDevice, st0));
-        HIP_TRY(hipEventRecord(p->upload_done, st0));
+        HIP_TRY(hipMemcpyAsync(p->dev_desc, hp, n_vec * sizeof(PackVec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(p->upload_done, st));
         const int chunks_per_vec = (int)(((len_max + 31) / 32 + 255) / 256);
-        hipLaunchKernelGGL(k_pack_bytes_batch, dim3((unsigned)(nv * chunks_per_vec)), dim3(256), 0, st0, (const PackVec*)p->dev_desc,
+        hipLaunchKernelGGL(k_pack_bytes_batch, dim3((unsigned)(n_vec * chunks_per_vec)), dim3(256), 0, st, (const PackVec*)p->dev_desc,
                            chunks_per_vec);
         HIP_TRY(hipGetLastError());
-        return align_impl(p, n_pairs, n_cand, FFS_DTYPE_U1, FFS_DTYPE_U1, packed.data(), vec_len, vec_lo, vec_hi, max_offset_samples,
-                          filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+        if ((rc0 = leave_stream(p, st))) return rc0;
+        return align_impl(p, n_pairs, n_cand, FFS_DTYPE_U1, FFS_DTYPE_U1, packed.data(), vec_len, vec_lo, vec_hi, nullptr,
+                          max_offset_samples, filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+    }
+    // Expands the call's list-only vectors (role `ref`/`cand` of type FFS_DTYPE_RUNS) to bits in the plan's pack buffer;
+    // `out` = the call's pointer table with those vectors replaced.  Queued on `st`.
+    auto expand_lists = [&](std::vector<const void*>* out) -> int {
+        std::vector<size_t> off(n_vec + 1, 0);
+        int64_t len_max = 1;
+        for (size_t i = 0; i < n_vec; ++i) {
+            const bool is_list = ((i % stride) ? dtype : ref_dt) == FFS_DTYPE_RUNS;
+            off[i + 1] = off[i] + (is_list ? (((size_t)(vec_len[i] + 31) / 32 * 4 + 63) & ~(size_t)63) : 0);
+            if (is_list && vec_len[i] > len_max) len_max = vec_len[i];
+        }
+        int rc0;
+        if ((rc0 = grow_pack_buf(p, off[n_vec]))) return rc0;
+        ExpandVec* d_ev = nullptr;
+        std::vector<ExpandVec> hev(n_vec);
+        out->assign(vec_ptr, vec_ptr + n_vec);
+        for (size_t i = 0; i < n_vec; ++i) {
+            const bool is_list = ((i % stride) ? dtype : ref_dt) == FFS_DTYPE_RUNS;
+            unsigned* dst = is_list ? (unsigned*)((char*)p->pack_buf + off[i]) : nullptr;
+            hev[i] = ExpandVec{(const int2*)((const char*)vec_ptr[i] + 16), (const int2*)vec_ptr[i], dst, (int32_t)vec_len[i], 0};
+            if (is_list) (*out)[i] = dst;
+        }
+        // (rare path: a synchronous upload keeps the host table's lifetime trivial)
+        HIP_TRY(hipMallocAsync((void**)&d_ev, n_vec * sizeof(ExpandVec), st));
+        HIP_TRY(hipMemcpyAsync(d_ev, hev.data(), n_vec * sizeof(ExpandVec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int chunks_per_vec = (int)(((len_max + 31) / 32 + 255) / 256);
+        hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)(n_vec * chunks_per_vec)), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks_per_vec);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipFreeAsync(d_ev, st));
+        return FFS_OK;
+    };
+    if (lists_in && (p->algo == FFS_ALGO_FFT || p->direct_only || !runs_able(dtype) || !runs_able(ref_dt))) {
+        // boundary lists where only the transforms (or the direct kernel of short plans) may run: as bits
+        HIP_TRY(hipSetDevice(p->device));
+        int rc0;
+        if ((rc0 = enter_stream(p, st))) return rc0;
+        std::vector<const void*> bits_ptr;
+        if ((rc0 = expand_lists(&bits_ptr))) return rc0;
+        if ((rc0 = leave_stream(p, st))) return rc0;
+        return align_impl(p, n_pairs, n_cand, ref_dt == FFS_DTYPE_RUNS ? FFS_DTYPE_U1 : ref_dt,
+                          dtype == FFS_DTYPE_RUNS ? FFS_DTYPE_U1 : dtype, bits_ptr.data(), vec_len, vec_lo, vec_hi, nullptr,
+                          max_offset_samples, filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
     }
     {
-        // The boundary lists of the run-boundary path take 256 KiB per vector: a call with more than 65 536 vectors of
-        // bit-packed two-level samples is solved as consecutive sub-calls (results land where one call would put them).
-        const int64_t stride = 1 + (int64_t)n_cand, max_pairs = (int64_t(1) << 16) / stride > 0 ? (int64_t(1) << 16) / stride : 1;
-        if (p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U1 && ref_dt == FFS_DTYPE_U1 && n_pairs > max_pairs) {
+        // The plan-owned boundary lists take 256 KiB per vector: a call with more than 65 536 vectors of bit-packed
+        // two-level samples is solved as consecutive sub-calls (results land where one call would put them).
+        const int64_t max_pairs = (int64_t(1) << 16) / stride > 0 ? (int64_t(1) << 16) / stride : 1;
+        if (p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && runs_able(ref_dt) && n_pairs > max_pairs) {
             for (int64_t p0 = 0; p0 < n_pairs; p0 += max_pairs) {
                 const int np = (int)((n_pairs - p0) < max_pairs ? (n_pairs - p0) : max_pairs);
                 const int rc_sub = align_impl(p, np, n_cand, ref_dt, dtype, vec_ptr + p0 * stride, vec_len + p0 * stride,
-                                              vec_lo + p0 * stride, vec_hi + p0 * stride, max_offset_samples, filter_max_offset,
-                                              cand_out_dev + p0 * n_cand, pair_out_dev + p0, hip_stream);
+                                              vec_lo + p0 * stride, vec_hi + p0 * stride, vec_bound ? vec_bound + p0 * stride : nullptr,
+                                              max_offset_samples, filter_max_offset, cand_out_dev + p0 * n_cand, pair_out_dev + p0,
+                                              hip_stream);
                 if (rc_sub) return rc_sub;
             }
             return FFS_OK;
@@ -1163,10 +1316,10 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     }
     static_assert(sizeof(CandResult) == sizeof(ffs_cand_result), "ABI struct mismatch");
     static_assert(sizeof(PairResult) == sizeof(ffs_pair_result), "ABI struct mismatch");
-    hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(p->device));
     int rc;
     if ((rc = enter_stream(p, st))) return rc;
+    StreamLeave leave{p, st};
     auto now_ns = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double ht0 = p->host_timing ? now_ns() : 0.0;
     double ht1 = ht0, ht2 = ht0, ht3 = ht0;
@@ -1187,15 +1340,24 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     const size_t n_cands = (size_t)n_pairs * n_cand;
     size_t n_xf = (size_t)n_pairs * xf_per_pair;
     const size_t n_xf_alloc = p->seg ? (size_t)n_pairs * kSegBlocks * n_slots : n_xf;  // block-segmented mode needs more
-    // descriptor block layout: [CandDesc n_cands][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
+    const int n_chunks = (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight;
+    // Run-boundary path: two-level vectors on both sides, as bits (FFS_DTYPE_U1: their lists are extracted here) or as
+    // boundary lists (FFS_DTYPE_RUNS); everything else, and every sub-batch whose lists turn out too long, goes through
+    // the transforms.  Its buffers come first: without them (out of memory) an AUTO call on bits still has the transforms.
+    bool runs_ok = p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && runs_able(ref_dt);
+    const bool need_extract = runs_ok && (dtype == FFS_DTYPE_U1 || ref_dt == FFS_DTYPE_U1);
+    if (runs_ok && (rc = ensure_runs(p, need_extract ? n_vec : 0, 0, (size_t)n_chunks))) {
+        if (lists_in || p->algo != FFS_ALGO_AUTO) return rc;
+        runs_ok = false;  // FFS_ALGO_AUTO: "only the time differs" -- the transforms need no list buffers
+    }
+    // the types the transform kernels see (list-only vectors are expanded to bits before they run)
+    const int t_dtype = dtype == FFS_DTYPE_RUNS ? FFS_DTYPE_U1 : dtype, t_ref_dt = ref_dt == FFS_DTYPE_RUNS ? FFS_DTYPE_U1 : ref_dt;
+    const bool mixed = t_ref_dt != t_dtype;
+    // descriptor block layout: [PoolHeader][CandDesc n_cands][RunsRef n_vec][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
     const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
     const size_t o_cand = 64;
-    // Run-boundary path: bit-packed two-level vectors on both sides (ffs_runs.h); everything else, and every sub-batch
-    // whose boundary lists turn out too long, goes through the transforms.
-    const bool runs_ok = p->algo != FFS_ALGO_FFT && !p->direct_only && dtype == FFS_DTYPE_U1 && ref_dt == FFS_DTYPE_U1;
-    const size_t n_vec = (size_t)n_pairs * (1 + (size_t)n_cand);
-    const size_t o_rv = o_cand + n_cands * sizeof(CandDesc);  // RunsVec[n_vec] when runs_ok
-    const size_t o_xf = (o_rv + (runs_ok ? n_vec * sizeof(RunsVec) : 0) + 63) & ~(size_t)63;
+    const size_t o_rv = o_cand + n_cands * sizeof(CandDesc);  // RunsRef[n_vec] when runs_ok
+    const size_t o_xf = (o_rv + (runs_ok ? n_vec * sizeof(RunsRef) : 0) + 63) & ~(size_t)63;
     const size_t host_bytes_max = o_xf + (n_xf_alloc > n_xf ? n_xf_alloc : n_xf) * sizeof(XformDesc);
     const size_t o_nom = (host_bytes_max + 255) & ~(size_t)255;
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
@@ -1211,56 +1373,51 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     }
     CandDesc* hc = (CandDesc*)(hb + o_cand);
     XformDesc* hx = (XformDesc*)(hb + o_xf);
-    const int stride = 1 + n_cand;
-    RunsVec* hrv = (RunsVec*)(hb + o_rv);
+    RunsRef* hrv = (RunsRef*)(hb + o_rv);
     char* db = (char*)p->dev_desc;
+    const void* const* xptr = vec_ptr;  // the vectors as the transform path reads them (list-only vectors: their expansion)
+    std::vector<const void*> expanded;
     if (runs_ok) {
-        // Run-boundary path, step 1: the boundary lists of every vector only need (pointer, length) -- launched before
-        // the candidate descriptors are built, so the host loop below runs while the device reads the vectors, and the
-        // list lengths are back by the time they are needed.
-        for (int pi = 0; pi < n_pairs; ++pi) {
-            const size_t b = (size_t)pi * stride;
-            for (int v = 0; v < stride; ++v) {
-                if (vec_len[b] <= 0 || vec_len[b + v] <= 0)
-                    return fail(FFS_E_EMPTY, "cannot align empty speech data (reference length=%lld, subtitle length=%lld)",
-                                (long long)vec_len[b], (long long)vec_len[b + (v ? v : 1)]);
-                if (!vec_ptr[b + v]) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
-                if ((uintptr_t)vec_ptr[b + v] & 3)
-                    return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
-                hrv[b + v] = RunsVec{(const unsigned*)vec_ptr[b + v], (int32_t)vec_len[b + v], 0};
+        // Run-boundary path, step 1: what the kernels need of every vector.  The lists of vectors that arrive as bits are
+        // extracted first -- the launch needs only this table, so the candidate descriptors are built while the device
+        // reads the vectors.
+        for (size_t i = 0; i < n_vec; ++i) {
+            const int dt = (i % stride) ? dtype : ref_dt;
+            if (dt == FFS_DTYPE_RUNS)  // caller-owned block: 16-byte header (n, ones, len, capacity), then the entries
+                hrv[i] = RunsRef{(const int2*)((const char*)vec_ptr[i] + 16), (const int2*)vec_ptr[i], nullptr, (int32_t)vec_len[i], 0};
+            else
+                hrv[i] = RunsRef{p->runs_e + i * RUNS_CAP, p->runs_n + i, (const unsigned*)vec_ptr[i], (int32_t)vec_len[i], RUNS_CAP};
+        }
+        if (need_extract) {
+            HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
+            leave.armed = true;
+            {
+                ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
+                hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
             }
+            HIP_TRY(hipGetLastError());
         }
-        if ((rc = ensure_runs(p, n_vec, 0))) return rc;
-        HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsVec), hipMemcpyHostToDevice, st));
-        {
-            ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-            hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsVec*)(db + o_rv), p->runs_q,
-                               p->runs_c, p->runs_n, RUNS_CAP);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(p->runs_n_host, p->runs_n, n_vec * sizeof(int2), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(p->runs_ev, st));
     }
     if (p->host_timing) ht1 = now_ns();
     int tiles_max = 1;
-    for (int pi = 0; pi < n_pairs; ++pi) {
-        const size_t b = (size_t)pi * stride;
-        const VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
-        for (int j = 0; j < n_cand; ++j) {
-            const VecView sub{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
-            if (!ref.ptr || !sub.ptr) {
-                if (ref.len > 0 && sub.len > 0) return fail(FFS_E_INVALID, "null device pointer for pair %d", pi);
-            }
-            if (((uintptr_t)ref.ptr & amask_of(ref_dt)) || ((uintptr_t)sub.ptr & amask_of(dtype)))
-                return fail(FFS_E_INVALID, "float / bit-packed vectors must be aligned to their element (pair %d)", pi);
-            CandDesc& cd = hc[(size_t)pi * n_cand + j];
-            if ((rc = fill_cand(ref, sub, max_offset_samples, &cd, ref_dt, dtype))) return rc;
-            if (runs_ok && !(cd.flags & CAND_NO_LAGS)) {
-                const int t = (cd.d_hi - cd.d_lo + RUNS_T) / RUNS_T;
-                if (t > tiles_max) tiles_max = t;
+    auto fill_all_cands = [&](const void* const* ptrs, int rdt, int cdt) -> int {
+        for (int pi = 0; pi < n_pairs; ++pi) {
+            const size_t b = (size_t)pi * stride;
+            const VecView ref{ptrs[b], vec_len[b], vec_lo[b], vec_hi[b]};
+            for (int j = 0; j < n_cand; ++j) {
+                const VecView sub{ptrs[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
+                CandDesc& cd = hc[(size_t)pi * n_cand + j];
+                int rcf;
+                if ((rcf = fill_cand(p, ref, sub, max_offset_samples, &cd, rdt, cdt))) return rcf;
+                if (runs_ok && !(cd.flags & CAND_NO_LAGS)) {
+                    const int t = (cd.d_hi - cd.d_lo + RUNS_T) / RUNS_T;
+                    if (t > tiles_max) tiles_max = t;
+                }
             }
         }
-    }
+        return FFS_OK;
+    };
+    if ((rc = fill_all_cands(vec_ptr, t_ref_dt, t_dtype))) return rc;
     // ---- descriptors of the transform path (built only when some sub-batch needs it) -------------------------
     BinList bins;
     memset(&bins, 0, sizeof bins);
@@ -1273,11 +1430,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     std::vector<VecView> views((size_t)n_pairs * stride);  // per pair: reference, candidates (reachable prefixes)
     for (int pi = 0; pi < n_pairs; ++pi) {
         const size_t b = (size_t)pi * stride;
-        VecView ref{vec_ptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
+        VecView ref{xptr[b], vec_len[b], vec_lo[b], vec_hi[b]};
         std::vector<VecView> subs(n_cand);
         int64_t ref_used = 1;
         for (int j = 0; j < n_cand; ++j) {
-            subs[j] = VecView{vec_ptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
+            subs[j] = VecView{xptr[b + 1 + j], vec_len[b + 1 + j], vec_lo[b + 1 + j], vec_hi[b + 1 + j]};
             const CandDesc& cd = hc[(size_t)pi * n_cand + j];
             // the transforms only read the prefixes that can reach the lag window (the exact re-evaluation
             // keeps working on the whole vectors through the candidate descriptor)
@@ -1325,7 +1482,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 seg_blocks = (int)((s_max + B - 1) / B);
                 seg_lo = d_lo;
                 // byte / float vectors move the pointer to the block's first sample, bit-packed ones the bit offset
-                const size_t esz = esz_of(dtype), esz_r = esz_of(ref_dt);
+                const size_t esz = esz_of(t_dtype), esz_r = esz_of(t_ref_dt);
                 n_xf = (size_t)n_pairs * seg_blocks * n_slots;
                 for (int pi = 0; pi < n_pairs; ++pi) {
                     const VecView& ref = views[(size_t)pi * stride];
@@ -1366,8 +1523,13 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     return FFS_OK;
     };
     if (!runs_ok && (rc = build_xforms())) return rc;
-    // one upload when the transforms run anyway; with the run-boundary path only [header, candidates] for now
-    HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
+    // one upload when the transforms run anyway; with the run-boundary path [header, candidates] (+ the vector table
+    // when no extraction was launched ahead of it)
+    if (runs_ok && !need_extract)
+        HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
+    else
+        HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
+    leave.armed = true;
     HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
     const CandDesc* dc = (const CandDesc*)(db + o_cand);
     const XformDesc* dx = (const XformDesc*)(db + o_xf);
@@ -1379,75 +1541,104 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     pa.half_last = (hflags & HALF_LAST) ? 1 : 0;
     CandResult* cres = (CandResult*)cand_out_dev;
     PairResult* pres = (PairResult*)pair_out_dev;
+    const int dt = t_dtype;  // (the transform kernels' element type of the candidates)
 
+    std::vector<char> chunk_fft((size_t)n_chunks, runs_ok ? 0 : 1);
+    bool any_fft = !runs_ok;
     if (p->direct_only) {
-        FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
+        FFS_BY_RESCORE_DTYPE(mixed, dt, hipLaunchKernelGGL((k_direct<DT>), dim3((unsigned)n_cands), dim3(256), 0, st, dc, cres));
         HIP_TRY(hipGetLastError());
     } else {
-        // ---- run-boundary path: boundary lists of every vector, exact correlation of every candidate whose lists are
-        // short enough; the list lengths come back (one event wait) and decide which sub-batches need the transforms
-        const int n_chunks = (n_pairs + p->pairs_in_flight - 1) / p->pairs_in_flight;
-        std::vector<char> chunk_fft((size_t)n_chunks, runs_ok ? 0 : 1);
-        bool any_fft = !runs_ok;
+        // ---- run-boundary path: exact correlation of every candidate whose lists are short enough, candidate and pair
+        // records written by the kernel itself; which sub-batches need the transforms instead is decided on the device
+        // (k_runs_chunk_flags) and read back as one int per sub-batch -- after everything else of the call is queued
         if (runs_ok) {
-            if ((rc = ensure_runs(p, n_vec, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0))) return rc;
+            if ((rc = ensure_runs(p, need_extract ? n_vec : 0, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0, (size_t)n_chunks)))
+                return rc;
             const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4
                                      : p->runs_budget >= 0 ? p->runs_budget
                                                            : 8 * (long long)p->N * (n_cand + 1) / (2 * n_cand);
-            if ((size_t)n_chunks > p->runs_flags_n) {
-                if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
-                (void)hipFree(p->runs_flags);
-                p->runs_flags = nullptr;
-                p->runs_flags_n = 0;
-                HIP_TRY(hipMalloc((void**)&p->runs_flags, ((size_t)n_chunks + 64) * sizeof(int)));
-                p->runs_flags_n = (size_t)n_chunks + 64;
+            // Lists that arrive with host-known length bounds (the rasteriser's: two entries per subtitle) settle the
+            // question on the host: within budget even at the bounds -> no flags kernel, no copy back, no wait.
+            bool proven = !need_extract && vec_bound != nullptr;
+            for (int pi = 0; proven && pi < n_pairs; ++pi) {
+                const size_t bq = (size_t)pi * stride;
+                if (vec_bound[bq] <= 0) proven = false;
+                for (int j = 0; proven && j < n_cand; ++j) {
+                    const CandDesc& cd = hc[(size_t)pi * n_cand + j];
+                    if (vec_bound[bq + 1 + j] <= 0 ||
+                        (!(cd.flags & CAND_NO_LAGS) &&
+                         runs_over_budget(vec_bound[bq + 1 + j], vec_bound[bq], INT64_MAX, INT64_MAX, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget)))
+                        proven = false;
+                }
+            }
+            const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 8;
+            unsigned long long* d_stats = (unsigned long long*)((char*)p->runs_flags + flag_bytes - 8);
+            const int* d_flags = proven ? p->runs_zero_flags : p->runs_flags;
+            if (!proven) {
+                HIP_TRY(hipMemsetAsync(d_stats, 0, 8, st));
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
+                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(p->runs_ev, st));
             }
             {
                 ProfSpan span(p, st, FFS_K_RUNS_CORR);
-                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
-                                   p->pairs_in_flight, p->runs_n, RUNS_CAP, budget, p->runs_flags);
-                hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(256), 0, st, dc, n_cand, p->runs_q,
-                                   p->runs_c, p->runs_n, RUNS_CAP, dn, da, p->runs_best, tiles_max, p->runs_flags,
-                                   p->pairs_in_flight);
+                hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st, dc, n_cand,
+                                   (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight);
                 if (tiles_max > 1)
                     hipLaunchKernelGGL(k_runs_pick, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, (int)n_cands, n_cand,
-                                       p->runs_best, tiles_max, dn, da, p->runs_flags, p->pairs_in_flight);
+                                       p->runs_best, tiles_max, cres, d_flags, p->pairs_in_flight);
             }
+            // (pairs of sub-batches that go through the transforms are finished again behind those)
+            hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
+                               (long long)filter_max_offset);
             HIP_TRY(hipGetLastError());
             if (p->host_timing) ht2 = now_ns();
-            HIP_TRY(hipEventSynchronize(p->runs_ev));  // the list lengths are on the host; k_runs_corr keeps the device busy
-            if (p->host_timing) ht3 = now_ns();
-            for (int pi = 0; pi < n_pairs; ++pi) {
-                const int ch = pi / p->pairs_in_flight;
-                if (chunk_fft[ch]) continue;
-                const int2 nr = p->runs_n_host[(size_t)pi * stride];
-                for (int j = 0; j < n_cand; ++j) {
-                    const CandDesc& cd = hc[(size_t)pi * n_cand + j];
-                    if (cd.flags & CAND_NO_LAGS) continue;
-                    if (runs_over_budget(p->runs_n_host[(size_t)pi * stride + 1 + j].x, nr.x, (long long)cd.d_hi - cd.d_lo + 1, cd.R,
-                                         RUNS_CAP, budget)) {
-                        chunk_fft[ch] = 1;
-                        any_fft = true;
-                        break;
-                    }
-                }
-            }
             p->runs_calls += 1;
             p->runs_chunks += n_chunks;
-            p->runs_last_boundaries = 0;
-            for (size_t i = 0; i < n_vec; ++i) p->runs_last_boundaries += p->runs_n_host[i].x;
-            if (any_fft) {
-                for (int ch = 0; ch < n_chunks; ++ch) p->runs_fft_chunks += chunk_fft[ch];
-                if ((rc = build_xforms())) return rc;  // also completes the candidate descriptors (tie margins)
-                HIP_TRY(hipMemcpyAsync(db + o_cand, hb + o_cand, o_xf + n_xf * sizeof(XformDesc) - o_cand, hipMemcpyHostToDevice, st));
-                for (int ch = 0; ch < n_chunks; ++ch) {  // clean accumulators for the sub-batches that are solved again
-                    if (!chunk_fft[ch]) continue;
-                    const size_t c0 = (size_t)ch * p->pairs_in_flight * n_cand;
-                    const size_t c1 = c0 + (size_t)p->pairs_in_flight * n_cand < n_cands ? c0 + (size_t)p->pairs_in_flight * n_cand : n_cands;
-                    HIP_TRY(hipMemsetAsync(da + c0 * KNOM, 0, (c1 - c0) * KNOM * sizeof(RescoreAcc), st));
-                    HIP_TRY(hipMemsetAsync(dpb + c0, 0, (c1 - c0) * sizeof(PoolBest), st));
+            p->runs_last_boundaries = -1;  // (not known on the host when nothing was copied back)
+            if (!proven) {
+                // a stream of dense calls: the transform descriptors are built while the device extracts and decides
+                bool built = false;
+                if (p->runs_prev_fft && !lists_in) {
+                    if ((rc = build_xforms())) return rc;
+                    built = true;
                 }
-                HIP_TRY(hipEventRecord(p->upload_done, st));
+                HIP_TRY(hipEventSynchronize(p->runs_ev));  // k_runs_corr keeps the device busy meanwhile
+                if (p->host_timing) ht3 = now_ns();
+                bool bad = false;
+                for (int ch = 0; ch < n_chunks; ++ch) {
+                    const int f = p->runs_flags_host[ch];
+                    if (f == 2) bad = true;
+                    if (f) chunk_fft[ch] = 1, any_fft = true;
+                }
+                memcpy(&p->runs_last_boundaries, (char*)p->runs_flags_host + flag_bytes - 8, 8);
+                if (bad)
+                    return fail(FFS_E_INVALID, "a boundary list of the call is truncated (more entries than its block holds): "
+                                "nothing can solve it -- pass the vector as bits");
+                p->runs_prev_fft = any_fft;
+                if (any_fft) {
+                    for (int ch = 0; ch < n_chunks; ++ch) p->runs_fft_chunks += chunk_fft[ch];
+                    if (lists_in) {  // the transforms read bits: expand the list-only vectors, point the descriptors at them
+                        if ((rc = expand_lists(&expanded))) return rc;
+                        xptr = expanded.data();
+                        int tm = tiles_max;
+                        if ((rc = fill_all_cands(xptr, t_ref_dt, t_dtype))) return rc;
+                        tiles_max = tm;
+                    }
+                    if (!built && (rc = build_xforms())) return rc;  // also completes the candidate descriptors (tie margins)
+                    HIP_TRY(hipMemcpyAsync(db + o_cand, hb + o_cand, o_xf + n_xf * sizeof(XformDesc) - o_cand, hipMemcpyHostToDevice, st));
+                    for (int ch = 0; ch < n_chunks; ++ch) {  // clean accumulators for the sub-batches that are solved again
+                        if (!chunk_fft[ch]) continue;
+                        const size_t c0 = (size_t)ch * p->pairs_in_flight * n_cand;
+                        const size_t c1 = c0 + (size_t)p->pairs_in_flight * n_cand < n_cands ? c0 + (size_t)p->pairs_in_flight * n_cand : n_cands;
+                        HIP_TRY(hipMemsetAsync(da + c0 * KNOM, 0, (c1 - c0) * KNOM * sizeof(RescoreAcc), st));
+                        HIP_TRY(hipMemsetAsync(dpb + c0, 0, (c1 - c0) * sizeof(PoolBest), st));
+                    }
+                    HIP_TRY(hipEventRecord(p->upload_done, st));
+                }
             }
         } else {
             HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
@@ -1473,10 +1664,10 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             {
                 ProfSpan span(p, st, FFS_K_PASS_A);
                 if (mixed) {  // the reference slot of every group in its own type, then the candidate slots in theirs
-                    FFS_BY_DTYPE(ref_dt, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_ref));
-                    if (!rc) FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_cand));
+                    FFS_BY_DTYPE(t_ref_dt, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_ref));
+                    if (!rc) FFS_BY_DTYPE(t_dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st, sel_cand));
                 } else {
-                    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st));
+                    FFS_BY_DTYPE(t_dtype, rc = launch_pass_a<DT>(sp, dxs, np * seg_blocks * n_slots, n_slots, n_slots, sflags, st));
                 }
             }
             if (rc) return rc;
@@ -1503,7 +1694,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 return rc;
             {
                 ProfSpan span(p, st, FFS_K_RESCORE);
-                FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
+                FFS_BY_RESCORE_DTYPE(mixed, t_dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
                                                                       st, dc, dn, da, first_cand));
             }
             HIP_TRY(hipGetLastError());
@@ -1515,12 +1706,12 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             {
                 ProfSpan sp(p, st, FFS_K_PASS_A);
                 if (mixed) {
-                    FFS_BY_DTYPE(ref_dt, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
+                    FFS_BY_DTYPE(t_ref_dt, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
                                                                 n_slots, hflags, st, sel_ref));
-                    if (!rc) FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair,
+                    if (!rc) FFS_BY_DTYPE(t_dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair,
                                                                         xf_per_pair, n_slots, hflags, st, sel_cand));
                 } else {
-                    FFS_BY_DTYPE(dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
+                    FFS_BY_DTYPE(t_dtype, rc = launch_pass_a<DT>(p, dx + (size_t)p0 * xf_per_pair, np * xf_per_pair, xf_per_pair,
                                                                n_slots, hflags, st));
                 }
             }
@@ -1551,22 +1742,39 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             if (rc) return rc;
             {
                 ProfSpan sp(p, st, FFS_K_RESCORE);
-                FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
+                FFS_BY_RESCORE_DTYPE(mixed, t_dtype, hipLaunchKernelGGL((k_rescore<DT>), dim3(DT == 2 ? 4 : RSEG, np * n_cand), dim3(256), 0,
                                                                       st, dc, dn, da, first_cand));
             }
             HIP_TRY(hipGetLastError());
         }
         if (any_fft) {
-            FFS_BY_RESCORE_DTYPE(mixed, dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
+            FFS_BY_RESCORE_DTYPE(mixed, t_dtype, hipLaunchKernelGGL((k_pool_rescore<DT>), dim3(2048), dim3(256), 0, st, dc, pa.header, pa.entries, dpb));
             hipLaunchKernelGGL(k_pool_pick, dim3(256), dim3(256), 0, st, pa.header, pa.entries, dpb);
         }
-        hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, dn, da, cres,
-                           (int)n_cands, mixed ? 4 : dtype, pa.header, dpb);
+        // candidate and pair records of everything the transforms solved (the run-boundary kernels wrote their own)
+        auto finalize_range = [&](size_t c0, size_t c1, int p0, int p1) {
+            hipLaunchKernelGGL(k_finalize_cands, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, st, dc + c0, dn + c0,
+                               da + c0 * KNOM, cres + c0, (int)(c1 - c0), mixed ? 4 : t_dtype, pa.header, dpb + c0);
+            hipLaunchKernelGGL(k_finalize_pairs, dim3((unsigned)((p1 - p0 + 255) / 256)), dim3(256), 0, st, cres + (size_t)p0 * n_cand,
+                               pres + p0, p1 - p0, n_cand, (long long)filter_max_offset);
+        };
+        if (!runs_ok) {
+            finalize_range(0, n_cands, 0, n_pairs);
+        } else {
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                if (!chunk_fft[ch]) continue;
+                const int p0 = ch * p->pairs_in_flight, p1 = (p0 + p->pairs_in_flight) < n_pairs ? (p0 + p->pairs_in_flight) : n_pairs;
+                finalize_range((size_t)p0 * n_cand, (size_t)p1 * n_cand, p0, p1);
+            }
+        }
         HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
-                       (long long)filter_max_offset);
-    HIP_TRY(hipGetLastError());
+    if (p->direct_only) {
+        hipLaunchKernelGGL(k_finalize_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, cres, pres, n_pairs, n_cand,
+                           (long long)filter_max_offset);
+        HIP_TRY(hipGetLastError());
+    }
+    leave.armed = false;
     rc = leave_stream(p, st);
     if (p->host_timing && runs_ok) {
         const double ht4 = now_ns();
@@ -1579,14 +1787,14 @@ int ffs_align_batch(ffs_plan* p, int n_pairs, int n_cand, int dtype, const void*
                     const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
                     int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
                     void* hip_stream) {
-    return align_impl(p, n_pairs, n_cand, dtype, dtype, vec_ptr, vec_len, vec_lo, vec_hi, max_offset_samples,
+    return align_impl(p, n_pairs, n_cand, dtype, dtype, vec_ptr, vec_len, vec_lo, vec_hi, nullptr, max_offset_samples,
                       filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
 }
 
-int ffs_align_batch_typed(ffs_plan* p, int n_pairs, int n_cand, const int32_t* vec_dtype, const void* const* vec_ptr,
-                          const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
-                          int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
-                          void* hip_stream) {
+int ffs_align_batch_runs(ffs_plan* p, int n_pairs, int n_cand, const int32_t* vec_dtype, const void* const* vec_ptr,
+                         const int64_t* vec_len, const double* vec_lo, const double* vec_hi, const int32_t* vec_max_boundaries,
+                         int64_t max_offset_samples, int64_t filter_max_offset, ffs_cand_result* cand_out_dev,
+                         ffs_pair_result* pair_out_dev, void* hip_stream) {
     if (!vec_dtype) return fail(FFS_E_INVALID, "null argument");
     if (n_pairs <= 0 || n_cand < 1) return n_pairs == 0 ? FFS_OK : fail(FFS_E_INVALID, "bad n_pairs / n_cand");
     // one type per ROLE: every reference of the call shares vec_dtype[0], every candidate vec_dtype[1]
@@ -1596,8 +1804,53 @@ int ffs_align_batch_typed(ffs_plan* p, int n_pairs, int n_cand, const int32_t* v
         if (vec_dtype[i] != (i % stride == 0 ? ref_dt : cand_dt))
             return fail(FFS_E_INVALID, "vector %zu has element type %d: within one call all references must share one type "
                         "and all candidates one type (split the call)", i, (int)vec_dtype[i]);
-    return align_impl(p, n_pairs, n_cand, ref_dt, cand_dt, vec_ptr, vec_len, vec_lo, vec_hi, max_offset_samples,
+    return align_impl(p, n_pairs, n_cand, ref_dt, cand_dt, vec_ptr, vec_len, vec_lo, vec_hi, vec_max_boundaries, max_offset_samples,
                       filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+}
+
+int ffs_align_batch_typed(ffs_plan* p, int n_pairs, int n_cand, const int32_t* vec_dtype, const void* const* vec_ptr,
+                          const int64_t* vec_len, const double* vec_lo, const double* vec_hi, int64_t max_offset_samples,
+                          int64_t filter_max_offset, ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                          void* hip_stream) {
+    return ffs_align_batch_runs(p, n_pairs, n_cand, vec_dtype, vec_ptr, vec_len, vec_lo, vec_hi, nullptr, max_offset_samples,
+                                filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+}
+
+int64_t ffs_runs_list_bytes(int64_t cap) { return cap < 0 ? 0 : 16 + 8 * cap; }
+
+int ffs_runs_from_bits(const uint32_t* bits_dev, int64_t len, void* list_dev, int64_t cap, void* hip_stream) {
+    if (!bits_dev || !list_dev) return fail(FFS_E_INVALID, "null argument");
+    if (len <= 0 || len >= (int64_t(1) << 30)) return fail(len <= 0 ? FFS_E_EMPTY : FFS_E_TOO_LONG, "vector of %lld samples", (long long)len);
+    if (cap < 1 || cap >= (int64_t(1) << 28)) return fail(FFS_E_INVALID, "list capacity %lld outside [1, 2^28)", (long long)cap);
+    if (((uintptr_t)bits_dev & 3) || ((uintptr_t)list_dev & 7)) return fail(FFS_E_INVALID, "misaligned pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
+    int rc_dev;
+    if ((rc_dev = guard.enter(list_dev))) return rc_dev;
+    hipLaunchKernelGGL(k_runs_extract_one, dim3(1), dim3(256), 0, st, (const unsigned*)bits_dev, (int)len,
+                       (int2*)((char*)list_dev + 16), (int2*)list_dev, (int)cap);
+    HIP_TRY(hipGetLastError());
+    return FFS_OK;
+}
+
+int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, void* hip_stream) {
+    if (!list_dev || !bits_out_dev) return fail(FFS_E_INVALID, "null argument");
+    if (len <= 0 || len >= (int64_t(1) << 30)) return fail(len <= 0 ? FFS_E_EMPTY : FFS_E_TOO_LONG, "vector of %lld samples", (long long)len);
+    if (((uintptr_t)bits_out_dev & 3) || ((uintptr_t)list_dev & 7)) return fail(FFS_E_INVALID, "misaligned pointer");
+    hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
+    int rc_dev;
+    if ((rc_dev = guard.enter(list_dev))) return rc_dev;
+    ExpandVec ev{(const int2*)((const char*)list_dev + 16), (const int2*)list_dev, (unsigned*)bits_out_dev, (int32_t)len, 0};
+    ExpandVec* d_ev = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d_ev, sizeof ev, st));
+    HIP_TRY(hipMemcpyAsync(d_ev, &ev, sizeof ev, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (ev is a stack temporary)
+    const int chunks = (int)(((len + 31) / 32 + 255) / 256);
+    hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)chunks), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipFreeAsync(d_ev, st));
+    return FFS_OK;
 }
 
 int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_len, double ref_lo, double ref_hi,
@@ -1818,6 +2071,97 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
                            is_metadata ? (const unsigned char*)(d + off_meta) : nullptr, (const RasterVec*)(d + off_vec),
                            (int)n_vec, sample_rate, start_seconds, out_dev);
         if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_rasterize_batch launch failed");
+    }
+    (void)hipFreeAsync(d, st);
+    return rc;
+}
+
+int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata, int64_t n_subs_total,
+                             const int64_t* vec_sub_first, const int64_t* vec_sub_count, const double* vec_ratio,
+                             const int64_t* vec_out_off, const int64_t* vec_cap, const int64_t* vec_len, int64_t n_vec,
+                             double sample_rate, double start_seconds, void* out_dev, int64_t out_bytes, void* hip_stream) {
+    if (n_vec < 0 || n_subs_total < 0 || out_bytes < 0) return fail(FFS_E_INVALID, "bad argument");
+    if (n_vec > 0 && (!vec_sub_first || !vec_sub_count || !vec_ratio || !vec_out_off || !vec_cap || !vec_len))
+        return fail(FFS_E_INVALID, "null vector table");
+    if (n_subs_total > 0 && (!start_us || !end_us)) return fail(FFS_E_INVALID, "null subtitle arrays");
+    if (n_vec > 0 && (!out_dev || ((uintptr_t)out_dev & 7))) return fail(FFS_E_INVALID, "null or misaligned output");
+    if (n_vec >= (int64_t(1) << 31)) return fail(FFS_E_INVALID, "too many vectors");
+    if (start_seconds > 0.0)
+        return fail(FFS_E_INVALID, "start_seconds > 0 can make start samples negative (Python slices wrap them around): "
+                    "use ffs_rasterize_batch_bits");
+    if (n_vec == 0) return FFS_OK;
+    // Tracks must reach the kernel sorted by start time.  Unsorted ones (rare) are sorted into extra rows behind the
+    // caller's; vectors naming the same unsorted range share one copy.
+    std::vector<int64_t> xs, xe;
+    std::vector<uint8_t> xm;
+    std::vector<RasterRunsVec> vecs((size_t)n_vec);
+    int64_t last_first = -1, last_count = -1, last_new_first = -1;
+    for (int64_t v = 0; v < n_vec; ++v) {
+        const int64_t f = vec_sub_first[v], c = vec_sub_count[v];
+        if (f < 0 || c < 0 || f + c > n_subs_total) return fail(FFS_E_INVALID, "vector %lld: subtitle range outside the arrays", (long long)v);
+        if (c >= (int64_t(1) << 27)) return fail(FFS_E_INVALID, "vector %lld: too many subtitles", (long long)v);
+        if (vec_len[v] < 0 || vec_len[v] >= (int64_t(1) << 30)) return fail(FFS_E_TOO_LONG, "raster longer than 2^30 - 1 samples");
+        if (vec_cap[v] < 2 * c + 1 || vec_cap[v] >= (int64_t(1) << 28))
+            return fail(FFS_E_INVALID, "vector %lld: list capacity %lld below 2 * %lld subtitles + 1", (long long)v, (long long)vec_cap[v], (long long)c);
+        if (vec_out_off[v] < 0 || (vec_out_off[v] & 7) || vec_out_off[v] + ffs_runs_list_bytes(vec_cap[v]) > out_bytes)
+            return fail(FFS_E_INVALID, "vector %lld: list block outside the buffer or misaligned", (long long)v);
+        int64_t first = f;
+        if (f == last_first && c == last_count) {
+            first = last_new_first;
+        } else {
+            bool sorted = true;
+            for (int64_t i = f + 1; i < f + c && sorted; ++i) sorted = start_us[i - 1] <= start_us[i];
+            if (!sorted) {
+                std::vector<int64_t> idx((size_t)c);
+                for (int64_t i = 0; i < c; ++i) idx[(size_t)i] = f + i;
+                std::stable_sort(idx.begin(), idx.end(), [&](int64_t x, int64_t y) { return start_us[x] < start_us[y]; });
+                first = n_subs_total + (int64_t)xs.size();
+                for (int64_t i : idx) {
+                    xs.push_back(start_us[i]);
+                    xe.push_back(end_us[i]);
+                    xm.push_back(is_metadata ? is_metadata[i] : 0);
+                }
+            }
+            last_first = f, last_count = c, last_new_first = first;
+        }
+        vecs[(size_t)v] = RasterRunsVec{(long long)first, (long long)vec_out_off[v], vec_ratio[v], (int32_t)c, (int32_t)vec_len[v],
+                                        (int32_t)vec_cap[v], 0};
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
+    int rc_dev;
+    if ((rc_dev = guard.enter(out_dev))) return rc_dev;
+    // one staging allocation: start | end | vector table | metadata flags (see ffs_rasterize_batch_bits)
+    const size_t nsub = (size_t)n_subs_total + xs.size(), off_end = nsub * 8, off_vec = 2 * nsub * 8;
+    const bool with_meta = is_metadata != nullptr;
+    const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterRunsVec), total = off_meta + (with_meta ? nsub : 0);
+    PinnedStage* stage = nullptr;
+    int rc = stage_acquire(total, &stage);
+    if (rc) return rc;
+    char* hs = (char*)stage->host;
+    const size_t n0 = (size_t)n_subs_total;
+    if (n0) {
+        memcpy(hs, start_us, n0 * 8);
+        memcpy(hs + off_end, end_us, n0 * 8);
+    }
+    if (!xs.empty()) {
+        memcpy(hs + n0 * 8, xs.data(), xs.size() * 8);
+        memcpy(hs + off_end + n0 * 8, xe.data(), xe.size() * 8);
+    }
+    memcpy(hs + off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterRunsVec));
+    if (with_meta) {
+        if (n0) memcpy(hs + off_meta, is_metadata, n0);
+        if (!xm.empty()) memcpy(hs + off_meta + n0, xm.data(), xm.size());
+    }
+    char* d = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d, total, st));
+    if (hipMemcpyAsync(d, hs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
+    if (rc == FFS_OK) {
+        hipLaunchKernelGGL(k_rasterize_runs, dim3((unsigned)n_vec), dim3(256), 0, st, (const long long*)d, (const long long*)(d + off_end),
+                           with_meta ? (const unsigned char*)(d + off_meta) : nullptr, (const RasterRunsVec*)(d + off_vec), sample_rate,
+                           start_seconds, (char*)out_dev);
+        if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_rasterize_runs launch failed");
     }
     (void)hipFreeAsync(d, st);
     return rc;

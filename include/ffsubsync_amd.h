@@ -46,6 +46,15 @@ extern "C" {
                            little-endian word i >> 5 (numpy.packbits(..., bitorder="little")); 0 -> lo, 1 -> hi.
                            The native format of the 0/1 activity vectors: an eighth of the HBM and PCIe bytes of
                            FFS_DTYPE_U8.  Pointers 4-byte aligned; the buffer must cover whole 32-bit words. */
+#define FFS_DTYPE_RUNS 5 /* two-level signal as its BOUNDARY LIST (what speech_transformers.py:957-980 is handed: the
+                           subtitles' intervals).  The pointer is a device block `ffs_runs_list` (8-byte aligned):
+                             int32 n, ones, len, cap;           -- boundaries, samples at the upper level, samples, entries
+                             struct { int32 pos, ones_before; } e[cap];
+                           e[k].pos (k < n, ascending, n even) = a sample where the value changes -- even k: a run of
+                           the upper level starts, odd k: one past its last sample (a run that reaches the end closes at
+                           `len`); e[k].ones_before = upper-level samples in front of it; e[n] = (INT32_MAX, ones).
+                           Producers: ffs_rasterize_batch_runs, ffs_runs_from_bits.  A list with n >= cap is truncated
+                           and unusable.  ffs_runs_list_bytes(cap) = 16 + 8 * cap. */
 
 /* result flags */
 #define FFS_FLAG_EMPTY_WINDOW 1 /* every lag masked: score=-inf, offset=N-1-S (aligners.py:45-48) */
@@ -142,12 +151,37 @@ int ffs_align_batch_typed(ffs_plan* plan, int n_pairs, int n_cand, const int32_t
                           ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
                           void* hip_stream);
 
+/* ffs_align_batch_typed plus, for FFS_DTYPE_RUNS vectors, vec_max_boundaries[i] (may be NULL; other types: ignored) = a
+ * HOST-KNOWN upper bound of list i's length (0 = unknown) -- the rasteriser's lists have at most two entries per
+ * subtitle.  When every vector of the call is a list with a bound and no candidate can exceed the coincidence budget
+ * even at the bounds, the call queues its kernels and returns without waiting for anything from the device; otherwise it
+ * waits once for one int per sub-batch (which sub-batches need the transforms).  A call whose lists break their stated
+ * bounds has undefined results.
+ * Replaces: aligners.py:50-80, 131-167 fed straight from speech_transformers.py:957-980 (no raster in between). */
+int ffs_align_batch_runs(ffs_plan* plan, int n_pairs, int n_cand, const int32_t* vec_dtype,
+                         const void* const* vec_ptr, const int64_t* vec_len,
+                         const double* vec_lo, const double* vec_hi, const int32_t* vec_max_boundaries,
+                         int64_t max_offset_samples, int64_t filter_max_offset,
+                         ffs_cand_result* cand_out_dev, ffs_pair_result* pair_out_dev,
+                         void* hip_stream);
+
+/* Bytes of an `ffs_runs_list` block with room for `cap` entries (sentinel included): 16 + 8 * cap. */
+int64_t ffs_runs_list_bytes(int64_t cap);
+/* Boundary list of a bit-packed vector (FFS_DTYPE_U1, `len` samples at bits_dev) into the caller's block list_dev of
+ * capacity `cap` entries (8-byte aligned, ffs_runs_list_bytes(cap) bytes): one pass over the bits.  A vector with cap
+ * boundaries or more leaves n >= cap in the header (truncated).  Convert once -- VAD labels, a deserialised reference
+ * (speech_transformers.py:993-1005) -- and every later solve skips the pass over the bits. */
+int ffs_runs_from_bits(const uint32_t* bits_dev, int64_t len, void* list_dev, int64_t cap, void* hip_stream);
+/* The inverse (parity tests; the transform path uses the same kernel for list-only vectors): `len` samples of the
+ * list's vector as FFS_DTYPE_U1 words at bits_out_dev (ceil(len/32) words). */
+int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, void* hip_stream);
+
 /* How ffs_align_batch / ffs_align_batch_typed evaluate the correlation of aligners.py:50-80.  Results are identical
  * either way (same exact scores, same tie rule); only the time differs.
- *   FFS_ALGO_AUTO (default): bit-packed two-level vectors (FFS_DTYPE_U1 on both sides) first go through the
- *     run-boundary path -- the exact integer correlation of the two run-length-coded vectors over every lag of the
- *     window, no transform (csrc/ffs_runs.h) -- and the call waits once (an event, not the stream) for the lengths of the
- *     boundary lists; sub-batches (pairs_in_flight pairs) holding a vector with 32 767 boundaries or more, or a candidate
+ *   FFS_ALGO_AUTO (default): two-level vectors given as bits or as boundary lists (FFS_DTYPE_U1 / FFS_DTYPE_RUNS on both
+ *     sides) first go through the run-boundary path -- the exact integer correlation of the two run-length-coded vectors
+ *     over every lag of the window, no transform (csrc/ffs_runs.h) -- and the call waits once (an event, not the stream,
+ *     after all of its kernels are queued) for one int per sub-batch: whether it needs the transforms; sub-batches (pairs_in_flight pairs) holding a vector with 32 768 boundaries or more, or a candidate
  *     whose expected number of boundary coincidences inside its lag window (boundaries of the candidate x boundaries of
  *     the reference x window lags / reference length) exceeds the budget -- by default eight per point of the plan's
  *     transform length and packed transform slot the candidate occupies, (n_cand + 1) / (2 n_cand) of one: the measured
@@ -261,6 +295,20 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
                              const double* vec_ratio, const int64_t* vec_out_word, const int64_t* vec_len, int64_t n_vec,
                              double sample_rate, double start_seconds, uint32_t* out_dev, int64_t out_words,
                              void* hip_stream);
+
+/* The same tracks as BOUNDARY LISTS (FFS_DTYPE_RUNS): no bitmap is written -- the union of a track's scaled sample
+ * intervals, overlapping and touching subtitles merged, IS the list (samples[start:end] = ... for every subtitle,
+ * speech_transformers.py:966-977, then read back as runs).  Vector v's block starts at byte vec_out_off[v] of out_dev
+ * (multiple of 8) and has room for vec_cap[v] >= 2 * vec_sub_count[v] + 1 entries (ffs_runs_list_bytes).  Expanded to
+ * bits (ffs_runs_to_bits) a list equals ffs_rasterize_batch_bits' raster bit for bit.  Subtitles need not be sorted (a
+ * track that is not sorted by start time is sorted in a staging copy); requires start_seconds <= 0 (a positive one can
+ * make start samples negative, which Python's slice semantics wrap around: use the bit rasteriser then).
+ * Replaces: subtitle_transformers.py:35-47 + speech_transformers.py:957-980 for the device-resident pipeline. */
+int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
+                             int64_t n_subs_total, const int64_t* vec_sub_first, const int64_t* vec_sub_count,
+                             const double* vec_ratio, const int64_t* vec_out_off, const int64_t* vec_cap,
+                             const int64_t* vec_len, int64_t n_vec, double sample_rate, double start_seconds,
+                             void* out_dev, int64_t out_bytes, void* hip_stream);
 
 /* Host-only helper of the drop-in classes: the float64 vectors FFTAligner.fit receives (aligners.py:51-57) are
  * two-level activity vectors in practice.  Returns 1 and writes lo = min, hi = max and the samples as bits

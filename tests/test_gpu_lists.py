@@ -1,0 +1,327 @@
+"""Boundary lists as an input format (FFS_DTYPE_RUNS, round 5): the subtitle rasteriser that writes lists instead of
+bitmaps, the bits -> list conversion, and solves fed with lists -- against the bit rasteriser (itself pinned to the
+unmodified reference by raster_golden.npz), numpy, and the bit-input solves of the same vectors ("identical records").
+Through the C ABI; need a real MI355X.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import raster_oracle as ro
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "raster_golden.npz"))
+RATIOS = [float(r) for r in GOLD["ratios"]]
+HEAD = json.load(open(os.path.join(HERE, "golden", "headline_golden.json")))["pairs"]
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch as t
+
+    assert t.cuda.is_available()
+    return t
+
+
+def _bits_of(words, n):
+    return np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")[:n]
+
+
+def _list_of(bits01):
+    """numpy model of a boundary list: positions where the value changes (a run that reaches the end closes at len) and
+    the ones in front of each."""
+    x = np.concatenate([[0], bits01.astype(np.int64), [0]])
+    pos = np.flatnonzero(np.diff(x))
+    ones_before = np.concatenate([[0], np.cumsum(bits01.astype(np.int64))])[pos]
+    return pos, ones_before, int(bits01.sum())
+
+
+def _lists_from_tracks(tracks, track_of, ratio):
+    from ffsubsync_amd import batch
+
+    ts = batch.TrackSet(tracks)
+    data, offs, lens, bounds = ts.rasterize_runs(track_of, ratio)
+    return ts, data, offs, lens, bounds
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_list_rasteriser_equals_the_reference_rasters(torch, name):
+    """raster_golden.npz = SubtitleScaler + SubtitleSpeechTransformer of the unmodified reference: the list, expanded to
+    bits, must be that raster; its ones-in-front column must be the running count."""
+    from ffsubsync_amd import _native
+
+    s, e, m = GOLD[name + "_start_us"], GOLD[name + "_end_us"], GOLD[name + "_meta"]
+    assert int(GOLD[name + "_start_seconds"]) == 0
+    ts, data, offs, lens, bounds = _lists_from_tracks([(s, e, m)], np.zeros(len(RATIOS), np.int64), np.array(RATIOS))
+    for j in range(len(RATIOS)):
+        want = (GOLD["%s_r%d" % (name, j)] != 0).astype(np.uint8)
+        assert lens[j] == want.size
+        block = data[int(offs[j]):]
+        got = _bits_of(_native.runs_to_bits(block, int(lens[j])), int(lens[j]))
+        assert np.array_equal(got, want), (name, j)
+        pos, ones_before, ones = _native.runs_list_host(block)
+        wpos, wones, wtot = _list_of(want)
+        assert np.array_equal(pos, wpos) and np.array_equal(ones_before, wones) and ones == wtot
+        assert len(pos) <= bounds[j]
+
+
+def test_list_rasteriser_overlaps_touching_unsorted_metadata_empty(torch):
+    """Overlapping and touching subtitles merge, unsorted tracks are sorted in staging, metadata lines and empty /
+    negative-duration intervals are skipped, tracks longer than one 1024-subtitle chunk carry their state across chunks;
+    the same vectors through the bit rasteriser (ffs_rasterize_batch_bits) are the yardstick, bit for bit."""
+    from ffsubsync_amd import _native, batch
+
+    rng = np.random.RandomState(5)
+    tracks = []
+    # 0: hand-made: overlap, touch, containment, duplicate, zero and negative duration, metadata
+    s = np.array([0, 1_000_000, 1_500_000, 3_000_000, 3_000_000, 5_000_000, 6_000_000, 6_000_000, 9_000_000, 9_500_000, 12_000_000])
+    e = np.array([500_000, 2_000_000, 1_800_000, 4_000_000, 3_500_000, 6_000_000, 7_000_000, 6_000_000, 8_000_000, 11_000_000, 12_010_000])
+    m = np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0], dtype=np.uint8)
+    tracks.append((s, e, m))
+    # 1: 3000 random, unsorted, heavily overlapping subtitles (three chunks)
+    s1 = rng.randint(0, 600_000_000, 3000).astype(np.int64)
+    e1 = s1 + rng.randint(-200_000, 4_000_000, 3000)
+    tracks.append((s1, e1, (rng.rand(3000) < 0.05).astype(np.uint8)))
+    # 2: sorted, touching chains (end == next start), no metadata array
+    s2 = np.arange(0, 2000, dtype=np.int64) * 1_000_000
+    e2 = s2 + np.where(np.arange(2000) % 3 == 0, 1_000_000, 700_000)
+    tracks.append((s2, e2, None))
+    # 3: a single subtitle; 4: nothing but metadata
+    tracks.append((np.array([1_230_000]), np.array([4_560_000]), None))
+    tracks.append((np.array([0, 2_000_000]), np.array([1_000_000, 3_000_000]), np.array([1, 1], dtype=np.uint8)))
+    ratios = [1.0, 1.0417, 0.96, 1.001]
+    track_of = np.repeat(np.arange(len(tracks)), len(ratios))
+    ratio = np.tile(ratios, len(tracks))
+    ts = batch.TrackSet(tracks)
+    d_bits, o_bits, l_bits = ts.rasterize(track_of, ratio)
+    d_runs, o_runs, l_runs, bounds = ts.rasterize_runs(track_of, ratio)
+    assert np.array_equal(l_bits, l_runs)
+    for v in range(track_of.size):
+        n = int(l_bits[v])
+        want = _bits_of(d_bits[int(o_bits[v]): int(o_bits[v]) + (n + 31) // 32 * 4], n)
+        block = d_runs[int(o_runs[v]):]
+        got = _bits_of(_native.runs_to_bits(block, n), n)
+        assert np.array_equal(got, want), v
+        pos, ones_before, ones = _native.runs_list_host(block)
+        wpos, wones, wtot = _list_of(want)
+        assert np.array_equal(pos, wpos) and np.array_equal(ones_before, wones) and ones == wtot, v
+        raw = block[:16].view(torch.int32).cpu().numpy()
+        assert raw[2] == n and raw[0] <= bounds[v]
+        sent = block[16 + 8 * int(raw[0]): 24 + 8 * int(raw[0])].view(torch.int32).cpu().numpy()
+        assert sent[0] == np.iinfo(np.int32).max and sent[1] == wtot
+
+
+def test_list_rasteriser_refuses_positive_start_seconds(torch):
+    from ffsubsync_amd import _native
+
+    out = torch.zeros(1024, dtype=torch.uint8, device="cuda")
+    with pytest.raises(_native.NativeError):
+        _native.rasterize_batch_runs(np.array([0]), np.array([10 ** 6]), None, [0], [1], [1.0], [0], [3], [102], out, 100.0, 5.0)
+
+
+@pytest.mark.parametrize("n,density,run", [(720_000, 0.35, 300), (70_001, 0.5, 3), (33, 0.5, 1), (4096, 0.0, 1), (4097, 1.0, 1)])
+def test_runs_from_bits_round_trip(torch, n, density, run):
+    from ffsubsync_amd import _native
+
+    rng = np.random.RandomState(n)
+    if density in (0.0, 1.0):
+        x = np.full(n, int(density), dtype=np.uint8)
+    else:
+        x = np.repeat((rng.rand(n // run + 1) < density).astype(np.uint8), run)[:n]
+    words = torch.from_numpy(np.packbits(np.concatenate([x, np.zeros(-n % 32, np.uint8)]), bitorder="little").view(np.int32).copy()).cuda()
+    wpos, wones, wtot = _list_of(x)
+    cap = max(len(wpos) + 1, 4)
+    block = _native.runs_from_bits(words, n, cap)
+    pos, ones_before, ones = _native.runs_list_host(block)
+    assert np.array_equal(pos, wpos) and np.array_equal(ones_before, wones) and ones == wtot
+    assert np.array_equal(_bits_of(_native.runs_to_bits(block, n), n), x)
+    if len(wpos) > 8:  # too small a block: the header says so (n >= cap), nothing is written beyond the block
+        small = torch.full((4 + 2 * 8 + 16,), -7, dtype=torch.int32, device="cuda")
+        _native.runs_from_bits(words, n, 8, out=small)
+        raw = small.cpu().numpy()
+        assert raw[0] >= 8 and (raw[4 + 16:] == -7).all()
+
+
+def _same_records(a, b):
+    ca, pa = a
+    cb, pb = b
+    for f in ("score", "offset", "flags", "score_f32"):
+        assert np.array_equal(ca[f], cb[f]), (f, np.argwhere(ca[f] != cb[f])[:5])
+    assert np.array_equal(pa, pb)
+
+
+def _solve(db, n_fft, max_off, algorithm, n_cand=7, pairs_in_flight=64):
+    from ffsubsync_amd import batch
+
+    al = batch.BatchAligner(n_fft, n_cand, max_off, pairs_in_flight=pairs_in_flight, algorithm=algorithm)
+    out = al.solve(db)
+    stats = al.plan.runs_stats()
+    al.close()
+    return out, stats
+
+
+@pytest.fixture(scope="module")
+def headline(torch):
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(g["seed"]) for g in HEAD[:96]]
+    db = synth.build_device_batch(specs)
+    yield specs, db, HEAD[:96]
+    del db
+    torch.cuda.empty_cache()
+
+
+def test_lists_give_the_records_of_the_bits(headline):
+    """configs[2] pairs: the vectors as bits, as lists converted from those bits, and with only the candidates as lists
+    (reference still bits) -- identical records, equal to the unmodified reference's goldens."""
+    import test_gpu_headline as th
+    from ffsubsync_amd import _native, batch
+
+    specs, db, gold = headline
+    n_fft = db.required_fft_length(6000)
+    a, st_a = _solve(db, n_fft, 6000, "auto")
+    dl = db.to_runs(cap=8192)
+    b, st_b = _solve(dl, n_fft, 6000, "auto")
+    assert st_a[2] == 0 and st_b[2] == 0
+    _same_records(a, b)
+    th._check_seven(b[1], b[0], gold)
+    # roles of different kinds: the reference's bits + the candidates' lists, in one buffer
+    base = (db.data.numel() + 63) // 64 * 64  # (_torch_cat pads the first buffer to a multiple of 64 bytes)
+    both = batch.DeviceBatch(_torch_cat(db.data, dl.data), np.concatenate([db.offs[:, :1], dl.offs[:, 1:] + base], axis=1),
+                             db.lens, db.lo, db.hi, _native.FFS_DTYPE_RUNS, _native.FFS_DTYPE_U1)
+    c, st_c = _solve(both, n_fft, 6000, "auto")
+    assert st_c[2] == 0
+    _same_records(a, c)
+    # host-known bounds: the call needs nothing back from the device
+    n_b = np.zeros(dl.offs.shape, dtype=np.int32)
+    for i, o in enumerate(dl.offs.ravel()):
+        n_b.ravel()[i] = int(dl.data[int(o): int(o) + 4].view(_native.require_gpu().int32).item())
+    bounded = batch.DeviceBatch(dl.data, dl.offs, dl.lens, dl.lo, dl.hi, _native.FFS_DTYPE_RUNS, None, n_b + 2)
+    d, st_d = _solve(bounded, n_fft, 6000, "auto")
+    _same_records(a, d)
+
+
+def _torch_cat(a, b):
+    import torch
+
+    pad = (-a.numel()) % 64
+    return torch.cat([a, torch.zeros(pad, dtype=a.dtype, device=a.device), b]) if pad else torch.cat([a, b])
+
+
+@pytest.mark.parametrize("max_off", [None, 150000])
+def test_lists_in_wide_and_absent_windows(headline, max_off):
+    """Windows of many tiles (k_runs_pick) and the edge masks taken from the lists (no bitmap to fetch them from):
+    single-ratio solves, lists against bits."""
+    specs, db, gold = headline
+    from workloads import synth
+
+    db16 = synth.build_device_batch(specs[:16])
+    one = db16.select_candidates([sp.true_ratio_index for sp in specs[:16]])
+    n_fft = one.required_fft_length(max_off)
+    a, _ = _solve(one, n_fft, max_off, "runs", n_cand=1, pairs_in_flight=16)
+    b, st = _solve(one.to_runs(cap=8192), n_fft, max_off, "runs", n_cand=1, pairs_in_flight=16)
+    assert st[2] == 0
+    _same_records(a, b)
+
+
+def test_short_vectors_and_edge_masks_from_lists(torch):
+    """Short, dense-ish vectors of unequal lengths with runs touching both ends: every lag's one-sided counts come from
+    list-derived edge masks; bits against lists, and both against the CPU oracle."""
+    from ffsubsync_amd import _native, batch
+    from oracle import aligners_oracle as orc
+
+    rng = np.random.RandomState(77)
+    n_pairs, n_cand = 24, 3
+    vecs, lens = [], np.zeros((n_pairs, 1 + n_cand), dtype=np.int64)
+    for p in range(n_pairs):
+        for j in range(1 + n_cand):
+            n = int(rng.randint(5000, 9000))
+            x = np.repeat((rng.rand(n // 40 + 2) < 0.5).astype(np.uint8), 40)[:n]
+            if p % 3 == 0:
+                x[:50] = 1
+            if p % 4 == 1:
+                x[-70:] = 1
+            vecs.append(x)
+            lens[p, j] = n
+    nbytes = (lens + 31) // 32 * 4
+    offs, total = batch._layout(lens, nbytes)
+    host = np.zeros(total, dtype=np.uint8)
+    for x, o in zip(vecs, offs.ravel()):
+        pk = np.packbits(np.concatenate([x, np.zeros(-x.size % 32, np.uint8)]), bitorder="little")
+        host[int(o): int(o) + pk.size] = pk
+    db = batch.DeviceBatch(torch.from_numpy(host).cuda(), offs, lens, np.zeros(lens.shape), np.ones(lens.shape), _native.FFS_DTYPE_U1)
+    for max_off in (None, 700):
+        n_fft = max(db.required_fft_length(max_off), 16384)
+        a, _ = _solve(db, n_fft, max_off, "runs", n_cand=n_cand, pairs_in_flight=8)
+        b, st = _solve(db.to_runs(cap=1024), n_fft, max_off, "runs", n_cand=n_cand, pairs_in_flight=8)
+        assert st[2] == 0
+        _same_records(a, b)
+        for p in range(0, n_pairs, 5):
+            for j in range(n_cand):
+                conv, n_sub = orc.convolve_full(vecs[p * (1 + n_cand)].astype(float), vecs[p * (1 + n_cand) + 1 + j].astype(float))
+                masked = orc.mask_extreme_offsets(conv, n_sub, max_off)
+                k = len(masked) - 1 - int(b[0][p, j]["offset"]) - n_sub  # the device's lag in the reference's array
+                assert abs(masked[k] - masked.max()) < 1e-6 and float(b[0][p, j]["score"]) == pytest.approx(masked.max(), abs=1e-6)
+                assert k == int(np.flatnonzero(masked >= masked.max() - 1e-6)[0])  # first maximum = largest lag among ties
+
+
+def test_dense_lists_fall_back_to_the_transforms(torch):
+    """Lists over the coincidence budget: the sub-batch is expanded to bits and solved by the transforms; FFS_ALGO_FFT on
+    list inputs does the same for everything.  Records as from the bits."""
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(7000 + i, run_scale=0.0625) for i in range(8)]
+    db = synth.build_device_batch(specs)
+    n_fft = db.required_fft_length(6000)
+    a, _ = _solve(db, n_fft, 6000, "fft", pairs_in_flight=8)
+    dl = db.to_runs()
+    b, st = _solve(dl, n_fft, 6000, "auto", pairs_in_flight=8)
+    assert st[:3] == (1, 1, 1)
+    _same_records_but_f32(a, b)
+    c, st_c = _solve(dl, n_fft, 6000, "fft", pairs_in_flight=8)
+    assert st_c == (0, 0, 0)
+    _same_records_but_f32(a, c)
+
+
+def _same_records_but_f32(a, b):
+    for f in ("score", "offset", "flags"):
+        assert np.array_equal(a[0][f], b[0][f]), f
+    assert np.array_equal(a[1], b[1])
+
+
+def test_truncated_list_is_an_error(torch):
+    from ffsubsync_amd import _native
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(3)]
+    db = synth.build_device_batch(specs)
+    dl = db.to_runs(cap=64)  # far too small: every list is truncated
+    with pytest.raises(_native.NativeError) as err:
+        _solve(dl, db.required_fft_length(6000), 6000, "auto", pairs_in_flight=1)
+    assert "truncated" in str(err.value)
+
+
+def test_interval_lists_to_records_without_a_bitmap(torch):
+    """The device-resident pipeline of round 5: interval lists -> ffs_rasterize_batch_runs -> ffs_align_batch_runs with
+    host-known bounds; same records as interval lists -> bit rasters -> extraction -> solve."""
+    from ffsubsync_amd import batch
+    from ffsubsync_amd.constants import candidate_ratios
+    from workloads import synth
+
+    ratios = candidate_ratios()
+    recs = []
+    for i in range(12):
+        ref = synth.make_subtitle_records(100 + i, duration_s=1800.0)
+        s, e, m = synth.make_subtitle_records(200 + i, duration_s=1800.0)
+        recs.append((ref, (s + 1_370_000, e + 1_370_000, m)))
+    d_bits = batch.pairs_from_intervals(recs, ratios)
+    d_runs = batch.pairs_from_intervals(recs, ratios, lists=True)
+    assert np.array_equal(d_bits.lens, d_runs.lens) and d_runs.bounds is not None
+    n_fft = d_bits.required_fft_length(6000)
+    a, _ = _solve(d_bits, n_fft, 6000, "auto", pairs_in_flight=12)
+    b, st = _solve(d_runs, n_fft, 6000, "auto", pairs_in_flight=12)
+    assert st[2] == 0
+    _same_records(a, b)
