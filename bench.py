@@ -94,9 +94,12 @@ def compact_record(result, detail_path=None):
     if "error" in result:
         out["error"] = str(result["error"])[:300]
     out["config"] = {k: cfg.get(k) for k in ("workload", "algorithm", "path", "pairs_per_gpu", "pairs_in_flight", "n_fft_reference",
-                                             "n_fft_device", "input_format", "parallelism", "gather_fallback", "devices_used")
+                                             "n_fft_device", "input_format", "parallelism", "gather_impl", "gather_fallback",
+                                             "devices_used", "ranks_seen")
                      if k in cfg}
-    for k in ("workload", "input_format", "parallelism", "path"):
+    if isinstance(out["config"].get("ranks_seen"), list) and len(out["config"]["ranks_seen"]) > 16:
+        out["config"]["ranks_seen"] = out["config"]["ranks_seen"][:16]
+    for k in ("workload", "input_format", "parallelism", "path", "gather_impl"):
         if isinstance(out["config"].get(k), str):
             out["config"][k] = out["config"][k][:200]
     om = result.get("offset_match", {})
@@ -110,6 +113,9 @@ def compact_record(result, detail_path=None):
                 "share_of_kernel_time", "per_launch", "peak_source", "lds_conflict_frac")
         return {k: _num(r[k]) for k in keep if k in r}
 
+    for k in ("gathered_records", "gathered_best_cand_valid"):  # N > 1: every rank's records arrived
+        if k in result:
+            out[k] = result[k]
     out["roofline"] = slim_roofline(result.get("roofline"))
     if result.get("roofline_hbm") is not None:
         out["roofline_hbm"] = slim_roofline(result.get("roofline_hbm"))
@@ -140,6 +146,9 @@ def compact_record(result, detail_path=None):
         "ingest_cold_pairs_per_s": _pick(result, "ingest_inclusive", "solves_per_s"),
         "ingest_warm_plan_stream_pairs_per_s": _pick(result, "ingest_inclusive", "warm_plan_stream", "solves_per_s"),
         "ingest_lists_warm_pairs_per_s": _pick(result, "ingest_inclusive", "boundary_lists", "solves_per_s"),
+        "ingest_lists_resident_tracks_pairs_per_s": _pick(result, "ingest_inclusive", "boundary_lists", "resident_tracks", "solves_per_s"),
+        "ingest_lists_trackset_per_batch_pairs_per_s": _pick(result, "ingest_inclusive", "boundary_lists", "trackset_built_per_batch", "solves_per_s"),
+        "resident_lists_value": _pick(result, "resident_lists", "value"),
         "drop_in_ms_device_rasters": _pick(result, "drop_in", "device_rasters", "ms_per_solve_median"),
         "drop_in_ms_host_arrays": _pick(result, "drop_in", "host_float64_arrays", "ms_per_solve_median"),
         "vad_GBps": _pick(result, "vad", "roofline", "achieved"),
@@ -457,7 +466,7 @@ def gss_figures(torch, _native, specs, n_files=256):
     refs = [DeviceRaster(data[int(o): int(o) + (int(l) + 31) // 32 * 4].view(torch.int32), 0.0, 1.0, int(l)) for o, l in zip(offs, lens)]
     i1 = [i for i, r in enumerate(specs[0].ratios) if r == 1.0][0]
     recs = [(sp.cand_starts[i1] * 10000, sp.cand_ends[i1] * 10000, None) for sp in specs]
-    fit_gss_batch(refs[:8], recs[:8], max_offset_samples=6000)  # warm-up: plan, staging buffers
+    fit_gss_batch(refs, recs, max_offset_samples=6000)  # warm-up at the timed size: plan, staging buffers, allocator pools
     torch.cuda.synchronize()
     stats = {}
     t0 = time.perf_counter()
@@ -479,8 +488,21 @@ def gss_figures(torch, _native, specs, n_files=256):
     msa = MaxScoreAligner(FFTAligner(max_offset_samples=6000))
     msa.fit(refs[0], [lambda r: Pipe(r)])
     (s1, o1), pipe = msa.transform()
+    # every file against the per-file search (one rasterisation and one solve per file and step through the drop-in's
+    # solve_pairs: the path fit_gss_batch falls back to): same recorded (score, offset, ratio) -- VERDICT r4 item 9
+    from ffsubsync_amd.batch_gss import _fit_gss_batch_per_file
+
+    n_chk = min(n, int(os.environ.get("FFS_BENCH_GSS_CHECK", "256")))
+    per_file = _fit_gss_batch_per_file(refs[:n_chk], recs[:n_chk], max_offset_samples=6000)
+    same = sum(int(repr(a[1]) == repr(b[1]) and int(a[0][1]) == int(b[0][1]) and float(a[0][0]) == float(b[0][0]))
+               for a, b in zip(got[:n_chk], per_file))
     return {
-        "what": "%d files x 2 h: fit_gss_batch(max_offset_samples=6000), golden-section search on [0.9, 1.1] to 1e-4" % n,
+        "all_files_equal_per_file_search": "%d/%d" % (same, n_chk),
+        "lists": bool(stats.get("lists")),
+        "what": "%d files x 2 h: fit_gss_batch(max_offset_samples=6000), golden-section search on [0.9, 1.1] to 1e-4; a warm "
+                "service (the same search has run once before at this size: plan, staging buffers and allocator pools exist); "
+                "per step one ffs_rasterize_batch_runs (device-resident subtitle tables) + one ffs_align_batch_runs on boundary "
+                "lists + the read-back of the scores" % n,
         "files_per_s": n / el, "ms_per_file": 1e3 * el / n, "steps": stats.get("steps"), "ms_per_step": 1e3 * el / max(1, stats.get("steps", 1)),
         "evaluations_per_s": n * stats.get("steps", 0) / el,
         "files_ending_within_1e-3_of_the_true_ratio": "%d/%d" % (near, n),
@@ -572,6 +594,65 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
         return pres, n_batches * n_pairs / dt
 
     pres_w, rate_w = warm_stream()
+
+    # Round 5: the same stream without any bitmap -- interval lists -> BOUNDARY lists (ffs_rasterize_batch_runs) -> solve
+    # (ffs_align_batch_runs with the lists' host-known bounds: no pass over a vector, nothing read back per batch).
+    def lists_stream(n_batches=16, tables="per_batch"):
+        al = batch.BatchAligner(batch.pairs_from_intervals(recs, ratios).required_fft_length(6000), 7, 6000,
+                                pairs_in_flight=min(256, n_pairs))
+        outs = [(torch.empty(n_pairs * 7 * 24, dtype=torch.uint8, device="cuda"),
+                 torch.empty(n_pairs * 24, dtype=torch.uint8, device="cuda")) for _ in range(2)]
+        keep = []
+        tracks = [t for rec in recs for t in rec]
+        track_of = (np.tile(np.array([0] + [1] * len(ratios)), (n_pairs, 1)) + 2 * np.arange(n_pairs)[:, None]).ravel()
+        ratio = np.tile(np.array([1.0] + list(ratios)), (n_pairs, 1)).ravel()
+        hi = np.minimum(1.0 / ratio, 1.0).reshape(n_pairs, 8)
+        held = None if tables == "per_batch" else batch.TrackSet(tracks)
+        if tables == "device":
+            held.to_device()
+
+        def run(k):
+            ts = held if held is not None else batch.TrackSet(tracks)
+            data, offs, lens, bounds = ts.rasterize_runs(track_of, ratio)
+            db = batch.DeviceBatch(data, offs.reshape(n_pairs, 8), lens.reshape(n_pairs, 8), np.zeros_like(hi), hi,
+                                   _native.FFS_DTYPE_RUNS, None, bounds.reshape(n_pairs, 8))
+            keep.append(db)
+            al.solve_async(db, 0, n_pairs, outs[k % 2][0], outs[k % 2][1])
+            if len(keep) > 2:
+                keep.pop(0)
+
+        for k in range(8):  # warm: staging buffers, descriptor storage and the allocator's pools reach their final size
+            run(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_batches):
+            run(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pres = outs[(n_batches - 1) % 2][1].cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:n_pairs].copy()
+        al.close()
+        return pres, n_batches * n_pairs / dt
+
+    try:
+        pres_l, rate_l = lists_stream(tables="per_batch")
+        pres_h, rate_h = lists_stream(tables="host")
+        pres_r, rate_r = lists_stream(tables="device")
+        lists_fig = {
+            "what": "the warm stream with boundary lists instead of bitmaps: batches of %d pairs back to back (16 timed after 8 "
+                    "warm ones), per batch ffs_rasterize_batch_runs -> ffs_align_batch_runs with host-known list bounds (no "
+                    "extraction pass, nothing read back).  solves_per_s: the subtitle tables held in one host TrackSet and "
+                    "uploaded with every batch" % n_pairs,
+            "solves_per_s": rate_h, "same_results": bool(np.array_equal(pres_h, pres_b)),
+            "trackset_built_per_batch": {
+                "what": "the TrackSet itself (numpy concatenation of the 2 x %d per-track arrays) built inside the timed region, "
+                        "as warm_plan_stream does" % n_pairs,
+                "solves_per_s": rate_l, "same_results": bool(np.array_equal(pres_l, pres_b))},
+            "resident_tracks": {
+                "what": "the subtitle tables uploaded once (TrackSet.to_device: the same files against many references, the "
+                        "steps of a search): per batch only the 32-byte-per-vector table travels",
+                "solves_per_s": rate_r, "same_results": bool(np.array_equal(pres_r, pres_b))}}
+    except Exception as exc:
+        lists_fig = {"error": repr(exc)[:300]}
     out = {"what": "%d pairs from interval lists -> rasters of the reference track and of the subtitle track at the seven "
                    "ratios -> one batch buffer -> one batched solve; includes plan creation.  One ffs_rasterize_batch_bits "
                    "call for the whole batch (interval arithmetic on the device, written straight into the batch buffer)"
@@ -582,6 +663,7 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
         "what": "8 batches of %d pairs back to back on one aligner created beforehand (plan, staging buffers and boundary-list "
                 "workspace warm): interval lists -> rasters -> solve, results of the last batch checked" % n_pairs,
         "solves_per_s": rate_w, "same_results": bool(np.array_equal(pres_w, pres_b))}
+    out["boundary_lists"] = lists_fig
     out["per_vector_calls"] = dict(fig_a, what="8 ffs_rasterize_subtitles_bits calls per pair from a Python loop (host interval "
                                                 "arithmetic) + pack_pairs: the round-3 figure before the batched entry point")
     return out
@@ -1023,10 +1105,66 @@ def main():
                            "wasted = traffic / must-move")
         return out
 
+    def coincidences_per_pair(sample=256):
+        """Boundary coincidences inside the lag window per seven-ratio pair = the scatter-adds k_runs_corr HAS to make
+        (one +-1 per pair of boundaries (p, q) with q - p among the window's lags but the last), counted exactly on the
+        host for the first `sample` pairs of the batch (numpy searchsorted over the generator's run lists)."""
+        tot, n_s = 0, min(sample, P)
+        for sp in specs[:n_s]:
+            ref, cands = synth.pair_arrays(sp)
+            q = np.flatnonzero(np.diff(np.concatenate([[0], ref, [0]]).astype(np.int8)))
+            R = ref.size
+            for c in cands:
+                p_ = np.flatnonzero(np.diff(np.concatenate([[0], c, [0]]).astype(np.int8)))
+                S = c.size
+                d_lo, d_hi = max(-5999, -S + 1), min(6000, R - 1)  # FFTAligner(6000): lags [-max+1, +max] (SURVEY 8a A3)
+                tot += int((np.searchsorted(q, p_ + d_hi - 1, "right") - np.searchsorted(q, p_ + d_lo, "left")).sum())
+        return tot / max(1, n_s), n_s
+
+    def lds_roofline(per_kernel, pairs, steps):
+        """`roofline` of k_runs_corr: bound by the LDS scatter-add rate (profiles/lds_atomic_ceiling.hip measures what the
+        chip sustains for uniformly random words: whatever the bank pattern or the active lanes, a ds_add_u32
+        wave-instruction costs ~7.5 LDS cycles, so the ceiling is reached only with all 64 lanes adding)."""
+        k = per_kernel["runs_corr"]
+        per_pair, n_s = coincidences_per_pair()
+        pairs_per_launch = pairs * steps / k["launches"]
+        peak, src = None, os.path.join(ROOT, "profiles", "lds_atomic_ceiling.json")
+        if os.path.exists(src):
+            cj = json.load(open(src))
+            cfg_ = cj.get("ds_add_u32_4x512_per_cu") or cj.get("ds_add_u32_2x512_per_cu")
+            peak = (cfg_.get("random_words_packed16_value") or cfg_["random_words"])["lanes_64_Gps"]
+        achieved = per_pair * pairs_per_launch / (k["avg_ms"] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_per_pair.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath)).get(str(n_dev), {})
+            if "runs_corr" in tj:
+                traffic = tj["runs_corr"] * pairs_per_launch
+        out = {"kernel": "k_runs_corr", "bound": "lds", "achieved": achieved, "peak": peak, "unit": "G lane-adds/s",
+               "frac": (achieved / peak) if peak else None, "traffic": traffic,
+               "per_launch": per_pair * pairs_per_launch, "avg_launch_ms": k["avg_ms"],
+               "share_of_kernel_time": k["total_ms"] / sum(v["total_ms"] for v in per_kernel.values()),
+               "peak_source": "profiles/lds_atomic_ceiling.json: ds_add_u32, uniformly random words, 64 active lanes, whole chip",
+               "note": "achieved = boundary coincidences inside the lag window per launch (exact count on the host for the first "
+                       "%d pairs x pairs per launch) / average launch duration (HIP events); traffic = PMC-measured HBM bytes "
+                       "per launch (the kernel reads the boundary lists: not what bounds it)" % n_s}
+        lj = json.load(open(tpath)).get("%d_work" % n_dev, {}).get("runs_corr", {}) if os.path.exists(tpath) else {}
+        if lj.get("lds_idx_active_per_pair"):
+            out["lds_conflict_frac"] = lj.get("lds_bank_conflict_per_pair", 0.0) / lj["lds_idx_active_per_pair"]
+        return out
+
     if profile and rank == 0:
         per_kernel = kernel_table(ktimes, args.steps, n_dev, seg_mode)
         result["kernels"] = per_kernel
-        result["roofline"] = roofline_of(per_kernel, P, args.steps, n_dev, seg_mode)
+        hbm_roof = roofline_of(per_kernel, P, args.steps, n_dev, seg_mode)
+        dom_all = max(per_kernel, key=lambda k: per_kernel[k]["total_ms"])
+        if dom_all == "runs_corr" and args.duration == 7200.0:
+            # the DOMINANT kernel of the timed path is not an HBM kernel: its roofline is the LDS scatter-add rate; the
+            # HBM record of the path's streaming kernel (k_runs_extract) stays beside it
+            result["roofline"] = lds_roofline(per_kernel, P, args.steps)
+            result["roofline_hbm"] = hbm_roof
+        else:
+            result["roofline"] = hbm_roof
 
     # BASELINE configs[3] in the same invocation: the SAME 1024 pairs split over the ranks, every step = this rank's share
     # (contiguous block, batch.shard_bounds) + the all-gather of the 24-byte records.  On one GPU it is the proxy the
@@ -1064,6 +1202,31 @@ def main():
             pk_x = kernel_table(kt_x, st_x, n_dev, seg_x)
             result["fft_path"]["kernels"] = pk_x
             result["fft_path"]["roofline"] = roofline_of(pk_x, P, st_x, n_dev, seg_x)
+    if secondary and by_runs and db.dtype == _native.FFS_DTYPE_U1:
+        # The same pairs with their BOUNDARY LISTS resident in HBM instead of their bits (FFS_DTYPE_RUNS: what the list
+        # rasteriser and ffs_runs_from_bits hand over): no extraction pass, and -- the lists' lengths are known on the
+        # host -- nothing read back per call.
+        try:
+            dl = db.to_runs(cap=8192)
+            torch.cuda.synchronize()
+            n_l = dl.data.view(torch.int32).reshape(-1, dl.offs.ravel()[1] // 4)[:, 0].cpu().numpy().reshape(dl.offs.shape)
+            dl.bounds = (n_l + 2).astype(np.int32)
+            st_l = max(2, args.steps // 2)
+            el_l, kt_l, _ = timed(n_dev, st_l, 1, the_db=dl)
+            pres_l = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
+            cres_l = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[: P * n_cand].reshape(P, n_cand)
+            result["resident_lists"] = {
+                "what": "same %d pairs, boundary lists resident in HBM (FFS_DTYPE_RUNS, %.0f entries per vector on average) with "
+                        "host-known bounds: k_runs_corr only" % (P, float(n_l.mean())),
+                "value": P * st_l / el_l, "unit": "7-ratio solves/s", "ms_per_step": 1e3 * el_l / st_l, "path": info_now["path"],
+                "identical_pair_results": bool(np.array_equal(pres_l, pres)),
+                "identical_candidate_results": bool(all(np.array_equal(cres_l[f], cres[f]) for f in ("score", "offset", "flags"))),
+            }
+            if profile:
+                result["resident_lists"]["kernels_us_per_pair"] = {k: 1e3 * v[0] / (P * st_l) for k, v in kt_l.items() if v[1]}
+            del dl
+        except Exception as exc:
+            result["resident_lists"] = {"error": repr(exc)[:300]}
     if secondary and not args.reference_length and n_dev != n_ref:
         # the same pairs with the reference's own transform length N = 2^21 (single transform), for the record
         st2 = max(2, args.steps // 4)

@@ -47,6 +47,7 @@ EXPORTED_SYMBOLS = (
     "ffs_align_batch_runs",
     "ffs_runs_list_bytes",
     "ffs_runs_from_bits",
+    "ffs_runs_from_bits_batch",
     "ffs_runs_to_bits",
     "ffs_rasterize_batch_runs",
     "ffs_correlate_full",
@@ -168,6 +169,8 @@ def load():
         lib.ffs_runs_list_bytes.argtypes = [c.c_int64]
         lib.ffs_runs_from_bits.restype = c.c_int
         lib.ffs_runs_from_bits.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_void_p]
+        lib.ffs_runs_from_bits_batch.restype = c.c_int
+        lib.ffs_runs_from_bits_batch.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p]
         lib.ffs_runs_to_bits.restype = c.c_int
         lib.ffs_runs_to_bits.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
         lib.ffs_rasterize_batch_runs.restype = c.c_int
@@ -588,10 +591,25 @@ def rasterize_batch_runs(start_us, end_us, is_metadata, vec_sub_first, vec_sub_c
                          vec_len, out, sample_rate=100.0, start_seconds=0.0) -> None:
     """``ffs_rasterize_batch_runs``: every vector of a batch as its BOUNDARY LIST (FFS_DTYPE_RUNS), no bitmap.  Vector v
     covers subtitles [vec_sub_first[v], +vec_sub_count[v]) scaled by vec_ratio[v]; its list block starts at byte
-    vec_out_off[v] of ``out`` (CUDA tensor; offsets multiples of 8) and holds up to vec_cap[v] >= 2 * count + 1 entries."""
+    vec_out_off[v] of ``out`` (CUDA tensor; offsets multiples of 8) and holds up to vec_cap[v] >= 2 * count + 1 entries.
+    ``start_us`` / ``end_us`` / ``is_metadata``: host arrays, or int64 / int64 / uint8 CUDA tensors (tracks uploaded once,
+    sorted by start time: nothing of them is copied per call)."""
     torch = require_gpu()
-    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
     i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    if hasattr(start_us, "data_ptr"):  # device-resident tables
+        first, count, off, cap, length = i64(vec_sub_first), i64(vec_sub_count), i64(vec_out_off), i64(vec_cap), i64(vec_len)
+        ratio = np.ascontiguousarray(vec_ratio, dtype=np.float64)
+        n_vec = first.size
+        if not (count.size == off.size == cap.size == length.size == ratio.size == n_vec):
+            raise ValueError("the vector tables must have the same length")
+        check(load().ffs_rasterize_batch_runs(start_us.data_ptr(), end_us.data_ptr(),
+                                              None if is_metadata is None else is_metadata.data_ptr(), start_us.numel(),
+                                              first.ctypes.data, count.ctypes.data, ratio.ctypes.data, off.ctypes.data,
+                                              cap.ctypes.data, length.ctypes.data, n_vec, float(sample_rate),
+                                              float(start_seconds), out.data_ptr(), out.numel() * out.element_size(),
+                                              current_stream_ptr(torch)))
+        return
+    start_us, end_us, meta = _us_arrays(start_us, end_us, is_metadata)
     first, count, off, cap, length = i64(vec_sub_first), i64(vec_sub_count), i64(vec_out_off), i64(vec_cap), i64(vec_len)
     ratio = np.ascontiguousarray(vec_ratio, dtype=np.float64)
     n_vec = first.size
@@ -615,6 +633,20 @@ def runs_from_bits(words, n: int, cap: Optional[int] = None, out=None):
         raise ValueError("list block too small")
     check(load().ffs_runs_from_bits(words.data_ptr(), int(n), out.data_ptr(), cap, current_stream_ptr(torch)))
     return out
+
+
+def runs_from_bits_batch(bits_ptr, lens, list_ptr, caps) -> None:
+    """``ffs_runs_from_bits_batch``: n vectors (device pointers to FFS_DTYPE_U1 words, lengths in samples) into n list
+    blocks (device pointers, capacities in entries) with one launch."""
+    torch = require_gpu()
+    bits_ptr = np.ascontiguousarray(bits_ptr, dtype=np.uint64)
+    list_ptr = np.ascontiguousarray(list_ptr, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    caps = np.ascontiguousarray(caps, dtype=np.int64)
+    if not (bits_ptr.size == list_ptr.size == lens.size == caps.size):
+        raise ValueError("the vector tables must have the same length")
+    check(load().ffs_runs_from_bits_batch(bits_ptr.ctypes.data, lens.ctypes.data, list_ptr.ctypes.data, caps.ctypes.data,
+                                          bits_ptr.size, current_stream_ptr(torch)))
 
 
 def runs_to_bits(block, n: int):

@@ -87,8 +87,8 @@ class DeviceBatch:
         n = self.offs.size
         data = torch.empty(n * block, dtype=torch.uint8, device=self.data.device)
         offs = (np.arange(n, dtype=np.int64) * block).reshape(self.offs.shape)
-        for o_src, o_dst, ln in zip(self.offs.ravel(), offs.ravel(), self.lens.ravel()):
-            _native.runs_from_bits(self.data[int(o_src):], int(ln), cap, out=data[int(o_dst): int(o_dst) + block])
+        _native.runs_from_bits_batch(self.data.data_ptr() + self.offs.ravel().astype(np.uint64), self.lens.ravel(),
+                                     data.data_ptr() + offs.ravel().astype(np.uint64), np.full(n, cap, dtype=np.int64))
         return DeviceBatch(data, offs, self.lens, self.lo, self.hi, _native.FFS_DTYPE_RUNS)
 
 
@@ -140,6 +140,22 @@ class TrackSet:
             self.meta = np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else np.asarray(t[2], dtype=np.uint8)
                                         for t in tracks])
         self.end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64)
+        self._dev = None  # (start_us, end_us, is_metadata) CUDA tensors once to_device() has uploaded them
+
+    def to_device(self) -> "TrackSet":
+        """Upload the interval tables once (sorted by start time inside every track): ``rasterize_runs`` then copies
+        nothing but its 32-byte-per-vector table -- for tracks that are rasterised again and again (the steps of a
+        golden-section search, one subtitle file against many references)."""
+        torch = _native.require_gpu()
+        if self._dev is None:
+            order = np.arange(self.start_us.size)
+            for f, c in zip(self.firsts, self.counts):
+                seg = self.start_us[f:f + c]
+                if c > 1 and (seg[1:] < seg[:-1]).any():
+                    order[f:f + c] = f + np.argsort(seg, kind="stable")
+            up = lambda a: torch.from_numpy(np.ascontiguousarray(a[order])).cuda()
+            self._dev = (up(self.start_us), up(self.end_us), None if self.meta is None else up(self.meta))
+        return self
 
     def rasterize(self, track_of, ratio, sample_rate: int = 100, start_seconds: float = 0):
         """Vector v = track ``track_of[v]`` with its times scaled by ``ratio[v]`` (``SubtitleScaler`` +
@@ -167,8 +183,8 @@ class TrackSet:
         caps = 2 * counts + 2
         offs, total = _layout(lens, 16 + 8 * caps)
         data = torch.empty(max(total, 64), dtype=torch.uint8, device="cuda")
-        _native.rasterize_batch_runs(self.start_us, self.end_us, self.meta, self.firsts[track_of], counts, ratio, offs, caps,
-                                     lens, data, sample_rate, 0.0)
+        s_us, e_us, meta = self._dev if self._dev is not None else (self.start_us, self.end_us, self.meta)
+        _native.rasterize_batch_runs(s_us, e_us, meta, self.firsts[track_of], counts, ratio, offs, caps, lens, data, sample_rate, 0.0)
         return data, offs, lens, np.maximum(2 * counts, 2).astype(np.int32)
 
 

@@ -70,10 +70,14 @@ def fit_gss_batch(refs: Sequence, subtitle_records: Sequence[Tuple[np.ndarray, n
     (start_us, end_us, is_metadata) of its subtitles.  Returns a list of ((score, offset), ratio) -- the evaluation each
     file's search flagged as last, which is what the reference records in ``_scores`` (aligners.py:124-125).
 
-    Every search step is ONE ``ffs_rasterize_batch_bits`` call (every file's track at that file's current ratio, interval
-    arithmetic on the device) and ONE ``ffs_align_batch`` call over all files, on one plan held across the ~17 steps;
-    the reference vectors are uploaded once and stay bit-packed in HBM.  Multi-level (float) references take the
-    per-file path (``_fit_gss_batch_per_file``).  ``stats``, if given, receives {"steps", "files", "plan_length"}."""
+    Every search step is ONE rasteriser call (every file's track at that file's current ratio, interval arithmetic on the
+    device) and ONE solve over all files, on one plan held across the ~17 steps.  With ``start_seconds <= 0`` nothing is
+    ever a bitmap (round 5): the subtitle tables are uploaded once (``TrackSet.to_device``), every step writes the tracks'
+    BOUNDARY LISTS (``ffs_rasterize_batch_runs``), the references are converted to lists once (``ffs_runs_from_bits_batch``)
+    and the solves take lists on both sides with host-known bounds -- no pass over any vector, no wait for the device
+    besides the step's own scores.  Otherwise (or when a reference is too dense for a list) the step rasterises bits
+    (``ffs_rasterize_batch_bits``) against the bit-packed references.  Multi-level (float) references take the per-file
+    path (``_fit_gss_batch_per_file``).  ``stats``, if given, receives {"steps", "files", "plan_length", "lists"}."""
     from . import _native
     from .aligners import _Vec
     from .batch import TrackSet
@@ -119,14 +123,48 @@ def fit_gss_batch(refs: Sequence, subtitle_records: Sequence[Tuple[np.ndarray, n
     recorded = [None] * n
     which = np.arange(n)
     steps = [0]
+    # boundary lists on both sides when the rasteriser may write them (start_seconds <= 0) and every reference fits one
+    use_lists = start_seconds <= 0
+    ref_lists = None
+    bounds = np.zeros(2 * n, dtype=np.int32)
+    if use_lists:
+        cap = 32768
+        block = (_native.runs_list_bytes(cap) + 63) // 64 * 64
+        ref_lists = torch.empty(n * block, dtype=torch.uint8, device="cuda")
+        list_ptr = ref_lists.data_ptr() + (np.arange(n, dtype=np.uint64) * np.uint64(block))
+        _native.runs_from_bits_batch(ref_ptr, ref_len, list_ptr, np.full(n, cap, dtype=np.int64))
+        n_ref = ref_lists.view(torch.int32).reshape(n, block // 4)[:, 0].cpu().numpy()  # (one small read-back per search)
+        if (n_ref >= cap).any():
+            use_lists, ref_lists = False, None
+        else:
+            tracks.to_device()
+            ptrs[0::2] = list_ptr
+            bounds[0::2] = np.maximum(n_ref, 2)
+    dtypes = (_native.FFS_DTYPE_RUNS, _native.FFS_DTYPE_RUNS) if use_lists else _native.FFS_DTYPE_U1
+
+    timers = stats.setdefault("timers_us", {"rasterize": 0.0, "solve": 0.0, "read_back": 0.0}) if stats is not None and stats.get("time_steps") else None
+    import time as _time
 
     def evaluate(ratios, is_last):
-        data, c_offs, c_lens = tracks.rasterize(which, ratios, sample_rate, start_seconds)
+        t0 = _time.perf_counter()
+        if use_lists:
+            data, c_offs, c_lens, c_bounds = tracks.rasterize_runs(which, ratios, sample_rate)
+            bounds[1::2] = c_bounds
+        else:
+            data, c_offs, c_lens = tracks.rasterize(which, ratios, sample_rate, start_seconds)
         ptrs[1::2] = data.data_ptr() + c_offs.astype(np.uint64)
         lens[1::2] = c_lens
         hi[1::2] = np.minimum(1.0 / np.asarray(ratios, dtype=np.float64), 1.0)  # speech_transformers.py:977
-        plan.align_batch(n, 1, _native.FFS_DTYPE_U1, ptrs, lens, lo, hi, max_offset_samples, None, cand_out, pair_out)
+        t1 = _time.perf_counter()
+        plan.align_batch(n, 1, dtypes, ptrs, lens, lo, hi, max_offset_samples, None, cand_out, pair_out,
+                         vec_max_boundaries=bounds if use_lists else None)
+        t2 = _time.perf_counter()
         cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[:n]
+        if timers is not None:
+            t3 = _time.perf_counter()
+            timers["rasterize"] += 1e6 * (t1 - t0)
+            timers["solve"] += 1e6 * (t2 - t1)
+            timers["read_back"] += 1e6 * (t3 - t2)
         steps[0] += 1
         if (cres["flags"] & _native.FLAG_AMBIGUOUS).any():  # degenerate input (e.g. a silent reference): the careful path
             raise _Ambiguous()
@@ -140,8 +178,8 @@ def fit_gss_batch(refs: Sequence, subtitle_records: Sequence[Tuple[np.ndarray, n
     except _Ambiguous:
         return _fit_gss_batch_per_file(refs, subtitle_records, max_offset_samples, sample_rate, start_seconds)
     if stats is not None:
-        stats.update({"steps": steps[0], "files": n, "plan_length": int(n_fft)})
-    del ref_dev, keep
+        stats.update({"steps": steps[0], "files": n, "plan_length": int(n_fft), "lists": bool(use_lists)})
+    del ref_dev, keep, ref_lists
     return recorded
 
 

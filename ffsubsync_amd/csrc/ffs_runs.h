@@ -249,6 +249,13 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restri
     runs_extract_body(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 
+// vectors into caller-owned list blocks (ffs_runs_from_bits_batch): the block header also gets (len, cap)
+__global__ __launch_bounds__(256, 8) void k_runs_extract_lists(const RunsRef* __restrict__ refs) {
+    const RunsRef r = refs[blockIdx.x];
+    if (threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
+    runs_extract_body(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+}
+
 // one vector into a caller-owned list (ffs_runs_from_bits)
 __global__ __launch_bounds__(256, 8) void k_runs_extract_one(const unsigned* __restrict__ bits, int len, int2* __restrict__ e,
                                                              int2* __restrict__ hdr, int cap) {

@@ -2090,6 +2090,23 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
         return fail(FFS_E_INVALID, "start_seconds > 0 can make start samples negative (Python slices wrap them around): "
                     "use ffs_rasterize_batch_bits");
     if (n_vec == 0) return FFS_OK;
+    // DEVICE-resident subtitle tables (the same tracks rasterised again and again: the steps of a golden-section search, a
+    // subtitle file against many references): nothing of them is copied, only the vector table travels.  They must be
+    // sorted by start time already (the host cannot look).
+    bool tables_on_device = false;
+    if (n_subs_total > 0) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, start_us) == hipSuccess && attr.type == hipMemoryTypeDevice) {
+            tables_on_device = true;
+            hipPointerAttribute_t a2;
+            if (hipPointerGetAttributes(&a2, end_us) != hipSuccess || a2.type != hipMemoryTypeDevice)
+                return fail(FFS_E_INVALID, "start_us is device memory, end_us is not: the subtitle tables must live on one side");
+            if (is_metadata && (hipPointerGetAttributes(&a2, is_metadata) != hipSuccess || a2.type != hipMemoryTypeDevice))
+                return fail(FFS_E_INVALID, "start_us is device memory, is_metadata is not: the subtitle tables must live on one side");
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     // Tracks must reach the kernel sorted by start time.  Unsorted ones (rare) are sorted into extra rows behind the
     // caller's; vectors naming the same unsorted range share one copy.
     std::vector<int64_t> xs, xe;
@@ -2106,7 +2123,9 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
         if (vec_out_off[v] < 0 || (vec_out_off[v] & 7) || vec_out_off[v] + ffs_runs_list_bytes(vec_cap[v]) > out_bytes)
             return fail(FFS_E_INVALID, "vector %lld: list block outside the buffer or misaligned", (long long)v);
         int64_t first = f;
-        if (f == last_first && c == last_count) {
+        if (tables_on_device) {
+            // sorted by contract
+        } else if (f == last_first && c == last_count) {
             first = last_new_first;
         } else {
             bool sorted = true;
@@ -2131,15 +2150,16 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
     DeviceGuard guard;
     int rc_dev;
     if ((rc_dev = guard.enter(out_dev))) return rc_dev;
-    // one staging allocation: start | end | vector table | metadata flags (see ffs_rasterize_batch_bits)
-    const size_t nsub = (size_t)n_subs_total + xs.size(), off_end = nsub * 8, off_vec = 2 * nsub * 8;
+    // one staging allocation: start | end | vector table | metadata flags (see ffs_rasterize_batch_bits); with
+    // device-resident tables only the vector table
+    const size_t nsub = tables_on_device ? 0 : (size_t)n_subs_total + xs.size(), off_end = nsub * 8, off_vec = 2 * nsub * 8;
     const bool with_meta = is_metadata != nullptr;
-    const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterRunsVec), total = off_meta + (with_meta ? nsub : 0);
+    const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterRunsVec), total = off_meta + (with_meta && !tables_on_device ? nsub : 0);
     PinnedStage* stage = nullptr;
     int rc = stage_acquire(total, &stage);
     if (rc) return rc;
     char* hs = (char*)stage->host;
-    const size_t n0 = (size_t)n_subs_total;
+    const size_t n0 = tables_on_device ? 0 : (size_t)n_subs_total;
     if (n0) {
         memcpy(hs, start_us, n0 * 8);
         memcpy(hs + off_end, end_us, n0 * 8);
@@ -2149,7 +2169,7 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
         memcpy(hs + off_end + n0 * 8, xe.data(), xe.size() * 8);
     }
     memcpy(hs + off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterRunsVec));
-    if (with_meta) {
+    if (with_meta && !tables_on_device) {
         if (n0) memcpy(hs + off_meta, is_metadata, n0);
         if (!xm.empty()) memcpy(hs + off_meta + n0, xm.data(), xm.size());
     }
@@ -2158,10 +2178,47 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
     if (hipMemcpyAsync(d, hs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
     if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
     if (rc == FFS_OK) {
-        hipLaunchKernelGGL(k_rasterize_runs, dim3((unsigned)n_vec), dim3(256), 0, st, (const long long*)d, (const long long*)(d + off_end),
-                           with_meta ? (const unsigned char*)(d + off_meta) : nullptr, (const RasterRunsVec*)(d + off_vec), sample_rate,
-                           start_seconds, (char*)out_dev);
+        const long long* d_start = tables_on_device ? (const long long*)start_us : (const long long*)d;
+        const long long* d_end = tables_on_device ? (const long long*)end_us : (const long long*)(d + off_end);
+        const unsigned char* d_meta = !with_meta ? nullptr : tables_on_device ? (const unsigned char*)is_metadata : (const unsigned char*)(d + off_meta);
+        hipLaunchKernelGGL(k_rasterize_runs, dim3((unsigned)n_vec), dim3(256), 0, st, d_start, d_end, d_meta,
+                           (const RasterRunsVec*)(d + off_vec), sample_rate, start_seconds, (char*)out_dev);
         if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_rasterize_runs launch failed");
+    }
+    (void)hipFreeAsync(d, st);
+    return rc;
+}
+
+int ffs_runs_from_bits_batch(const uint32_t* const* bits_dev, const int64_t* len, void* const* list_dev, const int64_t* cap,
+                             int64_t n_vec, void* hip_stream) {
+    if (n_vec < 0 || (n_vec > 0 && (!bits_dev || !len || !list_dev || !cap))) return fail(FFS_E_INVALID, "bad argument");
+    if (n_vec == 0) return FFS_OK;
+    if (n_vec >= (int64_t(1) << 31)) return fail(FFS_E_INVALID, "too many vectors");
+    for (int64_t v = 0; v < n_vec; ++v) {
+        if (!bits_dev[v] || !list_dev[v]) return fail(FFS_E_INVALID, "vector %lld: null pointer", (long long)v);
+        if (len[v] <= 0 || len[v] >= (int64_t(1) << 30))
+            return fail(len[v] <= 0 ? FFS_E_EMPTY : FFS_E_TOO_LONG, "vector %lld of %lld samples", (long long)v, (long long)len[v]);
+        if (cap[v] < 1 || cap[v] >= (int64_t(1) << 28)) return fail(FFS_E_INVALID, "vector %lld: list capacity %lld outside [1, 2^28)", (long long)v, (long long)cap[v]);
+        if (((uintptr_t)bits_dev[v] & 3) || ((uintptr_t)list_dev[v] & 7)) return fail(FFS_E_INVALID, "vector %lld: misaligned pointer", (long long)v);
+    }
+    hipStream_t st = (hipStream_t)hip_stream;
+    DeviceGuard guard;
+    int rc_dev;
+    if ((rc_dev = guard.enter(list_dev[0]))) return rc_dev;
+    PinnedStage* stage = nullptr;
+    int rc = stage_acquire((size_t)n_vec * sizeof(RunsRef), &stage);
+    if (rc) return rc;
+    RunsRef* hr = (RunsRef*)stage->host;
+    for (int64_t v = 0; v < n_vec; ++v)
+        hr[v] = RunsRef{(const int2*)((const char*)list_dev[v] + 16), (const int2*)list_dev[v], (const unsigned*)bits_dev[v], (int32_t)len[v],
+                        (int32_t)cap[v]};
+    RunsRef* d = nullptr;
+    HIP_TRY(hipMallocAsync((void**)&d, (size_t)n_vec * sizeof(RunsRef), st));
+    if (hipMemcpyAsync(d, hr, (size_t)n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the vector table failed");
+    if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
+    if (rc == FFS_OK) {
+        hipLaunchKernelGGL(k_runs_extract_lists, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)d);
+        if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_runs_extract_lists launch failed");
     }
     (void)hipFreeAsync(d, st);
     return rc;

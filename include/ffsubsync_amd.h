@@ -172,6 +172,9 @@ int64_t ffs_runs_list_bytes(int64_t cap);
  * boundaries or more leaves n >= cap in the header (truncated).  Convert once -- VAD labels, a deserialised reference
  * (speech_transformers.py:993-1005) -- and every later solve skips the pass over the bits. */
 int ffs_runs_from_bits(const uint32_t* bits_dev, int64_t len, void* list_dev, int64_t cap, void* hip_stream);
+/* The same for n_vec vectors in one launch (host tables of device pointers / lengths / capacities). */
+int ffs_runs_from_bits_batch(const uint32_t* const* bits_dev, const int64_t* len, void* const* list_dev, const int64_t* cap,
+                             int64_t n_vec, void* hip_stream);
 /* The inverse (parity tests; the transform path uses the same kernel for list-only vectors): `len` samples of the
  * list's vector as FFS_DTYPE_U1 words at bits_out_dev (ceil(len/32) words). */
 int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, void* hip_stream);
@@ -303,6 +306,9 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
  * bits (ffs_runs_to_bits) a list equals ffs_rasterize_batch_bits' raster bit for bit.  Subtitles need not be sorted (a
  * track that is not sorted by start time is sorted in a staging copy); requires start_seconds <= 0 (a positive one can
  * make start samples negative, which Python's slice semantics wrap around: use the bit rasteriser then).
+ * start_us / end_us / is_metadata may be DEVICE pointers (all of them): tracks that are rasterised again and again -- the
+ * steps of a golden-section search, one subtitle file against many references -- are uploaded once, nothing of them is
+ * copied per call; device-resident tracks must already be sorted by start time.
  * Replaces: subtitle_transformers.py:35-47 + speech_transformers.py:957-980 for the device-resident pipeline. */
 int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
                              int64_t n_subs_total, const int64_t* vec_sub_first, const int64_t* vec_sub_count,

@@ -23,7 +23,8 @@
     } while (0)
 
 // 256-thread layout: 6144-word histogram (two lags per word) in 39 KB of LDS -> four workgroups per CU (round 4's kernel);
-// 512-thread layout: 12 288-word histogram (one lag per word) in 62 KB -> two workgroups per CU (round 5's kernel)
+// 512-thread layouts: 12 288-word histogram (one lag per word) in 62 KB -> two workgroups per CU; 6144-word histogram
+// (two lags per word, the value shifted by the lag's parity) in 38 KB -> four workgroups per CU (round 5's kernel)
 enum { ADD = 0, ADD_RTN = 1, WRITE = 2 };
 enum { FREE = 0, RANDOM = 1, SAME_BANK = 2, SAME_WORD = 3, RANDOM_PACKED16 = 4 };
 
@@ -148,6 +149,15 @@ int main() {
         printf("  \"%s\": {", pat_names[p]);
         for (int m = 0; m < 3; ++m) {
             const double r = run<ADD, 512>(p, masks[m].mask, 2, n_cu, out, cyc, iters, 12288, 62 * 1024);
+            printf("\"lanes_%s\": %.3f, \"lanes_%s_Gps\": %.1f%s", masks[m].name, r / clk / n_cu, masks[m].name, r / 1e9, m < 2 ? ", " : "");
+        }
+        printf("}%s\n", p < 1 ? "," : "");
+    }
+    printf(" },\n \"ds_add_u32_4x512_per_cu\": {\n");
+    for (int p = 0; p < 2; ++p) {
+        printf("  \"%s\": {", pat_names[p == 0 ? 0 : 4]);
+        for (int m = 0; m < 3; ++m) {
+            const double r = run<ADD, 512>(p == 0 ? 0 : 4, masks[m].mask, 4, n_cu, out, cyc, iters, 6144, 38 * 1024);
             printf("\"lanes_%s\": %.3f, \"lanes_%s_Gps\": %.1f%s", masks[m].name, r / clk / n_cu, masks[m].name, r / 1e9, m < 2 ? ", " : "");
         }
         printf("}%s\n", p < 1 ? "," : "");
