@@ -242,6 +242,36 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
     }
 }
 
+// Density probe (a stream of dense calls: FFS_ALGO_AUTO would extract lists only to throw them away): one wave per
+// vector reads RUNS_PROBE_WORDS words spread evenly over it and scales their boundary bits up to the whole vector --
+// hdr = (estimated boundaries, 0).  k_runs_chunk_flags on the estimates then says which sub-batches are far over budget.
+constexpr int RUNS_PROBE_WORDS = 256;
+__global__ __launch_bounds__(256) void k_runs_probe(const RunsRef* __restrict__ refs, int n_vec) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (v >= n_vec) return;
+    const RunsRef r = refs[v];
+    if (!r.bits) return;  // (a list-only vector has its true count in the header already)
+    const GWords w = (GWords)r.bits;
+    const int nw = r.len >> 5;  // whole words only
+    unsigned cnt = 0;
+    if (nw > 0) {
+#pragma unroll
+        for (int u = 0; u < RUNS_PROBE_WORDS / 64; ++u) {
+            const long long k = ((long long)(u * 64 + lane) * nw) / RUNS_PROBE_WORDS;
+            const unsigned x = w[k];
+            cnt += __popc((x ^ (x << 1)) & 0xfffffffeu);  // value changes between neighbouring samples inside the word: 31 places
+        }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) cnt += __shfl_xor(cnt, s, 64);
+    if (lane == 0) {
+        const long long sampled = (long long)(nw < RUNS_PROBE_WORDS ? (nw > 0 ? nw : 1) : RUNS_PROBE_WORDS) * 31;
+        long long est = (long long)cnt * (long long)r.len / sampled;
+        if (est > 0x3fffffff) est = 0x3fffffff;
+        const_cast<int2*>(r.hdr)[0] = make_int2((int)est, 0);
+    }
+}
+
 // every vector of a call that arrived as bits (list-only vectors are skipped)
 __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs) {
     const RunsRef r = refs[blockIdx.x];
@@ -341,7 +371,8 @@ FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
 // truncated (nothing can solve it: the host reports the error).  stats[0] += boundaries of the sub-batch's vectors.
 __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
                                                           int pairs_per_chunk, const RunsRef* __restrict__ refs, long long budget,
-                                                          int* __restrict__ flags, unsigned long long* __restrict__ stats) {
+                                                          int* __restrict__ flags, unsigned long long* __restrict__ stats,
+                                                          int estimates) {
     const int ch = blockIdx.x;
     const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
     int over = 0, bad = 0;
@@ -354,7 +385,9 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
         const GInts hq = (GInts)rr.hdr, hp = (GInts)rs.hdr;
         const int n_q = hq[0], n_p = hp[0];
         // (a caller's block carries its capacity in the header: n, ones, len, cap)
-        const int cap_q = rr.cap > 0 ? rr.cap : hq[3], cap_p = rs.cap > 0 ? rs.cap : hp[3];
+        // `estimates` (k_runs_probe): the headers of vectors that arrived as bits hold estimated counts, not list lengths
+        const int cap_q = (estimates && rr.bits) ? 0x7fffffff : (rr.cap > 0 ? rr.cap : hq[3]);
+        const int cap_p = (estimates && rs.bits) ? 0x7fffffff : (rs.cap > 0 ? rs.cap : hp[3]);
         nb += (unsigned)n_p + (j == 0 ? (unsigned)n_q : 0u);
         bad |= (!rs.bits && n_p >= cap_p) || (!rr.bits && n_q >= cap_q);
         if (cd.flags & CAND_NO_LAGS) continue;
@@ -369,7 +402,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
     __syncthreads();
     if (threadIdx.x == 0) {
         flags[ch] = bad ? 2 : over;
-        atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
+        if (!estimates) atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
     }
 }
 

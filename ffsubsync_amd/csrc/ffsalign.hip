@@ -1375,6 +1375,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     RunsRef* hrv = (RunsRef*)(hb + o_rv);
     char* db = (char*)p->dev_desc;
+    bool probe_first = false;           // (run-boundary path) a density probe stands in for the extraction so far
     const void* const* xptr = vec_ptr;  // the vectors as the transform path reads them (list-only vectors: their expansion)
     std::vector<const void*> expanded;
     if (runs_ok) {
@@ -1391,7 +1392,13 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         if (need_extract) {
             HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
             leave.armed = true;
-            {
+            // A stream of dense calls (the previous one needed the transforms): sample the vectors first -- when the
+            // estimate puts every sub-batch far over budget the lists are never extracted (decided below, once the
+            // candidate descriptors exist); otherwise the extraction is launched then.
+            probe_first = p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in;
+            if (probe_first) {
+                hipLaunchKernelGGL(k_runs_probe, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, st, (const RunsRef*)(db + o_rv), (int)n_vec);
+            } else {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
                 hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
             }
@@ -1575,10 +1582,40 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 8;
             unsigned long long* d_stats = (unsigned long long*)((char*)p->runs_flags + flag_bytes - 8);
             const int* d_flags = proven ? p->runs_zero_flags : p->runs_flags;
+            bool skip_runs = false;  // the probe says every sub-batch is dense: transforms only, nothing extracted
+            if (probe_first) {
+                // flags from the ESTIMATED counts against the budget (the estimate's sampling error is a few per cent of a
+                // count whose square enters: a sub-batch within that of the break-even costs the same either way)
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
+                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 1);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipEventRecord(p->runs_ev, st));
+                if ((rc = build_xforms())) return rc;  // (while the probe runs: needed in either case of a dense stream)
+                HIP_TRY(hipEventSynchronize(p->runs_ev));
+                skip_runs = true;
+                for (int ch = 0; ch < n_chunks; ++ch) skip_runs = skip_runs && p->runs_flags_host[ch] == 1;
+                if (!skip_runs) {  // not (any more) a dense stream: the usual order from here on
+                    ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
+                    hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
+                }
+                HIP_TRY(hipGetLastError());
+            }
+            if (skip_runs) {
+                for (int ch = 0; ch < n_chunks; ++ch) chunk_fft[ch] = 1;
+                any_fft = true;
+                p->runs_calls += 1;
+                p->runs_chunks += n_chunks;
+                p->runs_fft_chunks += n_chunks;
+                p->runs_last_boundaries = -1;
+                HIP_TRY(hipMemcpyAsync(db + o_cand, hb + o_cand, o_xf + n_xf * sizeof(XformDesc) - o_cand, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
+                HIP_TRY(hipEventRecord(p->upload_done, st));
+            } else {
             if (!proven) {
                 HIP_TRY(hipMemsetAsync(d_stats, 0, 8, st));
                 hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
-                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats);
+                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(p->runs_ev, st));
@@ -1601,8 +1638,8 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             p->runs_last_boundaries = -1;  // (not known on the host when nothing was copied back)
             if (!proven) {
                 // a stream of dense calls: the transform descriptors are built while the device extracts and decides
-                bool built = false;
-                if (p->runs_prev_fft && !lists_in) {
+                bool built = probe_first;  // (a probe has built them already)
+                if (!built && p->runs_prev_fft && !lists_in) {
                     if ((rc = build_xforms())) return rc;
                     built = true;
                 }
@@ -1640,6 +1677,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                     HIP_TRY(hipEventRecord(p->upload_done, st));
                 }
             }
+            }  // !skip_runs
         } else {
             HIP_TRY(hipMemsetAsync(da, 0, n_cands * KNOM * sizeof(RescoreAcc) + n_cands * sizeof(PoolBest), st));
         }

@@ -325,3 +325,29 @@ def test_interval_lists_to_records_without_a_bitmap(torch):
     b, st = _solve(d_runs, n_fft, 6000, "auto", pairs_in_flight=12)
     assert st[2] == 0
     _same_records(a, b)
+
+
+def test_dense_stream_is_probed_and_sparse_data_returns_to_the_lists(torch):
+    """FFS_ALGO_AUTO on a stream of dense calls: after the first call fell back to the transforms, the next ones sample
+    the vectors (k_runs_probe) and go straight to the transforms without extracting lists; a sparse call after that takes
+    the run-boundary path again.  Records as from FFS_ALGO_FFT throughout."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    dense = synth.build_device_batch([synth.make_pair_spec(7000 + i, run_scale=0.0625) for i in range(8)])
+    sparse = synth.build_device_batch([synth.make_pair_spec(i) for i in range(8)])
+    n_fft = max(dense.required_fft_length(6000), sparse.required_fft_length(6000))
+    want_dense, _ = _solve(dense, n_fft, 6000, "fft", pairs_in_flight=8)
+    want_sparse, _ = _solve(sparse, n_fft, 6000, "fft", pairs_in_flight=8)
+    al = batch.BatchAligner(n_fft, 7, 6000, pairs_in_flight=8, algorithm="auto")
+    for k in range(3):
+        got = al.solve(dense)
+        _same_records_but_f32(want_dense, got)
+        assert al.plan.runs_stats() == (k + 1, k + 1, k + 1)
+    got = al.solve(sparse)  # probed (the previous call was dense), found sparse, solved from its lists
+    _same_records_but_f32(want_sparse, got)
+    assert al.plan.runs_stats() == (4, 4, 3)
+    got = al.solve(dense)
+    _same_records_but_f32(want_dense, got)
+    assert al.plan.runs_stats() == (5, 5, 4)
+    al.close()
