@@ -810,14 +810,18 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     // score(d) = c0 ov + c1x n1x + cx1 nx1 + c11 n11 (two_level_score() multiplied out); fp32 first
     const float f0 = (float)(cd.s0 * cd.r0), f1x = (float)(cd.r0 * (cd.s1 - cd.s0)), fx1 = (float)(cd.s0 * (cd.r1 - cd.r0)),
                 f11 = (float)((cd.s1 - cd.s0) * (cd.r1 - cd.r0));
-    // |fp32 value - exact| <= 12 roundings of 2^-24 on sums of at most (|k0|+|k1x|+|kx1|+|k11|) * max(R, S); twice that
-    // separates "cannot be the maximum" from "may be": 24 * 2^-24, used with a factor 2 to spare
-    const float margin = 24.0f * 1.1920929e-7f * (fabsf(f0) + fabsf(f1x) + fabsf(fx1) + fabsf(f11)) * (float)(R > S ? R : S) * 1.01f + 1e-3f;
-    auto score32 = [&](int a11, int a1x, int ax1, int d) -> float {
+    // fp32 prefilter.  a(d) = f11 n11(d) + E(d), E = f1x n1x + fx1 nx1 + f0 ov the part that only moves where the
+    // overlap's ends pass a sample: |E(d+1) - E(d)| <= |f1x| + |fx1| + |f0| =: step.  E is refreshed every FOUR lags (exact
+    // integer counts, one popcount of four mask bits each) and used unchanged for the three lags behind -- at most
+    // 3 step off.  |fp32 value - exact| <= 12 roundings of 2^-24 on sums of at most (|k0|+|k1x|+|kx1|+|k11|) max(R, S);
+    // a lag whose prefilter value lies within 2 (rounding bound + 3 step) of the block's best may hold the maximum.
+    const float estep = fabsf(f1x) + fabsf(fx1) + fabsf(f0);
+    const float margin = 24.0f * 1.1920929e-7f * (estep + fabsf(f11)) * (float)(R > S ? R : S) * 1.01f + 6.0f * estep * 1.01f + 1e-3f;
+    auto edge32 = [&](int a1x, int ax1, int d) -> float {
         const int j0 = d < 0 ? -d : 0;
         const int j1 = (R - d) < S ? (R - d) : S;
         const int ov = j1 > j0 ? (j1 - j0) : 0;
-        return fmaf(f11, (float)a11, fmaf(f1x, (float)a1x, fmaf(fx1, (float)ax1, f0 * (float)ov)));
+        return fmaf(f1x, (float)a1x, fmaf(fx1, (float)ax1, f0 * (float)ov));
     };
     float tmax = -INFINITY;
     {
@@ -827,16 +831,16 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
         for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
             int h[4];
             unpack4(q4, h);
+            const float e32 = edge32(a1x, ax1, D0 + c + 4 * q4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = 4 * q4 + e;
-                const float f = score32(a11, a1x, ax1, D0 + c + i);
-                tmax = fmaxf(tmax, i < lim ? f : -INFINITY);
+                const float f = fmaf(f11, (float)a11, e32);
+                tmax = fmaxf(tmax, (4 * q4 + e) < lim ? f : -INFINITY);
                 g -= h[e];
                 a11 += g;
-                a1x += (int)((mi1 >> e) & 1u) - (int)((mo1 >> e) & 1u);
-                ax1 += (int)((mix >> e) & 1u) - (int)((mox >> e) & 1u);
             }
+            a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
+            ax1 += __popc(mix & 15u) - __popc(mox & 15u);
             mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
         }
     }
@@ -864,18 +868,22 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
         for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
             int h[4];
             unpack4(q4, h);
+            const float e32 = edge32(a1x, ax1, D0 + c + 4 * q4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int i = 4 * q4 + e, d = D0 + c + i;
-                if (i < lim && score32(a11, a1x, ax1, d) >= thr) {
-                    const double sc = two_level_score(cd, a11, a1x, ax1, d);
+                const int i = 4 * q4 + e;
+                if (i < lim && fmaf(f11, (float)a11, e32) >= thr) {
+                    const unsigned low = (1u << e) - 1u;  // the one-sided counts at this lag: e mask bits further
+                    const int b1x = a1x + __popc(mi1 & low) - __popc(mo1 & low), bx1 = ax1 + __popc(mix & low) - __popc(mox & low);
+                    const int d = D0 + c + i;
+                    const double sc = two_level_score(cd, a11, b1x, bx1, d);
                     if (sc >= bs) bs = sc, bd = d;
                 }
                 g -= h[e];
                 a11 += g;
-                a1x += (int)((mi1 >> e) & 1u) - (int)((mo1 >> e) & 1u);
-                ax1 += (int)((mix >> e) & 1u) - (int)((mox >> e) & 1u);
             }
+            a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
+            ax1 += __popc(mix & 15u) - __popc(mox & 15u);
             mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
         }
     }
