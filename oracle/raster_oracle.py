@@ -36,6 +36,28 @@ def rasterize(start_us, end_us, is_metadata, ratio, sample_rate=100, start_secon
     return samples
 
 
+def intervals(start_us, end_us, is_metadata, ratio, sample_rate=100, start_seconds=0, length=None):
+    """The [start, end) sample intervals ``rasterize`` paints (speech_transformers.py:966-977), clamped the way
+    ``samples[start:end] = ...`` clamps them on a vector of ``length`` samples (Python slice semantics: negative indices
+    count from the end); metadata lines and empty slices dropped.  [n, 2] int64."""
+    subs = scale(start_us, end_us, ratio)
+    if length is None:
+        max_time = 0
+        for _, te in subs:
+            max_time = max(max_time, te.total_seconds())
+        length = int(max_time * sample_rate) + 2
+    out = []
+    for (ts, te), meta in zip(subs, is_metadata):
+        if meta:
+            continue
+        start = int(round((ts.total_seconds() - start_seconds) * sample_rate))
+        end = start + int(round((te.total_seconds() - ts.total_seconds()) * sample_rate))
+        a, b, _ = slice(start, end).indices(length)
+        if a < b:
+            out.append((a, b))
+    return np.array(out, dtype=np.int64).reshape(-1, 2)
+
+
 def synth_subtitles(seed, n=180, minutes=10.0):
     """Seeded subtitle records with microsecond timestamps (as parsed srt times are), a few of them
     flagged as metadata."""

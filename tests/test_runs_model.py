@@ -78,3 +78,95 @@ def test_best_lag_equals_reference_restatement(max_offset):
             assert n - 1 - max_offset - S >= 0
         got_s, got_o = rm.best_lag(c, ref, d_lo, d_hi, (0.0, sp.cand_amp[j]), (0.0, 1.0))
         assert got_o == want_o and got_s == pytest.approx(want_s, rel=1e-12)
+
+
+def test_list_from_intervals_equals_the_painted_vector():
+    """k_rasterize_runs' rule (sorted starts, a run begins beyond every earlier end, touching intervals merge, ones in
+    front = ends minus starts of the runs in front) against painting the intervals into a vector; list_bits32 and
+    bits_from_list against the same vector."""
+    rng = np.random.RandomState(11)
+    for trial in range(300):
+        n = int(rng.randint(1, 500))
+        k = int(rng.randint(0, 40))
+        a = rng.randint(0, n + 1, k)
+        b = np.minimum(n, a + rng.randint(-3, 30, k))
+        if trial % 4 == 0 and k > 2:  # touching chains and duplicates
+            a[1:] = b[:-1]
+            b = np.minimum(n, a + rng.randint(0, 9, k))
+        x = np.zeros(n, np.uint8)
+        for s_, e_ in zip(a, b):
+            if s_ < e_:
+                x[s_:e_] = 1
+        pos, ones_before, ones = rm.list_from_intervals(a, b, n)
+        wq, wc = rm.boundaries(x)
+        assert np.array_equal(pos, wq) and np.array_equal(ones_before, wc) and ones == int(x.sum()), trial
+        assert np.array_equal(rm.bits_from_list(pos, n), x)
+        for start in (-40, -31, -1, 0, 5, n - 33, n - 1, n + 7):
+            want = 0
+            for i in range(32):
+                if 0 <= start + i < n and x[start + i]:
+                    want |= 1 << i
+            assert rm.list_bits32(pos, start) == want, (trial, start)
+
+
+def test_list_rasteriser_model_equals_the_reference_rasters():
+    """The same rule on the reference's own rasters (tests/golden/raster_golden.npz: SubtitleScaler +
+    SubtitleSpeechTransformer of the unmodified reference): intervals from the golden-pinned raster oracle -> list ->
+    bits == the committed raster."""
+    import os
+
+    from oracle import raster_oracle as ro
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "raster_golden.npz"))
+    ratios = [float(r) for r in gold["ratios"]]
+    for name in ("a", "b"):
+        s, e, m = gold[name + "_start_us"], gold[name + "_end_us"], gold[name + "_meta"]
+        for j, r in enumerate(ratios):
+            want = (gold["%s_r%d" % (name, j)] != 0).astype(np.uint8)
+            iv = ro.intervals(s, e, m, r, 100, 0, want.size)
+            pos, ones_before, ones = rm.list_from_intervals(iv[:, 0], iv[:, 1], want.size)
+            assert np.array_equal(rm.bits_from_list(pos, want.size), want), (name, j)
+            assert ones == int(want.sum())
+
+
+def test_fp32_prefilter_never_drops_the_maximum():
+    """The margin of k_runs_corr's fp32 prefilter (edge term refreshed every four lags): over random short problems and
+    the production-size window of a 2 h pair, every lag whose exact score equals the maximum survives."""
+    rng = np.random.RandomState(5)
+    cases = []
+    for _ in range(60):
+        S, R = int(rng.randint(40, 400)), int(rng.randint(40, 400))
+        cases.append((_vector(rng, S), _vector(rng, R), float(rng.choice([1.0, 0.96, 0.959]))))
+    sp = synth.make_pair_spec(1, duration_s=7200)
+    ref, cands = synth.pair_arrays(sp)
+    cases += [(cands[j], ref, float(sp.cand_amp[j])) for j in (0, 2)]
+    for s, r, amp in cases:
+        S, R = len(s), len(r)
+        d_lo, d_hi = max(-S + 1, -5999), min(R - 1, 6000)
+        n11, n1x, nx1, ov = rm.window_counts(s, r, d_lo, d_hi) if S < 1000 else _fast_counts(s, r, d_lo, d_hi)
+        keep, margin, exact = rm.prefilter_keeps_the_maximum(n11, n1x, nx1, ov, d_lo, -1.0, 2.0 * amp - 1.0, -1.0, 1.0, R, S)
+        assert keep[exact == exact.max()].all()
+        assert keep.sum() <= max(64, exact.size // 8) or S < 1000  # (and it does filter: a few per cent of a real window)
+
+
+def _fast_counts(s, r, d_lo, d_hi):
+    """Direct counts for long vectors through cumulative sums and an FFT-free sliding product (numpy correlate on a
+    window of lags would be O(N W); the run model itself is exact but slow in pure Python at 2 h)."""
+    S, R = len(s), len(r)
+    P, CP = rm.boundaries(s)
+    Q, CQ = rm.boundaries(r)
+    d = np.arange(d_lo, d_hi + 1, dtype=np.int64)
+    i0, i1 = np.maximum(0, -d), np.minimum(S, R - d)
+    ov = np.maximum(0, i1 - i0)
+    _, b1 = rm.ones_before(P, CP, int(s.sum()), np.clip(i1, 0, S))
+    _, b0 = rm.ones_before(P, CP, int(s.sum()), np.clip(i0, 0, S))
+    _, r1 = rm.ones_before(Q, CQ, int(r.sum()), np.clip(i1 + d, 0, R))
+    _, r0 = rm.ones_before(Q, CQ, int(r.sum()), np.clip(i0 + d, 0, R))
+    # n11(d) = sum over runs of s of ones of r in [a + d, e + d)
+    a, e = P[0::2], P[1::2]
+    n11 = np.zeros(d.size, dtype=np.int64)
+    for k in range(a.size):
+        _, hi_ = rm.ones_before(Q, CQ, int(r.sum()), np.clip(e[k] + d, 0, R))
+        _, lo_ = rm.ones_before(Q, CQ, int(r.sum()), np.clip(a[k] + d, 0, R))
+        n11 += hi_ - lo_
+    return n11, np.where(ov > 0, b1 - b0, 0), np.where(ov > 0, r1 - r0, 0), ov
