@@ -141,6 +141,25 @@ class TrackSet:
                                         for t in tracks])
         self.end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64)
         self._dev = None  # (start_us, end_us, is_metadata) CUDA tensors once to_device() has uploaded them
+        self._pinned = None  # pinned host tensors behind start_us / end_us / meta once pin() has moved them there
+
+    def pin(self) -> "TrackSet":
+        """Move the interval tables into pinned host memory (sorted by start time inside every track): ``rasterize_runs``
+        then uploads them straight from there, without the staging copy a pageable array needs.  The TrackSet must stay
+        alive until the stream has passed the calls that used it."""
+        torch = _native.require_gpu()
+        if self._pinned is None:
+            order = np.arange(self.start_us.size)
+            for f, c in zip(self.firsts, self.counts):
+                seg = self.start_us[f:f + c]
+                if c > 1 and (seg[1:] < seg[:-1]).any():
+                    order[f:f + c] = f + np.argsort(seg, kind="stable")
+            pin = lambda a: torch.from_numpy(np.ascontiguousarray(a[order])).pin_memory()
+            self._pinned = (pin(self.start_us), pin(self.end_us), None if self.meta is None else pin(self.meta))
+            self.start_us, self.end_us = self._pinned[0].numpy(), self._pinned[1].numpy()
+            if self.meta is not None:
+                self.meta = self._pinned[2].numpy()
+        return self
 
     def to_device(self) -> "TrackSet":
         """Upload the interval tables once (sorted by start time inside every track): ``rasterize_runs`` then copies

@@ -2189,31 +2189,56 @@ int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, con
     int rc_dev;
     if ((rc_dev = guard.enter(out_dev))) return rc_dev;
     // one staging allocation: start | end | vector table | metadata flags (see ffs_rasterize_batch_bits); with
-    // device-resident tables only the vector table
+    // device-resident tables only the vector table.  PINNED host tables (hipHostMalloc / hipHostRegister: the caller keeps
+    // them alive and unchanged until the stream has passed this call) are copied to the device straight from where they
+    // lie -- no staging copy on the host.
+    bool tables_pinned = false;
+    if (!tables_on_device && n_subs_total > 0 && xs.empty()) {
+        hipPointerAttribute_t a0, a1, a2;
+        tables_pinned = hipPointerGetAttributes(&a0, start_us) == hipSuccess && a0.type == hipMemoryTypeHost &&
+                        hipPointerGetAttributes(&a1, end_us) == hipSuccess && a1.type == hipMemoryTypeHost &&
+                        (!is_metadata || (hipPointerGetAttributes(&a2, is_metadata) == hipSuccess && a2.type == hipMemoryTypeHost));
+        (void)hipGetLastError();
+    }
+    const bool stage_subs = !tables_on_device && !tables_pinned;
     const size_t nsub = tables_on_device ? 0 : (size_t)n_subs_total + xs.size(), off_end = nsub * 8, off_vec = 2 * nsub * 8;
     const bool with_meta = is_metadata != nullptr;
     const size_t off_meta = off_vec + (size_t)n_vec * sizeof(RasterRunsVec), total = off_meta + (with_meta && !tables_on_device ? nsub : 0);
     PinnedStage* stage = nullptr;
-    int rc = stage_acquire(total, &stage);
+    int rc = stage_acquire(stage_subs ? total : (size_t)n_vec * sizeof(RasterRunsVec), &stage);
     if (rc) return rc;
     char* hs = (char*)stage->host;
     const size_t n0 = tables_on_device ? 0 : (size_t)n_subs_total;
-    if (n0) {
-        memcpy(hs, start_us, n0 * 8);
-        memcpy(hs + off_end, end_us, n0 * 8);
-    }
-    if (!xs.empty()) {
-        memcpy(hs + n0 * 8, xs.data(), xs.size() * 8);
-        memcpy(hs + off_end + n0 * 8, xe.data(), xe.size() * 8);
-    }
-    memcpy(hs + off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterRunsVec));
-    if (with_meta && !tables_on_device) {
-        if (n0) memcpy(hs + off_meta, is_metadata, n0);
-        if (!xm.empty()) memcpy(hs + off_meta + n0, xm.data(), xm.size());
+    if (stage_subs) {
+        if (n0) {
+            memcpy(hs, start_us, n0 * 8);
+            memcpy(hs + off_end, end_us, n0 * 8);
+        }
+        if (!xs.empty()) {
+            memcpy(hs + n0 * 8, xs.data(), xs.size() * 8);
+            memcpy(hs + off_end + n0 * 8, xe.data(), xe.size() * 8);
+        }
+        memcpy(hs + off_vec, vecs.data(), (size_t)n_vec * sizeof(RasterRunsVec));
+        if (with_meta) {
+            if (n0) memcpy(hs + off_meta, is_metadata, n0);
+            if (!xm.empty()) memcpy(hs + off_meta + n0, xm.data(), xm.size());
+        }
+    } else {
+        memcpy(hs, vecs.data(), (size_t)n_vec * sizeof(RasterRunsVec));
     }
     char* d = nullptr;
     HIP_TRY(hipMallocAsync((void**)&d, total, st));
-    if (hipMemcpyAsync(d, hs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    if (stage_subs) {
+        if (hipMemcpyAsync(d, hs, total, hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    } else {
+        bool ok = hipMemcpyAsync(d + off_vec, hs, (size_t)n_vec * sizeof(RasterRunsVec), hipMemcpyHostToDevice, st) == hipSuccess;
+        if (tables_pinned) {
+            ok = ok && hipMemcpyAsync(d, start_us, n0 * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+            ok = ok && hipMemcpyAsync(d + off_end, end_us, n0 * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+            if (with_meta) ok = ok && hipMemcpyAsync(d + off_meta, is_metadata, n0, hipMemcpyHostToDevice, st) == hipSuccess;
+        }
+        if (!ok) rc = fail(FFS_E_HIP, "copying the subtitle tables failed");
+    }
     if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
     if (rc == FFS_OK) {
         const long long* d_start = tables_on_device ? (const long long*)start_us : (const long long*)d;

@@ -308,7 +308,9 @@ int ffs_rasterize_batch_bits(const int64_t* start_us, const int64_t* end_us, con
  * make start samples negative, which Python's slice semantics wrap around: use the bit rasteriser then).
  * start_us / end_us / is_metadata may be DEVICE pointers (all of them): tracks that are rasterised again and again -- the
  * steps of a golden-section search, one subtitle file against many references -- are uploaded once, nothing of them is
- * copied per call; device-resident tracks must already be sorted by start time.
+ * copied per call; device-resident tracks must already be sorted by start time.  PINNED host tables (hipHostMalloc /
+ * hipHostRegister, sorted) are copied to the device straight from the caller's memory, without a staging copy: the caller
+ * keeps them alive and unchanged until the stream has passed the call (pageable tables may be freed after return).
  * Replaces: subtitle_transformers.py:35-47 + speech_transformers.py:957-980 for the device-resident pipeline. */
 int ffs_rasterize_batch_runs(const int64_t* start_us, const int64_t* end_us, const uint8_t* is_metadata,
                              int64_t n_subs_total, const int64_t* vec_sub_first, const int64_t* vec_sub_count,

@@ -1,12 +1,13 @@
 #!/bin/bash
-# One pass over every round-4 artefact, from one binary (run on the GPU box through gpurun):
+# One pass over every artefact of a round, from one binary (run on the GPU box through gpurun):
 #   GPU tests + smoke; PMC passes at the TIMED launch shape (512 pairs per launch) of the run-boundary kernels (default
 #   algorithm) and of the transform kernels (--algorithm fft; default plan + --reference-length); traffic_per_pair.json;
 #   rocprofv3 kernel trace of the bench command; rocprofv3 trace + PMC of the secondary kernels (VAD sweep, tokenizer,
 #   rasteriser, windowless / reference-length transforms); last the default bench line (reads the fresh traffic file).
-#   TAG=r04 bash profiles/refresh_all.sh
+#   rocprofv3 kernel trace of the transform path at the timed shape (bench.py --algorithm fft: <TAG>_kernel_stats_fft.csv);
+#   TAG=r05 bash profiles/refresh_all.sh
 set -u
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/refresh
 rm -rf "$O"; mkdir -p "$O"
@@ -27,6 +28,13 @@ bash profiles/run_trace.sh $TAG > "$O/trace.log" 2>&1
 cd "$GRAFT_REPO_ROOT"
 cp gpurun_out/trace_$TAG/bench_under_rocprof.json "$O/${TAG}_bench_under_rocprof.json"
 find gpurun_out/trace_$TAG -name "*kernel_stats.csv" -exec cp {} "$O/${TAG}_kernel_stats.csv" \;
+# the north star's transform kernels at the timed shape (8192 pairs per step, 512 per launch): VERDICT r4 item 7a
+bash profiles/run_trace.sh ${TAG}fft "--algorithm fft --steps 6 --warmup 2" > "$O/trace_fft.log" 2>&1
+cd "$GRAFT_REPO_ROOT"
+cp gpurun_out/trace_${TAG}fft/bench_under_rocprof.json "$O/${TAG}_bench_under_rocprof_fft.json"
+find gpurun_out/trace_${TAG}fft -name "*kernel_stats.csv" -exec cp {} "$O/${TAG}_kernel_stats_fft.csv" \;
+rm -rf gpurun_out/trace_${TAG}fft/*/*.db 2>/dev/null
+profiles/_bin/lds_atomic_ceiling > "$O/lds_atomic_ceiling.json" 2> /dev/null
 # secondary kernels: one kernel trace, two PMC passes
 S=$GRAFT_REPO_ROOT/$O/secondary
 mkdir -p "$S"

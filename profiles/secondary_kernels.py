@@ -51,7 +51,9 @@ for _ in range(REP):
 alg["k_speech_bounds"] = {"bytes_per_launch": 4 * n_frames}
 for _ in range(REP):
     _native.pack_bits(labels)
-alg["k_pack_bits"] = {"bytes_per_launch": 4 * n_frames + n_frames // 8}
+# (keyed by instantiation: k_pack_bits<1> packs fp32 labels here; k_pack_bits<0> packs the 0/1 BYTE chunks of
+# synth.build_device_batch further down -- round 4's summary divided those 184 MB launches by this 2 MB figure: "93 x")
+alg["k_pack_bits<1>"] = {"bytes_per_launch": 4 * n_frames + n_frames // 8}
 del pcm, labels
 torch.cuda.synchronize()
 
@@ -66,11 +68,34 @@ try:
     alg["k_rasterize_batch"] = {"bytes_per_launch": int(dbr.data.numel()) + 16 * n_sub,
                                 "what": "output bits (zeroed + written) + 16 bytes per (vector, subtitle) interval read"}
     del dbr
+    # round 5: the same vectors as boundary lists -- no bitmap (subtitle tables uploaded once, as the searches hold them)
+    ts = batch.TrackSet([t for rec in recs for t in rec]).to_device()
+    track_of = (np.tile(np.array([0] + [1] * 7), (pairs, 1)) + 2 * np.arange(pairs)[:, None]).ravel()
+    ratio = np.tile(np.array([1.0] + list(candidate_ratios())), (pairs, 1)).ravel()
+    for _ in range(REP):
+        data_l, offs_l, lens_l, bounds_l = ts.rasterize_runs(track_of, ratio)
+    torch.cuda.synchronize()
+    n_ent = int(sum(int(data_l[int(o): int(o) + 4].view(torch.int32).item()) + 1 for o in offs_l[:: max(1, len(offs_l) // 64)]) * max(1, len(offs_l) // 64))
+    alg["k_rasterize_runs"] = {"bytes_per_launch": 16 * n_sub + 8 * n_ent + 16 * len(offs_l),
+                               "what": "16 bytes per (vector, subtitle) interval read + 8 bytes per list entry and 16 per header "
+                                       "written (entries counted on every %d-th vector)" % max(1, len(offs_l) // 64)}
+    del data_l
 except Exception as exc:  # the record layout of pairs_from_intervals is checked by its own tests; never take the trace down
-    alg["k_rasterize_batch"] = {"error": repr(exc)[:200]}
+    alg.setdefault("k_rasterize_batch", {"error": repr(exc)[:200]})
+    alg.setdefault("k_rasterize_runs", {"error": repr(exc)[:200]})
 
 # ---- transform kernels of the three plans (FFS_ALGO_FFT), `pairs` pairs per launch
 db = synth.build_device_batch(specs)
+alg["k_pack_bits<0>"] = {"bytes_per_launch": float(np.sum(db.lens)) * (1.0 + 1.0 / 8.0) / max(1, (pairs + 31) // 32),
+                         "what": "synth.build_device_batch packing its 0/1 byte chunks of 32 pairs (bytes read + bits written)"}
+# bits -> boundary lists for every vector of the batch (ffs_runs_from_bits_batch = k_runs_extract_lists)
+for _ in range(2):
+    dl = db.to_runs(cap=8192)
+torch.cuda.synchronize()
+n_b = dl.data.view(torch.int32).reshape(-1, int(dl.offs.ravel()[1]) // 4)[:, 0].sum().item()
+alg["k_runs_extract_lists"] = {"bytes_per_launch": float(np.sum((db.lens + 31) // 32 * 4)) + 8.0 * n_b + 16.0 * db.lens.size,
+                               "what": "every bit-packed vector read once + 8 bytes per boundary written"}
+del dl
 unit = lambda nfft: 8.0 * nfft
 in_bytes = float(np.mean(db.lens.sum(axis=1))) / 8.0
 for label, mo, ref_len in (("default_3x2^18_segmented", 6000, False), ("windowless_3x2^19", None, False), ("reference_length_2^21", 6000, True)):

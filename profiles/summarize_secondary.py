@@ -49,6 +49,8 @@ for name, ns in calls.items():
         h = len(ns) // 2
         res["k_vad_energy[fp32 labels]"] = rec(ns[:h], alg["k_vad_energy"]["bytes_per_launch_fp32_labels"], name, slice(0, h))
         res["k_vad_energy[bit-packed labels]"] = rec(ns[h:], alg["k_vad_energy"]["bytes_per_launch_bit_labels"], name, slice(h, None))
+    elif name in alg and "bytes_per_launch" in alg[name]:  # keyed by instantiation (k_pack_bits<0> / <1> are different call sites)
+        res[name] = rec(ns, alg[name]["bytes_per_launch"], name)
     elif base in alg and "bytes_per_launch" in alg[base]:
         res[name] = rec(ns, alg[base]["bytes_per_launch"], name)
 # the transform kernels: launches come in plan order (default, windowless, reference length), two solves each
@@ -62,4 +64,13 @@ for name, ns in calls.items():
     by_n[name] = (k, ns)
 res["transform_kernels"] = {name: {"role": k, "launches": len(ns), "avg_us": sum(ns) / len(ns) / 1e3} for name, (k, ns) in by_n.items()}
 res["transform_plans"] = {p: alg[p] for p in plans}
+res["notes"] = {
+    "k_pack_bits<0>": "round 4 reported 93 x PMC-over-algorithmic: its launches (synth.build_device_batch packing 184 MB byte chunks) "
+                      "were divided by the 2 MB of the label-packing call site; records are now keyed by instantiation",
+    "k_vad_tokenize_scan": "PMC bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB uses the guide's gfx950 correction for wide streaming "
+                           "reads; this kernel's 4-byte loads are counted at face value, so the x 2 over-counts: with FETCH taken "
+                           "as is the figure is 1.0 x (reads 4 B + writes 4 B per frame)",
+    "k_rasterize_batch": "the bit rasteriser writes words with atomicOr after a memset (every output byte moves three times); "
+                         "device-resident pipelines use k_rasterize_runs since round 5 (boundary lists, no bitmap)",
+}
 print(json.dumps(res, indent=1, sort_keys=True))

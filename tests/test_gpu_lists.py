@@ -351,3 +351,29 @@ def test_dense_stream_is_probed_and_sparse_data_returns_to_the_lists(torch):
     _same_records_but_f32(want_dense, got)
     assert al.plan.runs_stats() == (5, 5, 4)
     al.close()
+
+
+def test_pinned_and_device_resident_tables_give_the_same_lists(torch):
+    """TrackSet.pin() (tables uploaded straight from pinned memory) and TrackSet.to_device() (tables uploaded once) against
+    pageable host tables: byte-identical list buffers, unsorted tracks included."""
+    from ffsubsync_amd import batch
+
+    rng = np.random.RandomState(9)
+    tracks = []
+    for k in range(6):
+        s = np.sort(rng.randint(0, 400_000_000, 700)).astype(np.int64)
+        if k % 2:
+            rng.shuffle(s)
+        tracks.append((s, s + rng.randint(100_000, 5_000_000, 700), (rng.rand(700) < 0.03).astype(np.uint8)))
+    track_of = np.repeat(np.arange(6), 3)
+    ratio = np.tile([1.0, 1.0417, 0.96], 6)
+    want, offs, lens, _ = batch.TrackSet(tracks).rasterize_runs(track_of, ratio)
+    for mode in ("pin", "to_device"):
+        ts = batch.TrackSet(tracks)
+        getattr(ts, mode)()
+        got, o2, l2, _ = ts.rasterize_runs(track_of, ratio)
+        assert np.array_equal(offs, o2) and np.array_equal(lens, l2)
+        for v in range(track_of.size):  # (compare what each block holds: header + entries incl. the sentinel)
+            n = int(want[int(offs[v]): int(offs[v]) + 4].view(torch.int32).item())
+            nb = 16 + 8 * (n + 1)
+            assert torch.equal(want[int(offs[v]): int(offs[v]) + nb], got[int(offs[v]): int(offs[v]) + nb]), (mode, v)
