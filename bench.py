@@ -610,8 +610,9 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
         held = None if tables == "per_batch" else batch.TrackSet(tracks)
         if tables == "device":
             held.to_device()
-        elif tables == "host":
-            held.pin()  # (a store of parsed subtitles would keep its tables in pinned memory: no staging copy per batch)
+        # (tables == "host": pageable tables, staged by the entry point.  TrackSet.pin() -- uploads straight from pinned
+        # memory -- is faster per call when calls are synchronised, 0.31 vs 0.43 ms, but slower in a stream of unsynchronised
+        # batches, 0.92 vs 0.52 ms of host time per call: profiles/ingest_profile.py)
 
         def run(k):
             ts = held if held is not None else batch.TrackSet(tracks)
@@ -642,8 +643,8 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
         lists_fig = {
             "what": "the warm stream with boundary lists instead of bitmaps: batches of %d pairs back to back (16 timed after 8 "
                     "warm ones), per batch ffs_rasterize_batch_runs -> ffs_align_batch_runs with host-known list bounds (no "
-                    "extraction pass, nothing read back).  solves_per_s: the subtitle tables held in one host TrackSet (pinned "
-                    "memory) and uploaded with every batch" % n_pairs,
+                    "extraction pass, nothing read back).  solves_per_s: the subtitle tables held in one host TrackSet and "
+                    "uploaded with every batch" % n_pairs,
             "solves_per_s": rate_h, "same_results": bool(np.array_equal(pres_h, pres_b)),
             "trackset_built_per_batch": {
                 "what": "the TrackSet itself (numpy concatenation of the 2 x %d per-track arrays) built inside the timed region, "

@@ -145,8 +145,10 @@ class TrackSet:
 
     def pin(self) -> "TrackSet":
         """Move the interval tables into pinned host memory (sorted by start time inside every track): ``rasterize_runs``
-        then uploads them straight from there, without the staging copy a pageable array needs.  The TrackSet must stay
-        alive until the stream has passed the calls that used it."""
+        then uploads them straight from there, without the staging copy a pageable array needs (measured, 256 pairs x 8
+        vectors: 0.31 instead of 0.43 ms per synchronised call; in a stream of unsynchronised batches the staged path is
+        the faster one -- profiles/ingest_profile.py).  The TrackSet must stay alive until the stream has passed the calls
+        that used it."""
         torch = _native.require_gpu()
         if self._pinned is None:
             order = np.arange(self.start_us.size)

@@ -48,6 +48,9 @@ out["rasterize_runs_host_tables_us"] = {"host_only": t(lambda: ts_host.rasterize
                                         "with_sync": t(lambda: ts_host.rasterize_runs(track_of, ratio))}
 out["rasterize_runs_device_tables_us"] = {"host_only": t(lambda: ts_dev.rasterize_runs(track_of, ratio), sync=False),
                                           "with_sync": t(lambda: ts_dev.rasterize_runs(track_of, ratio))}
+ts_pin = batch.TrackSet(tracks).pin()
+out["rasterize_runs_pinned_tables_us"] = {"host_only": t(lambda: ts_pin.rasterize_runs(track_of, ratio), sync=False),
+                                          "with_sync": t(lambda: ts_pin.rasterize_runs(track_of, ratio))}
 out["rasterize_bits_us"] = {"with_sync": t(lambda: ts_host.rasterize(track_of, ratio))}
 data, offs, lens, bounds = ts_dev.rasterize_runs(track_of, ratio)
 db = batch.DeviceBatch(data, offs.reshape(n_pairs, 8), lens.reshape(n_pairs, 8), np.zeros_like(hi), hi, _native.FFS_DTYPE_RUNS, None,
