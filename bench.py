@@ -162,6 +162,9 @@ def compact_record(result, detail_path=None):
         detail["strong_proxy" if "strong_scaling_proxy" in result else "strong"] = {
             k: _num(ss[k]) for k in ("pairs_per_rank_per_step", "ms_per_step", "solves_per_s_this_gpu", "value",
                                      "efficiency_vs_headline_batch", "predicted_8_gpu_strong_solves_per_s") if k in ss}
+        if isinstance(ss.get("vectors_resident_as_boundary_lists"), dict) and "ms_per_step" in ss["vectors_resident_as_boundary_lists"]:
+            detail["strong_proxy_lists"] = {k: _num(v) for k, v in ss["vectors_resident_as_boundary_lists"].items()
+                                            if k in ("ms_per_step", "solves_per_s_this_gpu", "predicted_8_gpu_strong_solves_per_s")}
     bd = (result.get("boundary_density") or {}).get("sweep")
     if bd:  # [boundaries per vector, auto solves/s, transforms solves/s, path initial]
         detail["boundary_density"] = [[int(s["boundaries_per_vector"]), int(s["auto_solves_per_s"]), int(s["transforms_solves_per_s"]),
@@ -736,6 +739,31 @@ def strong_leg(torch, _native, batch, synth, args, rank, world, dist, comm, host
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     rec = gathered.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)
+    lists_fig = None
+    if world == 1:
+        # the same share with the vectors resident as BOUNDARY LISTS (converted once, outside the timed steps; their
+        # lengths known on the host): a step is k_runs_corr + k_finalize_pairs + the gather, and the call never waits
+        try:
+            dl = db.to_runs(cap=8192)
+            torch.cuda.synchronize()
+            n_l = dl.data.view(torch.int32).reshape(-1, int(dl.offs.ravel()[1]) // 4)[:, 0].cpu().numpy().reshape(dl.offs.shape)
+            dl.bounds = (n_l + 2).astype(np.int32)
+            db_bits, db = db, dl
+            for _ in range(warmup):
+                step()
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            fence()
+            el_l = time.perf_counter() - t1
+            same = bool(np.array_equal(gathered.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:n_local], rec[:n_local]))
+            db = db_bits
+            lists_fig = {"ms_per_step": 1e3 * el_l / steps, "solves_per_s_this_gpu": n_local * steps / el_l,
+                         "efficiency_vs_headline_batch": n_local * steps / el_l / headline_value, "same_records": same,
+                         "predicted_%d_gpu_strong_solves_per_s" % proxy_world: n_local * steps / el_l * proxy_world}
+        except Exception as exc:
+            lists_fig = {"error": repr(exc)[:200]}
     golden = load_headline_golden()
     mine = rec[(rank if world > 1 else 0) * per:][:n_local]
     ok = sum(int(mine[i]["best_cand"]) == golden[s]["index"] and int(mine[i]["offset"]) == golden[s]["offset"]
@@ -765,6 +793,8 @@ def strong_leg(torch, _native, batch, synth, args, rank, world, dist, comm, host
                     "here on one rank (xGMI latency of a %d-rank all-gather of %d bytes comes on top: ~20-30 us per step)"
                     % (proxy_world, per * 24, proxy_world, per * 24 * proxy_world),
         })
+        if lists_fig is not None:
+            out["vectors_resident_as_boundary_lists"] = lists_fig
     return out
 
 
@@ -962,6 +992,13 @@ def main():
                 entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
                 entry["frac_of_8TBps"] = entry["must_move_GBps"] * 1e9 / HBM_PEAK
                 entry["boundaries_per_vector"] = last_info["boundaries_last_call"] / (last_info["pairs_per_call"] * (1.0 + cands))
+            if k == "levels" and ref_bytes_per_sample is not None:
+                # k_levels_sample + k_levels_bits: every float sample of the references read once, three threshold planes of
+                # one bit per sample written
+                per_pair = float(np.mean(db.lens[:, 0])) * (ref_bytes_per_sample + 3.0 / 8.0)
+                entry["must_move_bytes_per_launch"] = per_pair * pairs_per_launch
+                entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
+                entry["frac_of_8TBps"] = entry["must_move_GBps"] * 1e9 / HBM_PEAK
             if k == "runs_corr":
                 entry["bound"] = "LDS atomics (one ds_add_u32 per boundary coincidence inside the lag window) -- not an HBM kernel"
             if k in work_pmc:  # wave-instructions and LDS-array cycles per pair from the PMC passes (profiles/make_traffic.py)
@@ -1390,7 +1427,9 @@ def main():
             result["float_inputs"] = {
                 "what": "%d pairs: float64 four-level reference vectors (0.6*silero + 0.4*webrtc levels) + seven bit-packed "
                         "candidates per pair, resident in HBM; ffs_align_batch_typed (reference FFS_DTYPE_F64, candidates "
-                        "FFS_DTYPE_U1); n_fft_device %d" % (nf, n_dev),
+                        "FFS_DTYPE_U1); n_fft_device %d.  Round 5: the library finds the levels on the device, writes the "
+                        "reference's three threshold planes (one pass over the 5.8 MB of float64 per reference: what bounds the "
+                        "leg), and the run-boundary kernel adds the levels up with integer multiplicities 2 : 1 : 2" % (nf, n_dev),
                 "path": info_now["path"], "value": nf * st_f / el_f, "unit": "7-ratio solves/s",
                 "pairs_matching_reference_golden": "%d/%d" % (f_ok, f_tot),
                 "golden": "tests/golden/float_golden.json (unmodified reference on seeds 5000..): offsets bit-identical, scores "

@@ -75,7 +75,7 @@ EXPORTED_SYMBOLS = (
     "ffs_last_error",
     "ffs_version",
 )
-KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore", "runs_extract", "runs_corr")
+KERNEL_NAMES = ("pass_a", "mid", "pass_c", "nominees", "rescore", "runs_extract", "runs_corr", "levels")
 FFS_ALGO_AUTO, FFS_ALGO_FFT, FFS_ALGO_RUNS = 0, 1, 2
 ALGORITHMS = {"auto": FFS_ALGO_AUTO, "fft": FFS_ALGO_FFT, "runs": FFS_ALGO_RUNS}
 

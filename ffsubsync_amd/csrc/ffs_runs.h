@@ -445,6 +445,169 @@ struct QGlb {
     FFS_DEV int2 two(int k) const { return make_int2(one(k), one(k + 1)); }
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-level references (round 5).  The `weighted` fused VAD hands the aligner 0.6 * silero + 0.4 * webrtc
+// (speech_transformers.py:290-293): four levels {l, .4 + .6 l, .6 + .4 l, 1} (l = non_speech_label), a float vector.
+// A vector with levels lam_0 < ... < lam_{L-1}, L <= 4, is  lam_0 + sum_k (lam_k - lam_{k-1}) [r >= lam_k]  -- L - 1
+// two-level THRESHOLD vectors; when the steps are small integer multiples m_k of one quantum q (2 : 1 : 2 above), the
+// integer-valued vector M = sum_k m_k [r >= lam_k] satisfies r = lam_0 + q M and its correlation with a two-level
+// candidate follows from the SAME histogram, every coincidence with threshold list k added m_k-fold:
+//     sum_i s'[i] (2 r[i+d] - 1) = (2 lam_0 - 1) (s0 ov + (s1 - s0) n1x) + 2 q (s0 Mx1 + (s1 - s0) M11),
+// M11 = sum_i b[i] M[i+d] and Mx1 = sum over the overlap of M exact integers.  Anything else (more levels, steps that are
+// not commensurable, a sample that is none of the levels) is flagged and takes the transforms.
+struct LevelInfo {
+    double lam[4];  // the distinct sample values, ascending
+    double q;       // quantum of the level steps
+    int32_t n_levels;  // 1 .. 4; 5 = more than four
+    int32_t m[3];      // lam[k + 1] - lam[k] = m[k] * q
+    int32_t ok;        // usable by the run-boundary path (cleared again when a sample matches no level)
+    int32_t pad[3];
+};
+constexpr int LEVELS_MAX_MULT = 8;
+
+template <class T>
+FFS_DEV void levels_insert(double (&v)[5], int& n, T x) {  // keep up to five distinct values (the fifth means "too many")
+    const double d = (double)x;
+    bool seen = false;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) seen |= (i < n && v[i] == d);
+    if (!seen && n < 5) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (i == n) v[i] = d;
+        ++n;
+    }
+}
+
+// One workgroup per reference vector: 2048 samples spread evenly -> the distinct values among them (a level that fills
+// less than ~0.3 % of a vector may be missed: k_levels_bits then meets an unknown sample and clears `ok`).
+template <class T>
+__global__ __launch_bounds__(256) void k_levels_sample(const T* const* __restrict__ vec, const int* __restrict__ len, LevelInfo* __restrict__ out) {
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typedef const __attribute__((address_space(1))) T* GT;
+    const GT x = (GT)vec[v];
+    const int n = len[v];
+    double vals[5];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const long long k = ((long long)(u * 256 + tid) * n) / 2048;
+        if (k < n) levels_insert(vals, cnt, x[k]);
+    }
+    // merge: lane 0 of every wave collects its lanes' values, thread 0 the four waves'
+    __shared__ double s_v[4][5];
+    __shared__ int s_n[4];
+    double wv[5];
+    int wn = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int cn = __shfl(cnt, l, 64);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const double d = __shfl(vals[i], l, 64);
+            if (i < cn) levels_insert(wv, wn, d);
+        }
+    }
+    if (lane == 0) {
+        s_n[wave] = wn;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) s_v[wave][i] = wv[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double all[5];
+        int an = 0;
+        for (int w = 0; w < 4; ++w)
+            for (int i = 0; i < s_n[w] && i < 5; ++i) levels_insert(all, an, s_v[w][i]);
+        for (int i = 1; i < an && i < 5; ++i)  // ascending (insertion sort of at most five)
+            for (int j = i; j > 0 && all[j] < all[j - 1]; --j) {
+                const double t = all[j];
+                all[j] = all[j - 1];
+                all[j - 1] = t;
+            }
+        LevelInfo li;
+        li.n_levels = an;
+        li.ok = 0;
+        li.q = 0.0;
+        li.pad[0] = li.pad[1] = li.pad[2] = 0;
+        for (int i = 0; i < 4; ++i) li.lam[i] = i < an ? all[i] : 0.0;
+        for (int i = 0; i < 3; ++i) li.m[i] = 0;
+        if (an >= 2 && an <= 4 && all[0] == all[0] && all[an - 1] - all[0] < 1e300) {
+            double q = all[1] - all[0];
+            for (int i = 2; i < an; ++i) q = (all[i] - all[i - 1]) < q ? (all[i] - all[i - 1]) : q;
+            // the steps as multiples of the smallest one over 1, 2, 3, 4: 2 : 1 : 2 needs the divisor 1, 3 : 2 the divisor 2 ...
+            for (int dv = 1; dv <= 4 && !li.ok; ++dv) {
+                const double qq = q / dv;
+                bool good = true;
+                int mm[3] = {0, 0, 0};
+                for (int i = 1; i < an; ++i) {
+                    const double r = (all[i] - all[i - 1]) / qq, rr = rint(r);
+                    good = good && fabs(r - rr) <= 1e-9 * rr && rr >= 1.0 && rr <= (double)LEVELS_MAX_MULT;
+                    mm[i - 1] = (int)rr;
+                }
+                if (good) {
+                    li.ok = 1;
+                    li.q = qq;
+                    for (int i = 0; i < 3; ++i) li.m[i] = mm[i];
+                }
+            }
+        }
+        out[v] = li;
+    }
+}
+
+// Threshold planes of a multi-level vector: plane k (k = 0 .. 2) bit i = [x[i] >= lam[k + 1]] (all zero for k >= L - 1),
+// `plane_words` 32-bit words apart.  grid = (chunks of 16 384 samples, vectors); a wave turns 64 samples into two words per
+// plane with a ballot.  A sample that equals none of the levels clears info->ok (the vector then takes the transforms).
+template <class T>
+__global__ __launch_bounds__(256) void k_levels_bits(const T* const* __restrict__ vec, const int* __restrict__ len,
+                                                     LevelInfo* __restrict__ info, unsigned* const* __restrict__ planes,
+                                                     const int* __restrict__ plane_words) {
+    const int v = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = len[v];
+    const long long c0 = (long long)blockIdx.x * 16384;
+    if (c0 >= n) return;
+    const LevelInfo li = info[v];
+    if (!li.ok) return;
+    typedef const __attribute__((address_space(1))) T* GT;
+    const GT x = (GT)vec[v];
+    unsigned* out = planes[v];
+    const int pw = plane_words[v];
+    bool bad = false;
+    // eight wave-steps of 64 samples at a time: their loads are issued together (one 8-byte load per lane and step would
+    // leave the sweep latency-bound), then classified and turned into words by ballots
+    constexpr int LU = 8;
+    for (int it = 0; it < 64; it += LU) {
+        const long long base0 = c0 + (long long)(it * 4 + wave * LU) * 64;  // this wave's LU consecutive steps
+        if (base0 >= n) break;
+        T xv[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const long long i = base0 + u * 64 + lane;
+            xv[u] = i < n ? __builtin_nontemporal_load(x + i) : (T)li.lam[0];
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const long long base = base0 + u * 64;
+            const double d = (double)xv[u];
+            int idx = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < li.n_levels && d == li.lam[k]) idx = k;
+            bad |= idx < 0;
+            if (base + lane >= n) idx = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long bal = __ballot(idx >= k + 1);
+                if (lane < 2 && base < n) {
+                    const long long w = (base >> 5) + lane;
+                    if (w < pw) out[(size_t)k * pw + w] = lane ? (unsigned)(bal >> 32) : (unsigned)bal;
+                }
+            }
+        }
+    }
+    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) info[v].ok = 0;
+}
+
 // inclusive prefix sum over the 64 lanes of three ints at once, DPP only (no LDS round trips)
 FFS_DEV void wave_incl_scan3(int& a, int& b, int& c) {
     a = (int)wave_incl_scan_u32((unsigned)a);
@@ -515,9 +678,13 @@ constexpr int RUNS_EDGE = 96;  // list entries staged per edge window stretch (d
 #ifndef FFS_RUNS_WPS
 #define FFS_RUNS_WPS 8
 #endif
-__global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
-    const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
-    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk) {
+// ML: the reference is a multi-level vector given as up to three threshold lists refs[n_vec_all + 3 pair + k] with the
+// multiplicities of linfo[pair] (see LevelInfo); the levels are processed one after the other into the same histogram.
+template <bool ML>
+FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs,
+                            CandResult* __restrict__ cres, RunsBest* __restrict__ best, int tiles_max,
+                            const int* __restrict__ chunk_flags, int pairs_per_chunk, const LevelInfo* __restrict__ linfo,
+                            int n_vec_all) {
     __shared__ __attribute__((aligned(16))) unsigned hist[RUNS_T / 2 + 4];  // second difference h of the tile's lags, 16 bits per lag
     __shared__ __attribute__((aligned(16))) int q_lds[RUNS_QCAP + 4];
     __shared__ int s_edge[4][RUNS_EDGE];
@@ -530,8 +697,16 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     const int pair = ci / n_cand;
     if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
     const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
-    const RunsRef rr = refs[vr], rs_ = refs[vs];  // (independent of the descriptor: the three loads travel together)
+    const int vr0 = ML ? n_vec_all + 3 * pair : vr;  // (first) list of the reference
+    RunsRef rr = refs[vr0];
+    const RunsRef rs_ = refs[vs];  // (independent of the descriptor: the three loads travel together)
     const CandDesc cd = cands[ci];
+    LevelInfo li;
+    int n_lv = 1;
+    if (ML) {
+        li = linfo[pair];
+        n_lv = li.n_levels - 1;
+    }
     if (cd.flags & CAND_NO_LAGS) {
         if (tile == 0 && tid == 0) {
             runs_write_cand(cd, cres, ci, 0.0, 0, true);
@@ -544,9 +719,12 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     const int S = cd.S, R = cd.R;
     const int D0 = cd.d_lo + tile * RUNS_T;
     const int Wt = (cd.d_hi - D0 + 1) < RUNS_T ? (cd.d_hi - D0 + 1) : RUNS_T;
-    const GEntries Pe = (GEntries)rs_.e, Qe = (GEntries)rr.e;
-    const GWords sbits = (GWords)rs_.bits, rbits = (GWords)rr.bits;
-    const int n_p = ((GInts)rs_.hdr)[0], n_q = ((GInts)rr.hdr)[0];
+    const GEntries Pe = (GEntries)rs_.e;
+    GEntries Qe = (GEntries)rr.e;
+    const GWords sbits = (GWords)rs_.bits;
+    GWords rbits = (GWords)rr.bits;
+    const int n_p = ((GInts)rs_.hdr)[0];
+    int n_q = ((GInts)rr.hdr)[0];
     const int c = tid * RUNS_LPT;  // this thread's lags: D0 + c .. D0 + c + RUNS_LPT - 1
     // the samples that enter (+) and leave (-) the two one-sided counts when the lag grows by one, lag c + i = bit i:
     //   n1x(d+1) = n1x(d) + b[-d-1] - b[R-d-1],   nx1(d+1) = nx1(d) - rho[d] + rho[S+d]   (zero outside the vectors)
@@ -556,11 +734,23 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
         m_in1x = __brev(fetch32(sbits, S, -dc - 32));
         m_out1x = __brev(fetch32(sbits, S, (long long)R - dc - 32));
     }
-    if (rbits) {
+    // ML: per group of four lags, sum over the threshold planes of m_k (samples entering - leaving nx1): wx1g
+    int wx1g[ML ? RUNS_LPT / 4 : 1];
+    if (ML) {
+#pragma unroll
+        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wx1g[g4] = 0;
+        for (int k = 0; k < n_lv; ++k) {
+            const GWords pb = (GWords)refs[vr0 + k].bits;
+            const unsigned mo = fetch32(pb, R, dc), mi = fetch32(pb, R, (long long)S + dc);
+#pragma unroll
+            for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4)
+                wx1g[g4] += li.m[k] * (__popc((mi >> (4 * g4)) & 15u) - __popc((mo >> (4 * g4)) & 15u));
+        }
+    } else if (rbits) {
         m_outx1 = fetch32(rbits, R, dc);
         m_inx1 = fetch32(rbits, R, (long long)S + dc);
     }
-    if ((!sbits || !rbits) && wave < 4) {
+    if (!ML && (!sbits || !rbits) && wave < 4) {
         // list-only vectors: wave w stages the stretch of the list that window w of ANY thread of the tile can touch
         // (windows: 0 b[-d-1], 1 b[R-d-1], 2 rho[d], 3 rho[S+d] over the tile's lags D0 .. D0 + RUNS_T - 1)
         const bool of_b = wave < 2;
@@ -578,7 +768,29 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             if (lane == 0) s_ek0[wave] = k0, s_ecnt[wave] = cnt;
         }
     }
+    {
+        uint4* hz = reinterpret_cast<uint4*>(hist);
+        for (int i = tid; i < (RUNS_T / 2 + 4) / 4; i += RUNS_THREADS) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
+    const int wmax = Wt - 2;                      // h is needed for the lags D0 .. D1 - 1
+    const int wlim = wmax >= 0 ? wmax : 0;        // (a one-lag tile never reads h: a stray add at 0 is harmless)
+    int n11p = 0, gp = 0, bsum = 0, rsum_all = 0;
+    bool any_sliced = false;
+    for (int lv = 0; lv < n_lv; ++lv) {  // (one pass unless ML)
+    int wk = 1;  // multiplicity of this level's coincidences
+    if (ML) {
+        if (lv > 0) {
+            __syncthreads();  // every wave is done with the previous level's staged list
+            rr = refs[vr0 + lv];
+            Qe = (GEntries)rr.e;
+            rbits = (GWords)rr.bits;
+            n_q = ((GInts)rr.hdr)[0];
+        }
+        wk = li.m[lv];
+    }
     const bool whole = n_q <= RUNS_QCAP;  // the reference's whole list fits the staging area
+    any_sliced |= !whole;
     // ones of rho in [0, x) = sum_k sgn_k * min(x, Q[k]) (sgn = -1 at run starts, +1 at run ends): the two positions
     // that bound the overlap at lag D0
     const int r_lo = D0 > 0 ? D0 : 0, r_hi = (S + D0) < R ? (S + D0) : R;
@@ -608,15 +820,12 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
         }
     }
-    {
-        uint4* hz = reinterpret_cast<uint4*>(hist);
-        for (int i = tid; i < (RUNS_T / 2 + 4) / 4; i += RUNS_THREADS) hz[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
+    rsum_all += wk * rsum;
     __syncthreads();
 #if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 1
     if (n_q >= 0) return;
 #endif
-    if (!sbits) {
+    if (!ML && !sbits) {
         if (s_ecnt[0] <= RUNS_EDGE && s_ecnt[1] <= RUNS_EDGE) {
             m_in1x = __brev(lds_list_bits32(s_edge[0], s_ek0[0], s_ecnt[0], -dc - 32));
             m_out1x = __brev(lds_list_bits32(s_edge[1], s_ek0[1], s_ecnt[1], (long long)R - dc - 32));
@@ -625,7 +834,7 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             m_out1x = __brev(list_bits32(Pe, n_p, (long long)R - dc - 32));
         }
     }
-    if (!rbits) {
+    if (!ML && !rbits) {
         if (s_ecnt[2] <= RUNS_EDGE && s_ecnt[3] <= RUNS_EDGE) {
             m_outx1 = lds_list_bits32(s_edge[2], s_ek0[2], s_ecnt[2], dc);
             m_inx1 = lds_list_bits32(s_edge[3], s_ek0[3], s_ecnt[3], (long long)S + dc);
@@ -634,10 +843,6 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             m_inx1 = list_bits32(Qe, n_q, (long long)S + dc);
         }
     }
-    const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
-    const int wmax = Wt - 2;                      // h is needed for the lags D0 .. D1 - 1
-    const int wlim = wmax >= 0 ? wmax : 0;        // (a one-lag tile never reads h: a stray add at 0 is harmless)
-    int n11p = 0, gp = 0, bsum = 0;
     // RUNS_TPW wave tasks at a time -- 64 consecutive candidate boundaries each, one per lane, task t of a wave = boundaries
     // r0 + (t * RUNS_WAVES + wave) * 64 + lane -- advanced TOGETHER: every step of the binary searches and of the walks
     // issues the tasks' LDS reads back to back and waits once, so a wave is stalled for one LDS latency per step instead of
@@ -651,7 +856,7 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             valid[t] = i < r1;
             x[t] = valid[t] ? Pe[i].pos + D0 : 0;
             a[t] = lo, b[t] = valid[t] ? hi : lo;  // first k in [lo, hi] with Q(k) >= x
-            sa[t] = (i & 1) ? -1 : 1;              // db[p]
+            sa[t] = ((i & 1) ? -1 : 1) * wk;       // db[p] (times the level's multiplicity)
         }
         for (;;) {
             bool any = false;
@@ -706,9 +911,11 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
                 if (lb[t] & 1) o -= Q.one(lb[t]) - x[t];  // inside a run: the run's ones from x on are not in front of x
                 n11p -= sa[t] * o;
                 gp -= sa[t] * (lb[t] & 1);
-                const int p = x[t] - D0;
-                const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
-                bsum -= sa[t] * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
+                if (!ML || lv == 0) {  // (the candidate's own count: once, without the multiplicity)
+                    const int p = x[t] - D0;
+                    const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
+                    bsum -= (sa[t] < 0 ? -1 : 1) * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
+                }
             }
         }
     };
@@ -743,6 +950,8 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
         else
             tasks(QGlb{Qe, n_q}, r0, r1, 0, n_q);
     }
+    }  // levels
+    int rsum = rsum_all;
 #if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 2
     if (n_q >= 0) return;
 #endif
@@ -752,7 +961,7 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
         wave_incl_scan3(n11p, gp, bsum);
         wave_incl_scan3(rsum, z, z);
     }
-    if (!whole) __syncthreads();  // (s_tmp[0] held the slice bounds)
+    if (any_sliced) __syncthreads();  // (s_tmp[0] held the slice bounds)
     if (lane == 63) s_tmp[0][wave * 4] = n11p, s_tmp[0][wave * 4 + 1] = gp, s_tmp[0][wave * 4 + 2] = bsum, s_tmp[0][wave * 4 + 3] = rsum;
     __syncthreads();  // also: every addition to hist has landed
     int n11_0 = 0, g_0 = 0, n1x_0 = 0, nx1_0 = 0;
@@ -778,6 +987,11 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     constexpr unsigned lpt_mask = RUNS_LPT == 32 ? 0xffffffffu : ((1u << RUNS_LPT) - 1u);
     int d1x = __popc(m_in1x & lpt_mask) - __popc(m_out1x & lpt_mask);
     int dx1 = __popc(m_inx1 & lpt_mask) - __popc(m_outx1 & lpt_mask);
+    if (ML) {
+        dx1 = 0;
+#pragma unroll
+        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) dx1 += wx1g[g4];
+    }
     int hpre = hs;
     block_excl_scan3_dpp<RUNS_WAVES>(hpre, d1x, dx1, s_tmp[1]);  // exclusive prefixes
     const int g_c = g_0 - hpre;  // g at the thread's first lag
@@ -807,16 +1021,24 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     }
 #endif
     const int lim = (Wt - c) < RUNS_LPT ? (Wt - c) : RUNS_LPT;               // lags of this thread inside the tile (<= 0: none)
-    // score(d) = c0 ov + c1x n1x + cx1 nx1 + c11 n11 (two_level_score() multiplied out); fp32 first
-    const float f0 = (float)(cd.s0 * cd.r0), f1x = (float)(cd.r0 * (cd.s1 - cd.s0)), fx1 = (float)(cd.s0 * (cd.r1 - cd.r0)),
-                f11 = (float)((cd.s1 - cd.s0) * (cd.r1 - cd.r0));
+    // score(d) = c0 ov + c1x n1x + cx1 nx1 + c11 n11 (two_level_score() multiplied out; ML: the weighted counts M11 / Mx1
+    // with the coefficients of the LevelInfo comment); fp32 first
+    double k0 = cd.s0 * cd.r0, k1x = cd.r0 * (cd.s1 - cd.s0), kx1 = cd.s0 * (cd.r1 - cd.r0), k11 = (cd.s1 - cd.s0) * (cd.r1 - cd.r0);
+    if (ML) {
+        const double base = 2.0 * li.lam[0] - 1.0, two_q = 2.0 * li.q;
+        k0 = base * cd.s0, k1x = base * (cd.s1 - cd.s0), kx1 = two_q * cd.s0, k11 = two_q * (cd.s1 - cd.s0);
+    }
+    const float f0 = (float)k0, f1x = (float)k1x, fx1 = (float)kx1, f11 = (float)k11;
+    // (ML: the counts are up to LEVELS_MAX_MULT * 3 times a sample count: the same bound on the sums holds with that factor)
+    const float count_max = (float)(R > S ? R : S) * (ML ? (float)(3 * LEVELS_MAX_MULT) : 1.0f);
     // fp32 prefilter.  a(d) = f11 n11(d) + E(d), E = f1x n1x + fx1 nx1 + f0 ov the part that only moves where the
     // overlap's ends pass a sample: |E(d+1) - E(d)| <= |f1x| + |fx1| + |f0| =: step.  E is refreshed every FOUR lags (exact
     // integer counts, one popcount of four mask bits each) and used unchanged for the three lags behind -- at most
     // 3 step off.  |fp32 value - exact| <= 12 roundings of 2^-24 on sums of at most (|k0|+|k1x|+|kx1|+|k11|) max(R, S);
     // a lag whose prefilter value lies within 2 (rounding bound + 3 step) of the block's best may hold the maximum.
     const float estep = fabsf(f1x) + fabsf(fx1) + fabsf(f0);
-    const float margin = 24.0f * 1.1920929e-7f * (estep + fabsf(f11)) * (float)(R > S ? R : S) * 1.01f + 6.0f * estep * 1.01f + 1e-3f;
+    const float estep_w = fabsf(f1x) + (ML ? (float)(3 * LEVELS_MAX_MULT) : 1.0f) * fabsf(fx1) + fabsf(f0);  // (one lag moves Mx1 by up to sum m_k)
+    const float margin = 24.0f * 1.1920929e-7f * (estep + fabsf(f11)) * count_max * 1.01f + 6.0f * estep_w * 1.01f + 1e-3f;
     auto edge32 = [&](int a1x, int ax1, int d) -> float {
         const int j0 = d < 0 ? -d : 0;
         const int j1 = (R - d) < S ? (R - d) : S;
@@ -840,7 +1062,14 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
                 a11 += g;
             }
             a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
-            ax1 += __popc(mix & 15u) - __popc(mox & 15u);
+            if (ML) {
+                int wdelta = 0;
+#pragma unroll
+                for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wdelta = g4 == q4 ? wx1g[g4] : wdelta;
+                ax1 += wdelta;
+            } else {
+                ax1 += __popc(mix & 15u) - __popc(mox & 15u);
+            }
             mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
         }
     }
@@ -874,16 +1103,41 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
                 const int i = 4 * q4 + e;
                 if (i < lim && fmaf(f11, (float)a11, e32) >= thr) {
                     const unsigned low = (1u << e) - 1u;  // the one-sided counts at this lag: e mask bits further
-                    const int b1x = a1x + __popc(mi1 & low) - __popc(mo1 & low), bx1 = ax1 + __popc(mix & low) - __popc(mox & low);
+                    const int b1x = a1x + __popc(mi1 & low) - __popc(mo1 & low);
                     const int d = D0 + c + i;
-                    const double sc = two_level_score(cd, a11, b1x, bx1, d);
+                    double sc;
+                    if (ML) {
+                        int bx1 = ax1;  // (rare: the planes' windows are fetched again for the partial group)
+                        for (int k = 0; k < n_lv; ++k) {
+                            const GWords pb = (GWords)refs[vr0 + k].bits;
+                            const unsigned mo = fetch32(pb, R, dc) >> (4 * q4), mi = fetch32(pb, R, (long long)S + dc) >> (4 * q4);
+                            bx1 += li.m[k] * (__popc(mi & low) - __popc(mo & low));
+                        }
+                        const int j0 = d < 0 ? -d : 0;
+                        const int j1 = (R - d) < S ? (R - d) : S;
+                        const int ov = j1 > j0 ? (j1 - j0) : 0;
+                        sc = (double)ov * k0;
+                        sc = __builtin_fma((double)b1x, k1x, sc);
+                        sc = __builtin_fma((double)bx1, kx1, sc);
+                        sc = __builtin_fma((double)a11, k11, sc);
+                    } else {
+                        const int bx1 = ax1 + __popc(mix & low) - __popc(mox & low);
+                        sc = two_level_score(cd, a11, b1x, bx1, d);
+                    }
                     if (sc >= bs) bs = sc, bd = d;
                 }
                 g -= h[e];
                 a11 += g;
             }
             a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
-            ax1 += __popc(mix & 15u) - __popc(mox & 15u);
+            if (ML) {
+                int wdelta = 0;
+#pragma unroll
+                for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wdelta = g4 == q4 ? wx1g[g4] : wdelta;
+                ax1 += wdelta;
+            } else {
+                ax1 += __popc(mix & 15u) - __popc(mox & 15u);
+            }
             mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
         }
     }
@@ -914,6 +1168,66 @@ __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
             RunsBest& o = best[(size_t)ci * tiles_max + tile];
             o.score = bs, o.d = bd;
         }
+    }
+}
+
+__global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
+    const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
+    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk) {
+    runs_corr_body<false>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, nullptr, 0);
+}
+// multi-level references (threshold lists + LevelInfo); a few more registers: three workgroups per CU
+__global__ __launch_bounds__(RUNS_THREADS, 6) void k_runs_corr_ml(
+    const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
+    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk,
+    const LevelInfo* __restrict__ linfo, int n_vec_all) {
+    runs_corr_body<true>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, linfo, n_vec_all);
+}
+
+// Multi-level flags: sub-batch = 1 when a reference of it is not usable (LevelInfo.ok == 0, a truncated threshold list, a
+// histogram cell that could overflow its 16 bits) or some candidate's coincidences (summed over the threshold lists)
+// exceed the budget.
+__global__ __launch_bounds__(256) void k_runs_chunk_flags_ml(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
+                                                             int pairs_per_chunk, const RunsRef* __restrict__ refs,
+                                                             const LevelInfo* __restrict__ linfo, int n_vec_all, long long budget,
+                                                             int* __restrict__ flags, unsigned long long* __restrict__ stats) {
+    const int ch = blockIdx.x;
+    const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
+    int over = 0;
+    unsigned long long nb = 0;
+    for (int i = p0 * n_cand + (int)threadIdx.x; i < p1 * n_cand; i += 256) {
+        const CandDesc& cd = cands[i];
+        const int pair = i / n_cand, j = i - pair * n_cand;
+        const RunsRef rs = refs[pair * (n_cand + 1) + 1 + j];
+        const LevelInfo li = linfo[pair];
+        const int n_p = ((GInts)rs.hdr)[0];
+        const int cap_p = rs.cap > 0 ? rs.cap : ((GInts)rs.hdr)[3];
+        nb += (unsigned)n_p;
+        if (!li.ok || n_p >= cap_p || n_p >= RUNS_CAP) {
+            over = 1;
+            continue;
+        }
+        long long coinc = 0, cell = 0;
+        for (int k = 0; k < li.n_levels - 1; ++k) {
+            const RunsRef rk = refs[n_vec_all + 3 * pair + k];
+            const int n_q = ((GInts)rk.hdr)[0];
+            if (j == 0) nb += (unsigned)n_q;
+            if (n_q >= rk.cap) over = 1;
+            coinc += (long long)n_p * n_q;
+            cell += (long long)li.m[k] * (n_p < n_q ? n_p : n_q);
+        }
+        if (cell >= 32768) over = 1;  // |h(d)| < 2^15 for the packed histogram
+        if (!(cd.flags & CAND_NO_LAGS) && coinc * ((long long)cd.d_hi - cd.d_lo + 1) / (cd.R > 0 ? cd.R : 1) > budget) over = 1;
+    }
+    over = __syncthreads_or(over);
+    __shared__ unsigned long long s_nb[4];
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) nb += __shfl_xor(nb, s, 64);
+    if ((threadIdx.x & 63) == 0) s_nb[threadIdx.x >> 6] = nb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        flags[ch] = over;
+        atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
     }
 }
 

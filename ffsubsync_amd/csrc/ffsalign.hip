@@ -222,6 +222,8 @@ struct ffs_plan {
     RunsBest* runs_best = nullptr;      // [candidates][tiles] (windows wider than one tile)
     size_t runs_best_n = 0;
     bool runs_prev_fft = false;         // the previous run-boundary call needed the transforms for some sub-batch
+    unsigned* lvl_buf = nullptr;        // threshold planes of a call's multi-level (float) references
+    size_t lvl_bytes = 0;
     hipEvent_t runs_ev = nullptr;
     int64_t runs_calls = 0, runs_fft_chunks = 0, runs_chunks = 0, runs_last_boundaries = 0;  // statistics (ffs_plan_runs_stats)
     // FFS_HOST_TIMING=1: host nanoseconds of the run-boundary calls by section, printed when the plan is destroyed
@@ -1144,6 +1146,7 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->runs_flags);
     (void)hipFree(p->runs_zero_flags);
     (void)hipFree(p->pack_buf);
+    (void)hipFree(p->lvl_buf);
     if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
     if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
     (void)hipFree(p->dev_desc);
@@ -1344,9 +1347,14 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     // Run-boundary path: two-level vectors on both sides, as bits (FFS_DTYPE_U1: their lists are extracted here) or as
     // boundary lists (FFS_DTYPE_RUNS); everything else, and every sub-batch whose lists turn out too long, goes through
     // the transforms.  Its buffers come first: without them (out of memory) an AUTO call on bits still has the transforms.
-    bool runs_ok = p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && runs_able(ref_dt);
-    const bool need_extract = runs_ok && (dtype == FFS_DTYPE_U1 || ref_dt == FFS_DTYPE_U1);
-    if (runs_ok && (rc = ensure_runs(p, need_extract ? n_vec : 0, 0, (size_t)n_chunks))) {
+    // Multi-level float references (the `weighted` fused VAD's four levels, speech_transformers.py:290-293) against
+    // two-level candidates: the reference's threshold planes are made on the device (k_levels_*), their lists extracted,
+    // and the run-boundary kernel adds the levels up (ffs_runs.h, LevelInfo); whatever does not qualify takes the transforms.
+    const bool ml = p->algo != FFS_ALGO_FFT && !p->direct_only && (ref_dt == FFS_DTYPE_F64 || ref_dt == FFS_DTYPE_F32) && runs_able(dtype);
+    bool runs_ok = p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && (runs_able(ref_dt) || ml);
+    const bool need_extract = runs_ok && (ml || dtype == FFS_DTYPE_U1 || ref_dt == FFS_DTYPE_U1);
+    const size_t n_rr = n_vec + (ml ? 3 * (size_t)n_pairs : 0);  // RunsRef entries: every vector, then three threshold planes per pair
+    if (runs_ok && (rc = ensure_runs(p, need_extract ? n_rr : 0, 0, (size_t)n_chunks))) {
         if (lists_in || p->algo != FFS_ALGO_AUTO) return rc;
         runs_ok = false;  // FFS_ALGO_AUTO: "only the time differs" -- the transforms need no list buffers
     }
@@ -1356,8 +1364,15 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     // descriptor block layout: [PoolHeader][CandDesc n_cands][RunsRef n_vec][XformDesc n_xf][NomList n_cands][RescoreAcc n_cands*KNOM]
     const size_t o_pool = 0;  // PoolHeader (uploaded: count = 0, capacity)
     const size_t o_cand = 64;
-    const size_t o_rv = o_cand + n_cands * sizeof(CandDesc);  // RunsRef[n_vec] when runs_ok
-    const size_t o_xf = (o_rv + (runs_ok ? n_vec * sizeof(RunsRef) : 0) + 63) & ~(size_t)63;
+    const size_t o_rv = o_cand + n_cands * sizeof(CandDesc);  // RunsRef[n_rr] when runs_ok
+    // multi-level tables behind it: LevelInfo | sample pointers | plane pointers | lengths | plane words, one per pair
+    const size_t o_li = (o_rv + (runs_ok ? n_rr * sizeof(RunsRef) : 0) + 63) & ~(size_t)63;
+    const bool ml_on = runs_ok && ml;
+    const size_t o_mp = o_li + (ml_on ? (size_t)n_pairs * sizeof(LevelInfo) : 0);
+    const size_t o_mq = o_mp + (ml_on ? (size_t)n_pairs * 8 : 0);
+    const size_t o_ml = o_mq + (ml_on ? (size_t)n_pairs * 8 : 0);
+    const size_t o_mw = o_ml + (ml_on ? (size_t)n_pairs * 4 : 0);
+    const size_t o_xf = (o_mw + (ml_on ? (size_t)n_pairs * 4 : 0) + 63) & ~(size_t)63;
     const size_t host_bytes_max = o_xf + (n_xf_alloc > n_xf ? n_xf_alloc : n_xf) * sizeof(XformDesc);
     const size_t o_nom = (host_bytes_max + 255) & ~(size_t)255;
     const size_t o_acc = o_nom + n_cands * sizeof(NomList);
@@ -1386,10 +1401,69 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             const int dt = (i % stride) ? dtype : ref_dt;
             if (dt == FFS_DTYPE_RUNS)  // caller-owned block: 16-byte header (n, ones, len, capacity), then the entries
                 hrv[i] = RunsRef{(const int2*)((const char*)vec_ptr[i] + 16), (const int2*)vec_ptr[i], nullptr, (int32_t)vec_len[i], 0};
-            else
+            else if (dt == FFS_DTYPE_U1)
                 hrv[i] = RunsRef{p->runs_e + i * RUNS_CAP, p->runs_n + i, (const unsigned*)vec_ptr[i], (int32_t)vec_len[i], RUNS_CAP};
+            else  // a multi-level reference: its threshold planes follow the vectors
+                hrv[i] = RunsRef{nullptr, p->runs_n + i, nullptr, (int32_t)vec_len[i], RUNS_CAP};
         }
-        if (need_extract) {
+        if (ml_on) {
+            std::vector<size_t> poff((size_t)n_pairs + 1, 0);
+            int64_t len_max = 1;
+            for (int pi = 0; pi < n_pairs; ++pi) {
+                const size_t pw = (size_t)(vec_len[(size_t)pi * stride] + 31) / 32;
+                poff[pi + 1] = poff[pi] + ((3 * pw * 4 + 63) & ~(size_t)63);
+                if (vec_len[(size_t)pi * stride] > len_max) len_max = vec_len[(size_t)pi * stride];
+            }
+            if (poff[n_pairs] > p->lvl_bytes) {
+                if (p->has_last) HIP_TRY(hipEventSynchronize(p->last_done));
+                (void)hipFree(p->lvl_buf);
+                p->lvl_buf = nullptr;
+                p->lvl_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&p->lvl_buf, poff[n_pairs] + poff[n_pairs] / 4));
+                p->lvl_bytes = poff[n_pairs] + poff[n_pairs] / 4;
+            }
+            const void** h_vp = (const void**)(hb + o_mp);
+            unsigned** h_pp = (unsigned**)(hb + o_mq);
+            int32_t* h_len = (int32_t*)(hb + o_ml);
+            int32_t* h_pw = (int32_t*)(hb + o_mw);
+            for (int pi = 0; pi < n_pairs; ++pi) {
+                const size_t b = (size_t)pi * stride;
+                const int32_t pw = (int32_t)((vec_len[b] + 31) / 32);
+                unsigned* planes = (unsigned*)((char*)p->lvl_buf + poff[pi]);
+                h_vp[pi] = vec_ptr[b];
+                h_pp[pi] = planes;
+                h_len[pi] = (int32_t)vec_len[b];
+                h_pw[pi] = pw;
+                for (int k = 0; k < 3; ++k) {
+                    const size_t r = n_vec + 3 * (size_t)pi + k;
+                    hrv[r] = RunsRef{p->runs_e + r * RUNS_CAP, p->runs_n + r, planes + (size_t)k * pw, (int32_t)vec_len[b], RUNS_CAP};
+                }
+            }
+            HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, o_xf - o_rv, hipMemcpyHostToDevice, st));
+            leave.armed = true;
+            LevelInfo* d_li = (LevelInfo*)(db + o_li);
+            const unsigned chunks = (unsigned)((len_max + 16383) / 16384);
+            {
+            ProfSpan lspan(p, st, FFS_K_LEVELS);
+            if (ref_dt == FFS_DTYPE_F64) {
+                hipLaunchKernelGGL((k_levels_sample<double>), dim3((unsigned)n_pairs), dim3(256), 0, st, (const double* const*)(db + o_mp),
+                                   (const int*)(db + o_ml), d_li);
+                hipLaunchKernelGGL((k_levels_bits<double>), dim3(chunks, (unsigned)n_pairs), dim3(256), 0, st, (const double* const*)(db + o_mp),
+                                   (const int*)(db + o_ml), d_li, (unsigned* const*)(db + o_mq), (const int*)(db + o_mw));
+            } else {
+                hipLaunchKernelGGL((k_levels_sample<float>), dim3((unsigned)n_pairs), dim3(256), 0, st, (const float* const*)(db + o_mp),
+                                   (const int*)(db + o_ml), d_li);
+                hipLaunchKernelGGL((k_levels_bits<float>), dim3(chunks, (unsigned)n_pairs), dim3(256), 0, st, (const float* const*)(db + o_mp),
+                                   (const int*)(db + o_ml), d_li, (unsigned* const*)(db + o_mq), (const int*)(db + o_mw));
+            }
+            }
+            HIP_TRY(hipGetLastError());
+            {
+                ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
+                hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_rr), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
+            }
+            HIP_TRY(hipGetLastError());
+        } else if (need_extract) {
             HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
             leave.armed = true;
             // A stream of dense calls (the previous one needed the transforms): sample the vectors first -- when the
@@ -1533,7 +1607,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     // one upload when the transforms run anyway; with the run-boundary path [header, candidates] (+ the vector table
     // when no extraction was launched ahead of it)
     if (runs_ok && !need_extract)
-        HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_rr * sizeof(RunsRef), hipMemcpyHostToDevice, st));
     else
         HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
     leave.armed = true;
@@ -1560,7 +1634,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         // records written by the kernel itself; which sub-batches need the transforms instead is decided on the device
         // (k_runs_chunk_flags) and read back as one int per sub-batch -- after everything else of the call is queued
         if (runs_ok) {
-            if ((rc = ensure_runs(p, need_extract ? n_vec : 0, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0, (size_t)n_chunks)))
+            if ((rc = ensure_runs(p, need_extract ? n_rr : 0, tiles_max > 1 ? n_cands * (size_t)tiles_max : 0, (size_t)n_chunks)))
                 return rc;
             const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4
                                      : p->runs_budget >= 0 ? p->runs_budget
@@ -1614,6 +1688,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             } else {
             if (!proven) {
                 HIP_TRY(hipMemsetAsync(d_stats, 0, 8, st));
+                if (ml_on)
+                    hipLaunchKernelGGL(k_runs_chunk_flags_ml, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
+                                       p->pairs_in_flight, (const RunsRef*)(db + o_rv), (const LevelInfo*)(db + o_li), (int)n_vec, budget,
+                                       p->runs_flags, d_stats);
+                else
                 hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
                                    (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 0);
                 HIP_TRY(hipGetLastError());
@@ -1622,6 +1701,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             }
             {
                 ProfSpan span(p, st, FFS_K_RUNS_CORR);
+                if (ml_on)
+                    hipLaunchKernelGGL(k_runs_corr_ml, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st, dc, n_cand,
+                                       (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight,
+                                       (const LevelInfo*)(db + o_li), (int)n_vec);
+                else
                 hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st, dc, n_cand,
                                    (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight);
                 if (tiles_max > 1)

@@ -366,7 +366,8 @@ int ffs_comm_destroy(ffs_comm* comm);
 #define FFS_K_RESCORE 4  /* exact re-evaluation of nominee lags                     */
 #define FFS_K_RUNS_EXTRACT 5 /* run-boundary path: boundary lists of every vector (reads the bit-packed vectors) */
 #define FFS_K_RUNS_CORR 6    /* run-boundary path: exact correlation over the lag window + argmax           */
-#define FFS_K_COUNT 7
+#define FFS_K_LEVELS 7       /* multi-level float references: level detection + threshold planes (reads the float vectors) */
+#define FFS_K_COUNT 8
 int ffs_plan_profile(ffs_plan* plan, int enable);
 /* Synchronises the recorded events, adds their durations to ms_total[FFS_K_COUNT] /
  * launches[FFS_K_COUNT] (caller-zeroed or accumulating) and clears the recording. */
