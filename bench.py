@@ -271,12 +271,14 @@ def vad_figures(torch, _native, minutes=90.0, iters=20):
     # the rocprofv3 record of the same kernel on the same workload (profiles/secondary_kernels.py under --kernel-trace and
     # --pmc FETCH_SIZE / WRITE_SIZE; refreshed by profiles/refresh_all.sh): duration, HBM bytes measured vs algorithmic
     rocprof = None
-    spath = os.path.join(ROOT, "profiles", "r04_secondary_kernels.json")
+    spath = os.path.join(ROOT, "profiles", "r05_secondary_kernels.json")
+    if not os.path.exists(spath):
+        spath = os.path.join(ROOT, "profiles", "r04_secondary_kernels.json")
     if os.path.exists(spath):
         sj = json.load(open(spath))
         rocprof = {k: {kk: v[kk] for kk in ("avg_us", "achieved_GBps", "frac_of_8TBps", "pmc_hbm_bytes_per_launch", "pmc_over_algorithmic")
                        if kk in v} for k, v in sj.items() if k.startswith("k_vad_energy")}
-        rocprof["source"] = "profiles/r04_secondary_kernels.json (rocprofv3 --kernel-trace --stats + --pmc FETCH_SIZE / WRITE_SIZE)"
+        rocprof["source"] = "profiles/%s (rocprofv3 --kernel-trace --stats + --pmc FETCH_SIZE / WRITE_SIZE)" % os.path.basename(spath)
     return {
         "roofline": {"kernel": "k_vad_energy", "bound": "hbm", "achieved": bytes_ / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": bytes_ / (ms * 1e-3) / HBM_PEAK, "bytes_per_launch": bytes_, "avg_launch_ms": ms,
