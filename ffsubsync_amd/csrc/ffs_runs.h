@@ -746,6 +746,10 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4)
                 wx1g[g4] += li.m[k] * (__popc((mi >> (4 * g4)) & 15u) - __popc((mo >> (4 * g4)) & 15u));
         }
+        if (!sbits) {  // a list-only candidate against a multi-level reference: its windows straight from the list
+            m_in1x = __brev(list_bits32(Pe, n_p, -dc - 32));
+            m_out1x = __brev(list_bits32(Pe, n_p, (long long)R - dc - 32));
+        }
     } else if (rbits) {
         m_outx1 = fetch32(rbits, R, dc);
         m_inx1 = fetch32(rbits, R, (long long)S + dc);

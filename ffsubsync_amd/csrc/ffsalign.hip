@@ -1304,8 +1304,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     {
         // The plan-owned boundary lists take 256 KiB per vector: a call with more than 65 536 vectors of bit-packed
         // two-level samples is solved as consecutive sub-calls (results land where one call would put them).
-        const int64_t max_pairs = (int64_t(1) << 16) / stride > 0 ? (int64_t(1) << 16) / stride : 1;
-        if (p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && runs_able(ref_dt) && n_pairs > max_pairs) {
+        // (a multi-level float reference brings three threshold planes of its own)
+        const bool ml_split = (ref_dt == FFS_DTYPE_F64 || ref_dt == FFS_DTYPE_F32) && runs_able(dtype);
+        const int64_t per_pair = stride + (ml_split ? 3 : 0);
+        const int64_t max_pairs = (int64_t(1) << 16) / per_pair > 0 ? (int64_t(1) << 16) / per_pair : 1;
+        if (p->algo != FFS_ALGO_FFT && !p->direct_only && runs_able(dtype) && (runs_able(ref_dt) || ml_split) && n_pairs > max_pairs) {
             for (int64_t p0 = 0; p0 < n_pairs; p0 += max_pairs) {
                 const int np = (int)((n_pairs - p0) < max_pairs ? (n_pairs - p0) : max_pairs);
                 const int rc_sub = align_impl(p, np, n_cand, ref_dt, dtype, vec_ptr + p0 * stride, vec_len + p0 * stride,

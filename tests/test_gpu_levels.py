@@ -182,3 +182,33 @@ def test_level_sets_that_fall_back_to_the_transforms(case):
     assert np.array_equal(got[0]["offset"], want[0]["offset"])
     assert np.array_equal(got[0]["score"][:2], want[0]["score"][:2])  # the sub-batch the transforms solved: their very records
     assert np.allclose(got[0]["score"], want[0]["score"], rtol=1e-9, atol=1e-6)
+
+
+def test_multi_level_reference_against_list_candidates():
+    """Roles of three kinds in one call: float64 four-level references, candidates as boundary lists (FFS_DTYPE_RUNS) --
+    the candidate's edge windows come from its list; records as with bit-packed candidates."""
+    import torch
+
+    from ffsubsync_amd import _native, batch
+    from workloads import synth
+
+    specs = [synth.make_pair_spec(g["seed"]) for g in GOLD[:6]]
+    db = synth.build_fused_batch(specs)
+    n_fft = db.required_fft_length(6000)
+    want, _ = _solve(db, n_fft, 6000, "auto")
+    # the candidates' lists: convert the bit-packed candidate vectors, keep the float references where they are
+    cand_bits = batch.DeviceBatch(db.data, db.offs[:, 1:], db.lens[:, 1:], db.lo[:, 1:], db.hi[:, 1:], _native.FFS_DTYPE_U1)
+    two = batch.DeviceBatch(db.data, np.concatenate([db.offs[:, 1:2], db.offs[:, 1:]], axis=1),
+                            np.concatenate([db.lens[:, 1:2], db.lens[:, 1:]], axis=1), np.concatenate([db.lo[:, 1:2], db.lo[:, 1:]], axis=1),
+                            np.concatenate([db.hi[:, 1:2], db.hi[:, 1:]], axis=1), _native.FFS_DTYPE_U1)
+    lists = two.to_runs(cap=8192)  # (column 0 is a throw-away copy of candidate 0: to_runs converts whole batches)
+    base = (db.data.numel() + 63) // 64 * 64
+    pad = base - db.data.numel()
+    data = torch.cat([db.data, torch.zeros(pad, dtype=torch.uint8, device=db.data.device), lists.data])
+    offs = np.concatenate([db.offs[:, :1], lists.offs[:, 1:] + base], axis=1)
+    mixed = batch.DeviceBatch(data, offs, db.lens, db.lo, db.hi, _native.FFS_DTYPE_RUNS, ref_dtype=_native.FFS_DTYPE_F64)
+    got, st = _solve(mixed, n_fft, 6000, "auto")
+    assert st[0] == 1 and st[2] == 0, st
+    for f in ("score", "offset", "flags"):
+        assert np.array_equal(got[0][f], want[0][f]), f
+    assert np.array_equal(got[1], want[1])
