@@ -366,9 +366,12 @@ FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
     a = pa, b = pb, c = pc;
 }
 
-// One workgroup per sub-batch (pairs_per_chunk pairs): flags[chunk] = 1 when some candidate of it is over budget (the
-// whole sub-batch then goes through the transforms and k_runs_corr leaves it alone), 2 when a list-only vector of it is
-// truncated (nothing can solve it: the host reports the error).  stats[0] += boundaries of the sub-batch's vectors.
+// RUNS_FLAG_SPLIT workgroups per sub-batch (pairs_per_chunk pairs; grid = (sub-batches, RUNS_FLAG_SPLIT), flags zeroed by the
+// caller): flags[chunk] = 1 when some candidate of it is over budget (the whole sub-batch then goes through the transforms
+// and k_runs_corr leaves it alone), 2 when a list-only vector of it is truncated (nothing can solve it: the host reports
+// the error).  stats[0] += boundaries of the sub-batch's vectors.  (One workgroup per sub-batch took 32 us for 512 x 7
+// candidates -- three dependent global loads per candidate -- on the stream between the extraction and k_runs_corr.)
+constexpr int RUNS_FLAG_SPLIT = 8;
 __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
                                                           int pairs_per_chunk, const RunsRef* __restrict__ refs, long long budget,
                                                           int* __restrict__ flags, unsigned long long* __restrict__ stats,
@@ -377,7 +380,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
     const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
     int over = 0, bad = 0;
     unsigned long long nb = 0;
-    for (int i = p0 * n_cand + (int)threadIdx.x; i < p1 * n_cand; i += 256) {
+    for (int i = p0 * n_cand + (int)(blockIdx.y * 256 + threadIdx.x); i < p1 * n_cand; i += 256 * RUNS_FLAG_SPLIT) {
         const CandDesc& cd = cands[i];
         const int pair = i / n_cand, j = i - pair * n_cand;
         const int vr = pair * (n_cand + 1), vs = vr + 1 + j;
@@ -391,7 +394,10 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
         nb += (unsigned)n_p + (j == 0 ? (unsigned)n_q : 0u);
         bad |= (!rs.bits && n_p >= cap_p) || (!rr.bits && n_q >= cap_q);
         if (cd.flags & CAND_NO_LAGS) continue;
-        over |= runs_over_budget(n_p, n_q, cap_p, cap_q, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget) ? 1 : 0;
+        // (16-bit histogram cells: lists of 32 768 entries or more never take the run-boundary kernel, whoever owns them)
+        const int lim_q = (estimates && rr.bits) ? cap_q : (cap_q < RUNS_CAP ? cap_q : RUNS_CAP);
+        const int lim_p = (estimates && rs.bits) ? cap_p : (cap_p < RUNS_CAP ? cap_p : RUNS_CAP);
+        over |= runs_over_budget(n_p, n_q, lim_p, lim_q, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget) ? 1 : 0;
     }
     over = __syncthreads_or(over);
     bad = __syncthreads_or(bad);
@@ -401,7 +407,8 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
     if ((threadIdx.x & 63) == 0) s_nb[threadIdx.x >> 6] = nb;
     __syncthreads();
     if (threadIdx.x == 0) {
-        flags[ch] = bad ? 2 : over;
+        const int f = bad ? 2 : over;
+        if (f) atomicMax(&flags[ch], f);
         if (!estimates) atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
     }
 }

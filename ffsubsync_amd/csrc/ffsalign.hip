@@ -1663,8 +1663,9 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             if (probe_first) {
                 // flags from the ESTIMATED counts against the budget (the estimate's sampling error is a few per cent of a
                 // count whose square enters: a sub-batch within that of the break-even costs the same either way)
-                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
-                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 1);
+                HIP_TRY(hipMemsetAsync(p->runs_flags, 0, flag_bytes, st));
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, RUNS_FLAG_SPLIT), dim3(256), 0, st, dc, n_pairs, n_cand,
+                                   p->pairs_in_flight, (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 1);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(p->runs_ev, st));
@@ -1690,14 +1691,14 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 HIP_TRY(hipEventRecord(p->upload_done, st));
             } else {
             if (!proven) {
-                HIP_TRY(hipMemsetAsync(d_stats, 0, 8, st));
+                HIP_TRY(hipMemsetAsync(p->runs_flags, 0, flag_bytes, st));  // (flags + the boundary counter behind them)
                 if (ml_on)
                     hipLaunchKernelGGL(k_runs_chunk_flags_ml, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
                                        p->pairs_in_flight, (const RunsRef*)(db + o_rv), (const LevelInfo*)(db + o_li), (int)n_vec, budget,
                                        p->runs_flags, d_stats);
                 else
-                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand, p->pairs_in_flight,
-                                   (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 0);
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, RUNS_FLAG_SPLIT), dim3(256), 0, st, dc, n_pairs, n_cand,
+                                   p->pairs_in_flight, (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipEventRecord(p->runs_ev, st));
