@@ -681,6 +681,8 @@ FFS_DEV unsigned lds_list_bits32(const int* ent, int k0, int cnt, long long star
 //      block's best fp32 value are re-evaluated with exact_score()'s fp64 expression; block argmax over those, ties to the
 //      largest lag;
 //   5. the winning thread writes the candidate's record.
+// (FFS_RUNS_STOP=n, never defined in the product build: section stop points for the A/B harness profiles/runs_ab.sh --
+// the kernel returns early with WRONG results so that the sections' shares of its time can be read off.)
 constexpr int RUNS_EDGE = 96;  // list entries staged per edge window stretch (denser: read from global memory)
 #ifndef FFS_RUNS_WPS
 #define FFS_RUNS_WPS 8

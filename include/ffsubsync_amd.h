@@ -188,7 +188,11 @@ int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, 
  *     whose expected number of boundary coincidences inside its lag window (boundaries of the candidate x boundaries of
  *     the reference x window lags / reference length) exceeds the budget -- by default eight per point of the plan's
  *     transform length and packed transform slot the candidate occupies, (n_cand + 1) / (2 n_cand) of one: the measured
- *     break-even -- are solved by the transforms instead.  Every other element type goes through the transforms.
+ *     break-even -- are solved by the transforms instead.  A FLOAT reference (FFS_DTYPE_F32 / F64) with at most four
+ *     distinct sample values whose steps are small integer multiples of one quantum -- the `weighted` fused VAD's
+ *     {l, .4 + .6 l, .6 + .4 l, 1}, speech_transformers.py:290-293 -- against two-level candidates takes the same path:
+ *     its threshold vectors are made on the device and their coincidences added with integer multiplicities; any other
+ *     float vector (more levels, no common quantum, noise) and every other element type go through the transforms.
  *   FFS_ALGO_FFT: transforms only (the path of rounds 1-3).
  *   FFS_ALGO_RUNS: like AUTO without the coincidence budget (truncated boundary lists still fall back).
  * Environment: FFS_ALGORITHM=auto|fft|runs presets new plans, FFS_RUNS_BUDGET=<coincidences> the budget. */

@@ -348,3 +348,40 @@ def test_two_level_pack_equals_the_numpy_detection():
     # strings and integer lists still come through (aligners.py:51-57)
     v = _Vec("0110")
     assert v.two_level and (v.lo, v.hi) == (0.0, 1.0) and v.packed[0] == 0b0110
+
+
+def test_algorithm_names_are_validated_and_explicit_choices_stick(monkeypatch):
+    """FFS_ALGORITHM is validated (case and blanks ignored, unknown values a clear ValueError instead of a
+    ctypes ArgumentError), and `algorithm_code` accepts names and FFS_ALGO_* codes only."""
+    from ffsubsync_amd import _native
+
+    assert _native.algorithm_code(" FFT ") == _native.FFS_ALGO_FFT and _native.algorithm_code("runs") == _native.FFS_ALGO_RUNS
+    assert _native.algorithm_code(_native.FFS_ALGO_AUTO) == _native.FFS_ALGO_AUTO
+    for bad in ("fast", 7, None, 1.5):
+        with pytest.raises(ValueError):
+            _native.algorithm_code(bad)
+    monkeypatch.delenv("FFS_ALGORITHM", raising=False)
+    assert _native.env_algorithm() == "auto"
+    monkeypatch.setenv("FFS_ALGORITHM", " Runs")
+    assert _native.env_algorithm() == "runs"
+    monkeypatch.setenv("FFS_ALGORITHM", "quick")
+    with pytest.raises(ValueError, match="FFS_ALGORITHM"):
+        _native.env_algorithm()
+
+
+def test_device_copy_cache_key_sees_every_in_place_edit():
+    """the cache key of a fitted vector's device copy is a checksum of ALL its bytes: zeroing ten seconds of a
+    two-hour vector (which 64 strided probes miss nine times out of ten) changes it; equal content under another object
+    identity does not."""
+    from ffsubsync_amd import subtitle_raster as sr
+
+    rng = np.random.RandomState(0)
+    x = (rng.rand(720_000) < 0.4).astype(np.float64)
+    k0 = sr._vector_key(x)
+    assert sr._vector_key(x.copy()) == k0
+    for start in rng.randint(0, 719_000, 20):
+        y = x.copy()
+        y[start:start + 1000] = 1.0 - y[start:start + 1000]
+        assert sr._vector_key(y) != k0
+    assert sr._vector_key(x.astype(np.float32)) != k0 and sr._vector_key(x.reshape(2, -1)) != k0
+    assert sr._vector_key(np.zeros(0)) is None and sr._vector_key([1.0, 0.0]) is None
