@@ -494,26 +494,27 @@ __global__ __launch_bounds__(256) void k_levels_sample(const T* const* __restric
     typedef const __attribute__((address_space(1))) T* GT;
     const GT x = (GT)vec[v];
     const int n = len[v];
-    double vals[5];
+    double vals[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     int cnt = 0;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const long long k = ((long long)(u * 256 + tid) * n) / 2048;
         if (k < n) levels_insert(vals, cnt, x[k]);
     }
-    // merge: lane 0 of every wave collects its lanes' values, thread 0 the four waves'
+    // merge: six butterfly steps leave the wave's distinct values in every lane, thread 0 merges the four waves'
     __shared__ double s_v[4][5];
     __shared__ int s_n[4];
-    double wv[5];
-    int wn = 0;
-    for (int l = 0; l < 64; ++l) {
-        const int cn = __shfl(cnt, l, 64);
+    for (int s = 1; s < 64; s <<= 1) {
+        const int cn = __shfl_xor(cnt, s, 64);
+        double pv[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const double d = __shfl(vals[i], l, 64);
-            if (i < cn) levels_insert(wv, wn, d);
-        }
+        for (int i = 0; i < 5; ++i) pv[i] = __shfl_xor(vals[i], s, 64);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            if (i < cn) levels_insert(vals, cnt, pv[i]);
     }
+    double (&wv)[5] = vals;
+    const int wn = cnt;
     if (lane == 0) {
         s_n[wave] = wn;
 #pragma unroll
@@ -565,6 +566,20 @@ __global__ __launch_bounds__(256) void k_levels_sample(const T* const* __restric
 // Threshold planes of a multi-level vector: plane k (k = 0 .. 2) bit i = [x[i] >= lam[k + 1]] (all zero for k >= L - 1),
 // `plane_words` 32-bit words apart.  grid = (chunks of 16 384 samples, vectors); a wave turns 64 samples into two words per
 // plane with a ballot.  A sample that equals none of the levels clears info->ok (the vector then takes the transforms).
+// (s_bitreplicate_b64_b32: every bit of a 32-bit scalar twice -- with the masks below two lane masks interleave into the
+// sample order of lanes that hold two consecutive samples each)
+FFS_DEV unsigned long long levels_interleave(unsigned even, unsigned odd) {
+    unsigned long long re, ro;
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(re) : "s"(even));
+    asm("s_bitreplicate_b64_b32 %0, %1" : "=s"(ro) : "s"(odd));
+    return (re & 0x5555555555555555ull) | (ro & 0xaaaaaaaaaaaaaaaaull);
+}
+
+// Threshold planes of a multi-level vector: plane k (k = 0 .. 2) bit i = [x[i] >= lam[k + 1]] (all zero for k >= L - 1),
+// `plane_words` 32-bit words apart.  grid = (chunks of 16 384 samples, vectors).  A lane holds TWO consecutive samples (one
+// 16-byte load for float64), a wave step covers 128: the compares' lane masks ARE the ballots, two of them interleave into
+// four words per plane on the scalar unit, lanes 0-3 store them.  A sample that equals none of the levels clears
+// info->ok (the vector then takes the transforms).
 template <class T>
 __global__ __launch_bounds__(256) void k_levels_bits(const T* const* __restrict__ vec, const int* __restrict__ len,
                                                      LevelInfo* __restrict__ info, unsigned* const* __restrict__ planes,
@@ -575,44 +590,51 @@ __global__ __launch_bounds__(256) void k_levels_bits(const T* const* __restrict_
     if (c0 >= n) return;
     const LevelInfo li = info[v];
     if (!li.ok) return;
+    typedef T T2 __attribute__((ext_vector_type(2), aligned(sizeof(T))));
+    typedef const __attribute__((address_space(1))) T2* GT2;
     typedef const __attribute__((address_space(1))) T* GT;
     const GT x = (GT)vec[v];
-    unsigned* out = planes[v];
+    __attribute__((address_space(1))) unsigned* out = (__attribute__((address_space(1))) unsigned*)planes[v];
     const int pw = plane_words[v];
-    bool bad = false;
-    // eight wave-steps of 64 samples at a time: their loads are issued together (one 8-byte load per lane and step would
-    // leave the sweep latency-bound), then classified and turned into words by ballots
-    constexpr int LU = 8;
-    for (int it = 0; it < 64; it += LU) {
-        const long long base0 = c0 + (long long)(it * 4 + wave * LU) * 64;  // this wave's LU consecutive steps
+    const double nan = __builtin_nan("");
+    const double l0 = li.lam[0], l1 = li.lam[1], l2 = li.n_levels > 2 ? li.lam[2] : nan, l3 = li.n_levels > 3 ? li.lam[3] : nan;
+    unsigned long long unknown = 0;  // lane mask: a sample of this lane matched no level
+    constexpr int LU = 8;  // wave steps whose loads are in flight together (4 and 16: the same time)
+    for (int it = 0; it < 128; it += 4 * LU) {
+        const long long base0 = c0 + (long long)(it + wave * LU) * 128;  // this wave's LU consecutive steps
         if (base0 >= n) break;
-        T xv[LU];
+        T2 xv[LU];
+        if (base0 + (long long)LU * 128 <= n) {  // (wave-uniform) all of it inside the vector: plain loads, all in flight
 #pragma unroll
-        for (int u = 0; u < LU; ++u) {
-            const long long i = base0 + u * 64 + lane;
-            xv[u] = i < n ? __builtin_nontemporal_load(x + i) : (T)li.lam[0];
+            for (int u = 0; u < LU; ++u) xv[u] = __builtin_nontemporal_load((GT2)(x + base0 + u * 128 + 2 * lane));
+        } else {
+#pragma unroll
+            for (int u = 0; u < LU; ++u) {
+                const long long i = base0 + u * 128 + 2 * lane;
+                xv[u].x = i < n ? x[i] : (T)l0;
+                xv[u].y = i + 1 < n ? x[i + 1] : (T)l0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < LU; ++u) {
-            const long long base = base0 + u * 64;
-            const double d = (double)xv[u];
-            int idx = -1;
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (k < li.n_levels && d == li.lam[k]) idx = k;
-            bad |= idx < 0;
-            if (base + lane >= n) idx = 0;
+            const long long base = base0 + u * 128;
+            const double da = (double)xv[u].x, db = (double)xv[u].y;
+            unknown |= ~(__ballot(da == l0 || da == l1 || da == l2 || da == l3) & __ballot(db == l0 || db == l1 || db == l2 || db == l3));
+            const double lk[3] = {l1, l2, l3};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const unsigned long long bal = __ballot(idx >= k + 1);
-                if (lane < 2 && base < n) {
-                    const long long w = (base >> 5) + lane;
-                    if (w < pw) out[(size_t)k * pw + w] = lane ? (unsigned)(bal >> 32) : (unsigned)bal;
+                const unsigned long long ea = __ballot(da >= lk[k]), eb = __ballot(db >= lk[k]);
+                const unsigned long long w01 = levels_interleave((unsigned)ea, (unsigned)eb);
+                const unsigned long long w23 = levels_interleave((unsigned)(ea >> 32), (unsigned)(eb >> 32));
+                const long long w = (base >> 5) + lane;
+                if (lane < 4 && w < pw) {  // (pw = words of the vector: nothing behind its end)
+                    const unsigned long long ww = (lane & 2) ? w23 : w01;
+                    out[(size_t)k * pw + w] = (lane & 1) ? (unsigned)(ww >> 32) : (unsigned)ww;
                 }
             }
         }
     }
-    if (__syncthreads_or(bad ? 1 : 0) && tid == 0) info[v].ok = 0;
+    if (__syncthreads_or(unknown != 0 ? 1 : 0) && tid == 0) info[v].ok = 0;
 }
 
 // inclusive prefix sum over the 64 lanes of three ints at once, DPP only (no LDS round trips)
