@@ -402,8 +402,10 @@ def e2e_figures(torch, _native, n_files, minutes=90.0, cpu_files=4):
 def drop_in_figures(torch, specs, n=12):
     """One seven-ratio 2 h solve at a time THROUGH THE DROP-IN CLASSES (the seam ffsubsync.py:230-235 calls):
     MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(ref, candidates) -- (i) from host float64 arrays, what an
-    unpatched pipeline hands over; (ii) from the bit-packed device rasters that install(device_rasters=True) leaves
-    in HBM (DeviceSubtitleSpeechTransformer outputs + the cached device copy of the reference vector)."""
+    unpatched pipeline hands over; (ii) from the device rasters that install(device_rasters=True) leaves in HBM
+    (DeviceSubtitleSpeechTransformer outputs + the cached device copy of the reference vector): bit-packed samples AND,
+    since round 5, their boundary lists with host-known length bounds -- the solve extracts nothing and does not wait
+    for the device before it returns."""
     import numpy as np
 
     from ffsubsync_amd import _native

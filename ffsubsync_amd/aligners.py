@@ -160,10 +160,22 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
     role_two_level = [all(v.two_level for v in vecs[0::stride]),
                       all(v.two_level for i, v in enumerate(vecs) if i % stride)]
     lens = np.array([len(v) for v in vecs], dtype=np.int64)
+    # A role whose vectors all carry their boundary list (DeviceRaster.runs: straight from the subtitle intervals, or
+    # extracted once when the reference vector was uploaded) goes over as lists (FFS_DTYPE_RUNS) with the lists'
+    # host-known length bounds: no pass over the bits, and the call does not wait for the device before it returns.
+    role_lists = [all(v.raster is not None and getattr(v.raster, "runs", None) is not None for v in vecs[0::stride]),
+                  all(v.raster is not None and getattr(v.raster, "runs", None) is not None
+                      for i, v in enumerate(vecs) if i % stride)]
+    bounds = np.zeros(len(vecs), dtype=np.int32)
     keep_alive = []  # device tensors the descriptors point into
     chunks = []
     for i, v in enumerate(vecs):
-        if role_two_level[1 if i % stride else 0]:
+        if role_lists[1 if i % stride else 0]:
+            v.dev = v.raster.runs
+            bounds[i] = v.raster.runs_bound
+            keep_alive.append(v.dev)
+            chunks.append(None)
+        elif role_two_level[1 if i % stride else 0]:
             # bit-packed (FFS_DTYPE_U1): host vectors are packed here, rasters that live in HBM as bytes are packed on
             # the device, bit-packed rasters are used in place
             if v.raster is not None:
@@ -176,8 +188,9 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
             # float inputs (fused / weighted VAD levels) go over as float64: the transforms nominate in fp32, the
             # winning lags are re-evaluated in fp64 from these very samples (no input rounding)
             chunks.append(np.ascontiguousarray(v.host_values(), dtype=np.float64).view(np.uint8))
-    role_dtype = [_native.FFS_DTYPE_U1 if t else _native.FFS_DTYPE_F64 for t in role_two_level]
-    dtype = role_dtype[0] if role_dtype[0] == role_dtype[1] else (role_dtype[0], role_dtype[1])
+    role_dtype = [_native.FFS_DTYPE_RUNS if l else (_native.FFS_DTYPE_U1 if t else _native.FFS_DTYPE_F64)
+                  for l, t in zip(role_lists, role_two_level)]
+    dtype = role_dtype[0] if role_dtype[0] == role_dtype[1] and not any(role_lists) else (role_dtype[0], role_dtype[1])
     # one H2D copy: host vectors packed back to back at 64-byte aligned offsets
     offs = np.zeros(len(chunks), dtype=np.int64)
     total = 0
@@ -186,22 +199,26 @@ def solve_pairs(pairs: Sequence[Tuple[_Vec, List[_Vec]]], max_offset_samples: Op
             continue
         offs[i] = total
         total += (c.size + 63) // 64 * 64
-    host = np.zeros(max(total, 64), dtype=np.uint8)
-    for c, o in zip(chunks, offs):
-        if c is not None:
-            host[o:o + c.size] = c
-    dev = torch.from_numpy(host).cuda()
+    dev = None
+    if total:  # (nothing to upload when every vector already lives in HBM)
+        host = np.zeros(total, dtype=np.uint8)
+        for c, o in zip(chunks, offs):
+            if c is not None:
+                host[o:o + c.size] = c
+        dev = torch.from_numpy(host).cuda()
     ptrs = np.array([v.dev.data_ptr() if c is None else dev.data_ptr() + int(o)
                      for v, c, o in zip(vecs, chunks, offs)], dtype=np.uint64)
     lo = np.array([v.lo for v in vecs], dtype=np.float64)
     hi = np.array([v.hi for v in vecs], dtype=np.float64)
     plan = _native.get_plan(n_fft, pairs_in_flight=1 if n_pairs == 1 else 2, max_cand=max(8, n_cand))
-    cand_out = torch.empty(n_pairs * n_cand * 24, dtype=torch.uint8, device=dev.device)
-    pair_out = torch.empty(n_pairs * 24, dtype=torch.uint8, device=dev.device)
+    n_cbytes = n_pairs * n_cand * 24
+    results = torch.empty(n_cbytes + n_pairs * 24, dtype=torch.uint8, device="cuda")  # both record arrays: one copy back
+    cand_out, pair_out = results[:n_cbytes], results[n_cbytes:]
     plan.align_batch(n_pairs, n_cand, dtype, ptrs, lens, lo, hi, max_offset_samples, filter_max_offset,
-                     cand_out, pair_out)
-    cres = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(n_pairs, n_cand).copy()
-    pres = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE).copy()
+                     cand_out, pair_out, vec_max_boundaries=bounds if any(role_lists) else None)
+    raw = results.cpu().numpy()
+    cres = raw[:n_cbytes].view(_native.CAND_RESULT_DTYPE).reshape(n_pairs, n_cand).copy()
+    pres = raw[n_cbytes:].view(_native.PAIR_RESULT_DTYPE).copy()
     del dev, keep_alive
     # A candidate with more tied maxima than its share of the exhaustive pool keeps FFS_FLAG_AMBIGUOUS.  Its
     # quota depends on how many candidates of the call overflowed, so solve such a pair again on its own

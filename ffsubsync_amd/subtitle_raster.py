@@ -26,12 +26,29 @@ class DeviceRaster:
     bit-packed form the kernels prefer (int32 words, sample i = bit i & 31 of word i >> 5,
     ``_native.FFS_DTYPE_U1``): an eighth of the HBM bytes."""
 
-    def __init__(self, bits, lo: float = 0.0, hi: float = 1.0, n: Optional[int] = None) -> None:
+    def __init__(self, bits, lo: float = 0.0, hi: float = 1.0, n: Optional[int] = None, runs=None,
+                 runs_bound: int = 0) -> None:
         self.bits = bits
         self.lo = float(lo)
         self.hi = float(hi)
         self.packed = n is not None
         self.n = int(bits.numel()) if n is None else int(n)
+        # the same vector as a boundary list (``ffs_runs_list`` block, FFS_DTYPE_RUNS) with a host-known upper bound of
+        # its length: the aligner then neither extracts the boundaries from the bits nor waits for their count
+        self.runs = runs
+        self.runs_bound = int(runs_bound)
+
+    def attach_runs(self) -> "DeviceRaster":
+        """Extract the vector's boundary list once (one pass over the bits on the device, one 4-byte read-back of its
+        length), so that every later solve starts from the list.  A vector too dense for the run-boundary path
+        (32 768 boundaries or more) keeps its bits only."""
+        if self.runs is None and self.n > 0:
+            cap = min(32768, self.n + 2)
+            block = _native.runs_from_bits(self.packed_words(), self.n, cap)
+            count = int(block[0].item())
+            if count < cap:
+                self.runs, self.runs_bound = block, max(count, 1)
+        return self
 
     def __len__(self) -> int:
         return self.n
@@ -41,9 +58,10 @@ class DeviceRaster:
         return self.n
 
     @classmethod
-    def from_host(cls, values) -> Optional["DeviceRaster"]:
+    def from_host(cls, values, lists: bool = True) -> Optional["DeviceRaster"]:
         """Bit-packed device copy of a two-level host vector (e.g. a VAD label vector: {non_speech_label, 1.0}); None
-        when the samples take more than two values.  One pass to find the levels, ``packbits``, one small upload."""
+        when the samples take more than two values.  One pass to find the levels, ``packbits``, one small upload;
+        ``lists``: also its boundary list (:meth:`attach_runs`)."""
         import torch
 
         v = np.asarray(values, dtype=float).ravel()
@@ -56,7 +74,8 @@ class DeviceRaster:
         packed = np.packbits(is_hi if hi != lo else np.zeros(v.size, bool), bitorder="little")
         host = np.zeros((v.size + 31) // 32 * 4, dtype=np.uint8)
         host[: packed.size] = packed
-        return cls(torch.from_numpy(host).cuda().view(torch.int32), lo, hi, v.size)
+        out = cls(torch.from_numpy(host).cuda().view(torch.int32), lo, hi, v.size)
+        return out.attach_runs() if lists else out
 
     def bytes01(self):
         """0/1 uint8 CUDA tensor of the samples."""
@@ -114,7 +133,29 @@ def rasterize_candidates(start_us, end_us, meta, ratios: Sequence[float], sample
     for r in ratios:
         words, n = _native.rasterize_subtitles(start_us, end_us, meta, r, sample_rate, start_seconds, packed=True)
         out.append(DeviceRaster(words, 0.0, min(1.0 / r, 1.0), n))
+    _attach_interval_lists(out, start_us, end_us, meta, ratios, sample_rate, start_seconds)
     return out
+
+
+def _attach_interval_lists(rasters, start_us, end_us, meta, ratios, sample_rate, start_seconds) -> None:
+    """The rasters' boundary lists straight from the subtitle intervals (``ffs_rasterize_batch_runs``: the merged
+    intervals ARE the list; one launch for all ratios, bound = two entries per subtitle)."""
+    import torch
+
+    count = int(np.size(start_us))
+    if start_seconds > 0 or count == 0 or any(r.n <= 0 for r in rasters):
+        return  # (negative start samples wrap around in Python slices: bits only)
+    cap = 2 * count + 2
+    stride = (_native.runs_list_bytes(cap) + 63) // 64 * 64
+    k = len(rasters)
+    data = torch.empty(k * stride, dtype=torch.uint8, device="cuda")
+    _native.rasterize_batch_runs(start_us, end_us, meta, np.zeros(k, np.int64), np.full(k, count, np.int64),
+                                 np.asarray(list(ratios), dtype=np.float64), np.arange(k, dtype=np.int64) * stride,
+                                 np.full(k, cap, np.int64), np.array([r.n for r in rasters], dtype=np.int64), data,
+                                 sample_rate, float(start_seconds))
+    for i, r in enumerate(rasters):
+        r.runs = data[i * stride: i * stride + _native.runs_list_bytes(cap)].view(torch.int32)
+        r.runs_bound = max(2 * count, 2)
 
 
 class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBoundariesMixin):
@@ -140,6 +181,8 @@ class DeviceSubtitleSpeechTransformer(TransformerMixin, ComputeSpeechFrameBounda
         words, n = _native.rasterize_subtitles(start_us, end_us, meta, 1.0, self.sample_rate, self.start_seconds,
                                                packed=True)
         self.subtitle_speech_results_ = DeviceRaster(words, 0.0, min(1.0 / self.framerate_ratio, 1.0), n)
+        _attach_interval_lists([self.subtitle_speech_results_], start_us, end_us, meta, [1.0], self.sample_rate,
+                               self.start_seconds)
         self.fit_boundaries(self.subtitle_speech_results_.frames_float())
         return self
 
@@ -174,7 +217,7 @@ def _device_copy_of(transformer, values):
             import torch
 
             lo, hi, packed = found
-            raster = DeviceRaster(torch.from_numpy(packed.view(np.int32).copy()).cuda(), lo, hi, flat.size)
+            raster = DeviceRaster(torch.from_numpy(packed.view(np.int32).copy()).cuda(), lo, hi, flat.size).attach_runs()
     out = values if raster is None else raster  # more than two levels (fused / weighted labels): the host floats
     if key is not None:
         transformer.__dict__["_ffs_device_copy"] = (key, out)  # (the key holds no reference to the host vector)

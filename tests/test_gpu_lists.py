@@ -377,3 +377,68 @@ def test_pinned_and_device_resident_tables_give_the_same_lists(torch):
             n = int(want[int(offs[v]): int(offs[v]) + 4].view(torch.int32).item())
             nb = 16 + 8 * (n + 1)
             assert torch.equal(want[int(offs[v]): int(offs[v]) + nb], got[int(offs[v]): int(offs[v]) + nb]), (mode, v)
+
+
+# ---- the drop-in classes on boundary lists -------------------------------------------------------------------------
+def test_rasters_from_intervals_carry_their_boundary_lists():
+    """rasterize_candidates / DeviceSubtitleSpeechTransformer: every raster's list (straight from the intervals) expands
+    to exactly the raster's bits, including a negative start_seconds; a positive one keeps the bits only."""
+    from datetime import timedelta
+
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.subtitle_raster import DeviceSubtitleSpeechTransformer, rasterize_candidates
+    from oracle import raster_oracle as ro
+
+    s, e, m = ro.synth_subtitles(77, n=140, minutes=9.0)
+    ratios = [0.9, 1.0, 25 / 24, 1.1]
+    for ss in (0, -3):
+        rasters = rasterize_candidates(s, e, m, ratios, 100, ss)
+        for r in rasters:
+            assert r.runs is not None and r.runs_bound >= int(r.runs[0].item())
+            assert np.array_equal(_native.runs_to_bits(r.runs, r.n).cpu().numpy(), r.packed_words().cpu().numpy()[: (r.n + 31) // 32])
+    assert all(r.runs is None for r in rasterize_candidates(s, e, m, ratios, 100, 2))
+
+    class Sub:
+        def __init__(self, a, b):
+            self.start, self.end, self.content = timedelta(microseconds=int(a)), timedelta(microseconds=int(b)), "x"
+
+    t = DeviceSubtitleSpeechTransformer(100, 0, 1.0).fit([Sub(a, b) for a, b in zip(s, e)])
+    r = t.transform()
+    assert r.runs is not None
+    assert np.array_equal(_native.runs_to_bits(r.runs, r.n).cpu().numpy(), r.packed_words().cpu().numpy()[: (r.n + 31) // 32])
+
+
+def test_drop_in_solves_from_lists_like_from_bits_and_host_arrays():
+    """MaxScoreAligner(FFTAligner) on DeviceRasters that carry lists (no extraction, no wait for the device), on the same
+    rasters without lists, and on the reference-shaped host arrays: one answer; the plan took the run-boundary path."""
+    from ffsubsync_amd import _native
+    from ffsubsync_amd.aligners import FFTAligner, MaxScoreAligner
+    from ffsubsync_amd.constants import candidate_ratios
+    from ffsubsync_amd.subtitle_raster import DeviceRaster, rasterize_candidates
+    from oracle import aligners_oracle as orc
+    from oracle import raster_oracle as ro
+
+    s, e, m = ro.synth_subtitles(5, n=210, minutes=12.0)
+    ratios = candidate_ratios()
+    truth = ro.rasterize(s, e, m, ratios[4], 100, 0)
+    ref = np.concatenate([np.zeros(233), (truth > 0).astype(float), np.zeros(500)])
+    host = [ro.rasterize(s, e, m, r, 100, 0) for r in ratios]
+    (o_score, o_offset), idx = orc.max_score_align(ref, host, 6000)
+    with_lists = rasterize_candidates(s, e, m, ratios)
+    dref = DeviceRaster.from_host(ref)
+    assert dref.runs is not None and all(c.runs is not None for c in with_lists)
+    without = [DeviceRaster(c.bits, c.lo, c.hi, c.n) for c in with_lists]
+    dref0 = DeviceRaster.from_host(ref, lists=False)
+    assert dref0.runs is None
+    answers = []
+    for r, cands in ((dref, with_lists), (dref0, without), (dref, without), (ref, host)):
+        (score, offset), winner = MaxScoreAligner(FFTAligner, None, 100, 60).fit_transform(r, list(cands))
+        answers.append((float(score), int(offset), [i for i, c in enumerate(cands) if c is winner][0]))
+    assert answers[0] == answers[1] == answers[2] == answers[3]
+    assert answers[0][1] == o_offset == 233 and answers[0][2] == idx == 4
+    assert answers[0][0] == pytest.approx(o_score, rel=1e-9)
+    # a dense vector (more boundaries than a list may hold) keeps its bits only and still solves
+    rng = np.random.default_rng(3)
+    dense = DeviceRaster.from_host((rng.random(200000) < 0.5).astype(float))
+    assert dense.runs is None
+    assert FFTAligner(6000).fit_transform(dense, with_lists[4]) == orc.fft_align(np.asarray(dense), host[4], 6000)[1]
