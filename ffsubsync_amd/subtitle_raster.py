@@ -148,7 +148,7 @@ def _attach_interval_lists(rasters, start_us, end_us, meta, ratios, sample_rate,
     cap = 2 * count + 2
     stride = (_native.runs_list_bytes(cap) + 63) // 64 * 64
     k = len(rasters)
-    data = torch.empty(k * stride, dtype=torch.uint8, device="cuda")
+    data = torch.empty(k * stride, dtype=torch.uint8, device=rasters[0].bits.device)
     _native.rasterize_batch_runs(start_us, end_us, meta, np.zeros(k, np.int64), np.full(k, count, np.int64),
                                  np.asarray(list(ratios), dtype=np.float64), np.arange(k, dtype=np.int64) * stride,
                                  np.full(k, cap, np.int64), np.array([r.n for r in rasters], dtype=np.int64), data,

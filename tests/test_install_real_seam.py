@@ -170,7 +170,27 @@ def _rasterize(start_us, end_us, meta, ratio, sample_rate=100.0, start_seconds=0
 def _bounds(frames):
     nz = np.nonzero(frames.numpy() > 0.5)[0]
     return (int(nz.min()), int(nz.max())) if nz.size else (None, None)
+def _list_block(x01, cap, out):                     # the ffs_runs_list block of a 0/1 vector: header, entries, sentinel
+    from oracle import runs_model as rm
+    q, cq = rm.boundaries(x01)
+    blk = out.view(torch.int32).numpy()
+    blk[:4] = (min(q.size, cap), int(x01.sum()), x01.size, cap)
+    if q.size < cap:
+        blk[4:4 + 2 * q.size] = np.stack([q, cq], 1).ravel()
+        blk[4 + 2 * q.size: 6 + 2 * q.size] = (2 ** 31 - 1, int(x01.sum()))
+def _runs_from_bits(words, n, cap=None, out=None):
+    cap = 32768 if cap is None else int(cap)
+    out = torch.zeros(4 + 2 * cap, dtype=torch.int32) if out is None else out
+    _list_block(np.unpackbits(words.numpy().view(np.uint8), bitorder="little")[:n], cap, out)
+    return out
+def _rasterize_runs(start_us, end_us, meta, first, count, ratio, off, cap, length, out, sample_rate=100.0, start_seconds=0.0):
+    for f, c, r, o, k, n in zip(first, count, ratio, off, cap, length):
+        x = ro.rasterize(np.asarray(start_us)[f:f + c], np.asarray(end_us)[f:f + c], None if meta is None else np.asarray(meta)[f:f + c],
+                         r, sample_rate, start_seconds) != 0
+        assert x.size == n
+        _list_block(x.astype(np.uint8), int(k), out[int(o): int(o) + 16 + 8 * int(k)])
 _native.vad_energy, _native.vad_tokenize, _native.rasterize_subtitles, _native.speech_bounds = _vad_energy, _vad_tokenize, _rasterize, _bounds
+_native.runs_from_bits, _native.rasterize_batch_runs = _runs_from_bits, _rasterize_runs
 '''
 
 DEVICE_RASTER_SCENARIO = PREAMBLE + r'''
@@ -233,6 +253,7 @@ assert ok is True and result["sync_was_successful"] is True, result
 assert abs(result["framerate_scale_factor"] - true_ratio) < 1e-12 and abs(result["offset_seconds"] - true_shift_s) <= 0.02, result
 assert len(seen) == 7 and all(r is amd_sr.DeviceRaster and c is amd_sr.DeviceRaster for r, c, _ in seen), seen
 assert len({i for _, _, i in seen}) == 1                    # the same reference raster for all seven candidates
+assert first.runs is not None and first.runs_bound >= int(first.runs[0])     # ... and it carries its boundary list
 print("DEVICE_RASTER_SEAM_OK offset=%.2f scale=%.6f" % (result["offset_seconds"], result["framerate_scale_factor"]))
 '''
 
