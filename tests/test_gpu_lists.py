@@ -379,6 +379,39 @@ def test_pinned_and_device_resident_tables_give_the_same_lists(torch):
             assert torch.equal(want[int(offs[v]): int(offs[v]) + nb], got[int(offs[v]): int(offs[v]) + nb]), (mode, v)
 
 
+def test_large_host_tables_give_the_same_lists(torch):
+    """8 MB of pageable subtitle tables (48 tracks of 10 000 heavily overlapping subtitles), one track unsorted: the same
+    list blocks as device-resident tables, and their expansion equals the bit rasteriser's output."""
+    from ffsubsync_amd import _native, batch
+
+    rng = np.random.RandomState(21)
+    tracks = []
+    for k in range(48):
+        s = np.sort(rng.randint(0, 2_000_000_000, 10_000)).astype(np.int64)
+        if k == 17:
+            rng.shuffle(s)
+        tracks.append((s, s + rng.randint(50_000, 400_000, s.size), (rng.rand(s.size) < 0.01).astype(np.uint8)))
+    track_of = np.arange(48)
+    ratio = np.where(track_of % 2, 1.0417, 1.0)
+    got, offs, lens, bounds = batch.TrackSet(tracks).rasterize_runs(track_of, ratio)
+    dev = batch.TrackSet([tracks[k] if k != 17 else tuple(a[np.argsort(tracks[17][0], kind="stable")] for a in tracks[17])
+                          for k in range(48)])
+    dev.to_device()
+    want, o2, l2, _ = dev.rasterize_runs(track_of, ratio)
+    assert np.array_equal(offs, o2) and np.array_equal(lens, l2)
+    bits, boffs, blens = batch.TrackSet(tracks).rasterize(track_of, ratio)
+    for v in (0, 1, 17, 47):
+        n = int(got[int(offs[v]): int(offs[v]) + 4].view(torch.int32).item())
+        assert 0 < n <= int(bounds[v])
+        nb = 16 + 8 * (n + 1)
+        assert torch.equal(want[int(offs[v]): int(offs[v]) + nb], got[int(offs[v]): int(offs[v]) + nb]), v
+        blk = got[int(offs[v]): int(offs[v]) + 16 + 8 * (int(bounds[v]) + 2)].view(torch.int32)
+        words = (int(lens[v]) + 31) // 32
+        assert int(blens[v]) == int(lens[v])
+        assert torch.equal(_native.runs_to_bits(blk, int(lens[v]))[:words],
+                           bits[int(boffs[v]): int(boffs[v]) + 4 * words].view(torch.int32)), v
+
+
 # ---- the drop-in classes on boundary lists -------------------------------------------------------------------------
 def test_rasters_from_intervals_carry_their_boundary_lists():
     """rasterize_candidates / DeviceSubtitleSpeechTransformer: every raster's list (straight from the intervals) expands
