@@ -3,7 +3,7 @@
 `rocprofv3 --kernel-trace --stats` (and one `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` pass) covers them:
 
     k_vad_energy (fp32 labels / bit-packed labels), k_vad_tokenize_scan, k_speech_bounds, k_pack_bits,
-    k_rasterize_batch, and the transform kernels of the windowless (3*2^19: k_pass_a3, k_mid, k_pass_c3) and
+    k_rasterize_batch, k_levels_bits (multi-level float references), and the transform kernels of the windowless (3*2^19: k_pass_a3, k_mid, k_pass_c3) and
     reference-length (2^21) plans plus the window-shortened default (k_pass_a, k_mid_seg_one, k_pass_c_pruned).
 
 Prints ONE JSON line: the algorithmic bytes per launch of each kernel (what profiles/summarize_secondary.py divides the
@@ -96,6 +96,22 @@ n_b = dl.data.view(torch.int32).reshape(-1, int(dl.offs.ravel()[1]) // 4)[:, 0].
 alg["k_runs_extract_lists"] = {"bytes_per_launch": float(np.sum((db.lens + 31) // 32 * 4)) + 8.0 * n_b + 16.0 * db.lens.size,
                                "what": "every bit-packed vector read once + 8 bytes per boundary written"}
 del dl
+# ---- multi-level float64 references (the `weighted` fused VAD's four levels) against the bit-packed candidates: the level
+# kernels (k_levels_sample, k_levels_bits: the float samples are read once), k_runs_extract on the planes + candidates, k_runs_corr_ml
+try:
+    n_f = min(pairs, 128)
+    dbf = synth.build_fused_batch(specs[:n_f])
+    alf = batch.BatchAligner(dbf.required_fft_length(6000), 7, 6000, pairs_in_flight=n_f)
+    for _ in range(REP):
+        alf.solve_async(dbf, 0, n_f)
+    torch.cuda.synchronize()
+    alf.close()
+    ref_lens = dbf.lens[:, 0].astype(np.float64)
+    alg["k_levels_bits"] = {"bytes_per_launch": float(np.sum(8.0 * ref_lens + 3.0 * np.ceil(ref_lens / 32.0) * 4.0)),
+                            "what": "%d float64 references read once + three bit planes written each" % n_f}
+    del dbf
+except Exception as exc:
+    alg["k_levels_bits"] = {"error": repr(exc)[:200]}
 unit = lambda nfft: 8.0 * nfft
 in_bytes = float(np.mean(db.lens.sum(axis=1))) / 8.0
 for label, mo, ref_len in (("default_3x2^18_segmented", 6000, False), ("windowless_3x2^19", None, False), ("reference_length_2^21", 6000, True)):

@@ -64,6 +64,8 @@ for name, ns in calls.items():
     by_n[name] = (k, ns)
 res["transform_kernels"] = {name: {"role": k, "launches": len(ns), "avg_us": sum(ns) / len(ns) / 1e3} for name, (k, ns) in by_n.items()}
 res["transform_plans"] = {p: alg[p] for p in plans}
+res["float_reference_kernels"] = {name: {"launches": len(ns), "avg_us": sum(ns) / len(ns) / 1e3} for name, ns in calls.items()
+                                  if name.startswith("k_levels_sample") or name.startswith("k_runs_corr_ml")}
 res["notes"] = {
     "k_pack_bits<0>": "round 4 reported 93 x PMC-over-algorithmic: its launches (synth.build_device_batch packing 184 MB byte chunks) "
                       "were divided by the 2 MB of the label-packing call site; records are now keyed by instantiation",
