@@ -1370,9 +1370,9 @@ def main():
                     })
                 result["boundary_density"] = {
                     "what": "256 pairs x 2 h x 7 ratios, max_offset_samples=6000; workloads.synth.make_pair_spec(run_scale): "
-                            "gaps U[0.2,8] s and runs U[0.5,6] s times run_scale.  Budget of the automatic choice: five boundary "
-                            "coincidences per point of the plan length; lists of 32 767 boundaries or more always go through "
-                            "the transforms", "sweep": sweep}
+                            "gaps U[0.2,8] s and runs U[0.5,6] s times run_scale.  Budget of the automatic choice: twelve boundary "
+                            "coincidences per point of the plan length and transform slot; lists of 32 768 boundaries or more "
+                            "always go through the transforms", "sweep": sweep}
             except Exception as exc:
                 result["boundary_density"] = {"error": repr(exc)[:300], "sweep": sweep}
             finally:

@@ -90,6 +90,11 @@ int fail(int code, const char* fmt, ...) {
 constexpr int64_t kMinFftN = 4096;  // shorter problems go to the exact direct kernel
 constexpr int64_t kMaxFftN = 1 << 24;
 constexpr unsigned kPoolCapacity = 1u << 20;
+// FFS_ALGO_AUTO: boundary coincidences per candidate, per point of the plan's transform length and packed transform slot
+// the candidate occupies, above which the transforms take over.  Measured break-even (profiles/budget_probe.py, round 5):
+// +-60 s window: ~20 per point of N = 3 * 2^18 (lists of 17 k x 20 k boundaries); no window: ~13 per point of N = 3 * 2^19
+// (118 lag tiles per candidate cost as much as 6 M coincidences).  Twelve keeps the choice on the winning side in both.
+constexpr long long kRunsBudgetPerPoint = 12;
 constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
@@ -1641,7 +1646,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 return rc;
             const long long budget = p->algo == FFS_ALGO_RUNS ? INT64_MAX / 4
                                      : p->runs_budget >= 0 ? p->runs_budget
-                                                           : 8 * (long long)p->N * (n_cand + 1) / (2 * n_cand);
+                                                           : kRunsBudgetPerPoint * (long long)p->N * (n_cand + 1) / (2 * n_cand);
             // Lists that arrive with host-known length bounds (the rasteriser's: two entries per subtitle) settle the
             // question on the host: within budget even at the bounds -> no flags kernel, no copy back, no wait.
             bool proven = !need_extract && vec_bound != nullptr;

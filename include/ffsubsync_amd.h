@@ -186,7 +186,7 @@ int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, 
  *     over every lag of the window, no transform (csrc/ffs_runs.h) -- and the call waits once (an event, not the stream,
  *     after all of its kernels are queued) for one int per sub-batch: whether it needs the transforms; sub-batches (pairs_in_flight pairs) holding a vector with 32 768 boundaries or more, or a candidate
  *     whose expected number of boundary coincidences inside its lag window (boundaries of the candidate x boundaries of
- *     the reference x window lags / reference length) exceeds the budget -- by default eight per point of the plan's
+ *     the reference x window lags / reference length) exceeds the budget -- by default twelve per point of the plan's
  *     transform length and packed transform slot the candidate occupies, (n_cand + 1) / (2 n_cand) of one: the measured
  *     break-even -- are solved by the transforms instead.  A FLOAT reference (FFS_DTYPE_F32 / F64) with at most four
  *     distinct sample values whose steps are small integer multiples of one quantum -- the `weighted` fused VAD's

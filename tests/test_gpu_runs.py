@@ -108,8 +108,8 @@ def test_seven_ratios_without_a_window(headline):
     b, _ = _solve(db8, n_fft, None, "fft", pairs_in_flight=8)
     assert st[2] == 0
     _same_records(a, b)
-    # auto: ~6.6 M boundary coincidences per candidate against a budget of five per transform point (7.9 M): either
-    # path costs about the same here; whatever the library picks, the records are the same
+    # auto: ~6.6 M boundary coincidences per candidate against a budget of twelve per transform point and slot (10.8 M):
+    # whatever the library picks, the records are the same
     c, st_auto = _solve(db8, n_fft, None, "auto", pairs_in_flight=8)
     assert st_auto[:2] == (1, 1)
     _same_records(c, b)
