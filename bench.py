@@ -133,6 +133,7 @@ def compact_record(result, detail_path=None):
     out["fft_path_roofline"] = slim_roofline((result.get("fft_path") or {}).get("roofline"))
     out["reference_length_value"] = _pick(result, "reference_length", "value")
     out["windowless_value"] = _pick(result, "windowless", "value")
+    out["windowless_golden"] = _pick(result, "windowless", "pairs_matching_reference_golden")
     detail = {
         "fft_path_identical_records": _pick(result, "fft_path", "identical_candidate_results"),
         "single_ratio_6000": _pick(result, "single_ratio", "max_offset_6000", "solves_per_s"),
@@ -1329,6 +1330,11 @@ def main():
         st_w = max(2, args.steps // 5)
         el_w, kt_w, seg_w = timed(n_w, st_w, 1, max_offset=None)
         pres_w = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
+        cres_w = cand_out.cpu().numpy().view(_native.CAND_RESULT_DTYPE)[: P * n_cand].reshape(P, n_cand)
+        from workloads import golden_check
+
+        wl_gold = golden_check.load("windowless_golden") if args.duration == 7200.0 else {}
+        wl_ok, wl_total, wl_first = golden_check.matching(wl_gold, seeds, pres_w, cres_w)
         result["windowless"] = {
             "what": "max_offset_samples=None (aligners.py:25-29 default): same pairs, every lag searched",
             "n_fft_device": int(n_w), "path": info_now["path"], "value": P * st_w / el_w, "unit": "7-ratio solves/s",
@@ -1337,7 +1343,12 @@ def main():
                 int(pres_w[i]["best_cand"]) == sp.true_ratio_index and abs(int(pres_w[i]["offset"]) - sp.true_offset_samples) <= 30
                 for i, sp in enumerate(specs))),
             "pairs": P,
+            # the unmodified reference's MaxScoreAligner(FFTAligner()) on the same seeds (tests/golden/windowless_golden.json):
+            # same rule as the windowed headline (workloads/golden_check.py)
+            "pairs_matching_reference_golden": "%d/%d" % (wl_ok, wl_total),
         }
+        if wl_first:
+            result["windowless"]["first_mismatches"] = [str(x) for x in wl_first]
         if profile:
             result["windowless"]["kernels"] = {
                 k: {kk: v[kk] for kk in ("avg_ms", "us_per_pair", "must_move_GBps", "frac_of_8TBps") if kk in v}

@@ -292,9 +292,9 @@ class Plan:
 
     def set_algorithm(self, algorithm, _from_env: bool = False) -> None:
         """"auto" (default: run-boundary path for short boundary lists, transforms otherwise), "fft" (transforms only) or
-        "runs" (run-boundary path without the coincidence budget); identical results either way.  A plan whose algorithm
-        was set through this method keeps it: ``get_plan`` only re-applies FFS_ALGORITHM to plans that were never set
-        explicitly."""
+        "runs" (run-boundary path without the coincidence budget); identical results either way.  The choice belongs to
+        whoever owns the plan: a plan obtained from ``get_plan`` (a per-thread cache shared between callers) gets
+        FFS_ALGORITHM re-applied at every hand-out."""
         check(self.lib.ffs_plan_set_algorithm(self.handle, algorithm_code(algorithm)))
         if not _from_env:
             self._algorithm_explicit = True
@@ -434,10 +434,12 @@ def get_plan(n_fft: int, pairs_in_flight: int = 1, max_cand: int = 8, device: Op
     else:
         cache.order.remove(key)
     cache.order.append(key)
-    # cached plans follow FFS_ALGORITHM like new ones do (auto | fft | runs; results are identical either way) -- unless
-    # the caller chose an algorithm for this plan through Plan.set_algorithm
-    if not getattr(plan, "_algorithm_explicit", False):
-        plan.set_algorithm(env_algorithm(), _from_env=True)
+    # Cached plans are SHARED between unrelated callers of the thread: every hand-out re-applies FFS_ALGORITHM (auto | fft |
+    # runs; results are identical either way), so a Plan.set_algorithm() by one user of a cached plan lasts until the next
+    # get_plan() for that key and never leaks into another caller's solves.  To pin an algorithm, own the plan
+    # (``Plan(...)`` / ``BatchAligner(algorithm=...)``).
+    plan.set_algorithm(env_algorithm(), _from_env=True)
+    plan._algorithm_explicit = False
     # evict least recently used plans beyond the budget (never the one just asked for)
     total = sum(p.workspace_bytes for p in cache.plans.values())
     while total > PLAN_CACHE_BYTES and len(cache.order) > 1:
@@ -649,10 +651,13 @@ def runs_from_bits_batch(bits_ptr, lens, list_ptr, caps) -> None:
                                           bits_ptr.size, current_stream_ptr(torch)))
 
 
-def runs_to_bits(block, n: int):
-    """FFS_DTYPE_U1 words (int32 CUDA tensor) of the ``n``-sample vector an ``ffs_runs_list`` block describes."""
+def runs_to_bits(block, n: int, out=None):
+    """FFS_DTYPE_U1 words (int32 CUDA tensor) of the ``n``-sample vector an ``ffs_runs_list`` block describes (written
+    into ``out`` when given: at least ``packed_words(n)`` int32)."""
     torch = require_gpu()
-    out = torch.empty(packed_words(n), dtype=torch.int32, device=block.device)
+    if out is None:
+        out = torch.empty(packed_words(n), dtype=torch.int32, device=block.device)
+    assert out.dtype == torch.int32 and out.numel() >= packed_words(n)
     check(load().ffs_runs_to_bits(block.data_ptr(), int(n), out.data_ptr(), current_stream_ptr(torch)))
     return out
 

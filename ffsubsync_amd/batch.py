@@ -192,10 +192,14 @@ class TrackSet:
                                      offs // 4, lens, data, sample_rate, start_seconds)
         return data, offs, lens
 
-    def rasterize_runs(self, track_of, ratio, sample_rate: int = 100):
+    def rasterize_runs(self, track_of, ratio, sample_rate: int = 100, start_seconds: float = 0):
         """The same vectors as BOUNDARY LISTS (FFS_DTYPE_RUNS; ``ffs_rasterize_batch_runs``): no bitmap is written, the
         merged intervals are the list.  Returns (uint8 CUDA buffer, byte offset of every vector's list block, length of
-        every vector in samples, upper bound of every list's length: two entries per subtitle)."""
+        every vector in samples, upper bound of every list's length: two entries per subtitle).  ``start_seconds`` as in
+        ``rasterize`` (speech_transformers.py:968-972); the list form needs ``start_seconds <= 0`` (a positive one makes
+        negative start samples, which wrap around in the reference's Python slices)."""
+        if start_seconds > 0:
+            raise ValueError("boundary lists need start_seconds <= 0 (negative start samples wrap around in Python slices)")
         torch = _native.require_gpu()
         track_of = np.asarray(track_of, dtype=np.int64).ravel()
         ratio = np.ascontiguousarray(ratio, dtype=np.float64).ravel()
@@ -205,7 +209,8 @@ class TrackSet:
         offs, total = _layout(lens, 16 + 8 * caps)
         data = torch.empty(max(total, 64), dtype=torch.uint8, device="cuda")
         s_us, e_us, meta = self._dev if self._dev is not None else (self.start_us, self.end_us, self.meta)
-        _native.rasterize_batch_runs(s_us, e_us, meta, self.firsts[track_of], counts, ratio, offs, caps, lens, data, sample_rate, 0.0)
+        _native.rasterize_batch_runs(s_us, e_us, meta, self.firsts[track_of], counts, ratio, offs, caps, lens, data, sample_rate,
+                                     float(start_seconds))
         return data, offs, lens, np.maximum(2 * counts, 2).astype(np.int32)
 
 
@@ -234,7 +239,7 @@ def pairs_from_intervals(records, ratios: Sequence[float], sample_rate: int = 10
     if lists:
         if start_seconds > 0:
             raise ValueError("boundary lists need start_seconds <= 0 (negative start samples wrap around in Python slices)")
-        data, offs, lens, bounds = TrackSet(tracks).rasterize_runs(track_of.ravel(), ratio.ravel(), sample_rate)
+        data, offs, lens, bounds = TrackSet(tracks).rasterize_runs(track_of.ravel(), ratio.ravel(), sample_rate, start_seconds)
         return DeviceBatch(data, offs.reshape(n_pairs, n_vec), lens.reshape(n_pairs, n_vec), np.zeros_like(hi), hi,
                            _native.FFS_DTYPE_RUNS, None, bounds.reshape(n_pairs, n_vec))
     data, offs, lens = rasterize_vectors(tracks, track_of.ravel(), ratio.ravel(), sample_rate, start_seconds)

@@ -148,7 +148,7 @@ def fit_gss_batch(refs: Sequence, subtitle_records: Sequence[Tuple[np.ndarray, n
     def evaluate(ratios, is_last):
         t0 = _time.perf_counter()
         if use_lists:
-            data, c_offs, c_lens, c_bounds = tracks.rasterize_runs(which, ratios, sample_rate)
+            data, c_offs, c_lens, c_bounds = tracks.rasterize_runs(which, ratios, sample_rate, start_seconds)
             bounds[1::2] = c_bounds
         else:
             data, c_offs, c_lens = tracks.rasterize(which, ratios, sample_rate, start_seconds)

@@ -1294,14 +1294,24 @@ struct ExpandVec {
     int32_t len;
     int32_t pad;
 };
-__global__ __launch_bounds__(256) void k_runs_expand(const ExpandVec* __restrict__ vecs, int chunks_per_vec) {
+// A caller-owned block is read through its own header (n, ones, len, cap): a truncated list (n >= cap) or one made for
+// another vector length is never followed past the block -- n is clamped to the entries the block holds and `err`
+// (optional) is raised so that the entry point can report FFS_E_INVALID like the run-boundary path's flags kernel does.
+__global__ __launch_bounds__(256) void k_runs_expand(const ExpandVec* __restrict__ vecs, int chunks_per_vec, int* __restrict__ err) {
     const int v = blockIdx.x / chunks_per_vec, c = blockIdx.x - v * chunks_per_vec;
     const ExpandVec ev = vecs[v];
     if (!ev.dst) return;
     const int n_words = (ev.len + 31) >> 5;
     const int w = c * 256 + (int)threadIdx.x;
     if (w >= n_words) return;
-    unsigned m = list_bits32((GEntries)ev.e, ((GInts)ev.hdr)[0], (long long)w * 32);
+    const GInts hd = (GInts)ev.hdr;
+    int n = hd[0];
+    const int cap = hd[3];
+    const bool broken = n < 0 || n >= cap || hd[2] != ev.len;
+    if (n >= cap) n = cap > 0 ? cap - 1 : 0;
+    if (n < 0) n = 0;
+    if (broken && err && w == 0) atomicOr(err, 1);
+    unsigned m = list_bits32((GEntries)ev.e, n, (long long)w * 32);
     if (w == n_words - 1 && (ev.len & 31)) m &= (1u << (ev.len & 31)) - 1u;
     ev.dst[w] = m;
 }

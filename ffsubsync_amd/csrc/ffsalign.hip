@@ -1284,14 +1284,27 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             hev[i] = ExpandVec{(const int2*)((const char*)vec_ptr[i] + 16), (const int2*)vec_ptr[i], dst, (int32_t)vec_len[i], 0};
             if (is_list) (*out)[i] = dst;
         }
-        // (rare path: a synchronous upload keeps the host table's lifetime trivial)
-        HIP_TRY(hipMallocAsync((void**)&d_ev, n_vec * sizeof(ExpandVec), st));
-        HIP_TRY(hipMemcpyAsync(d_ev, hev.data(), n_vec * sizeof(ExpandVec), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const int chunks_per_vec = (int)(((len_max + 31) / 32 + 255) / 256);
-        hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)(n_vec * chunks_per_vec)), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks_per_vec);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipFreeAsync(d_ev, st));
+        // (rare path; the table is followed by one int the kernel raises when a block's header does not fit the block)
+        const size_t tab = n_vec * sizeof(ExpandVec);
+        int bad_list = 0;
+        HIP_TRY(hipMallocAsync((void**)&d_ev, tab + sizeof(int), st));
+        hipError_t he = hipMemcpyAsync(d_ev, hev.data(), tab, hipMemcpyHostToDevice, st);
+        if (he == hipSuccess) he = hipMemsetAsync((char*)d_ev + tab, 0, sizeof(int), st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        if (he == hipSuccess) {
+            const int chunks_per_vec = (int)(((len_max + 31) / 32 + 255) / 256);
+            hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)(n_vec * chunks_per_vec)), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks_per_vec,
+                               (int*)((char*)d_ev + tab));
+            he = hipGetLastError();
+        }
+        if (he == hipSuccess) he = hipMemcpyAsync(&bad_list, (char*)d_ev + tab, sizeof(int), hipMemcpyDeviceToHost, st);
+        if (he == hipSuccess) he = hipStreamSynchronize(st);
+        const hipError_t hf = hipFreeAsync(d_ev, st);  // (on every path: an error above must not leak the table)
+        HIP_TRY(he);
+        HIP_TRY(hf);
+        if (bad_list)
+            return fail(FFS_E_INVALID, "a boundary list of the call is truncated (more entries than its block holds) or was made for "
+                        "another vector length: nothing can solve it -- pass the vector as bits");
         return FFS_OK;
     };
     if (lists_in && (p->algo == FFS_ALGO_FFT || p->direct_only || !runs_able(dtype) || !runs_able(ref_dt))) {
@@ -1648,7 +1661,8 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                                      : p->runs_budget >= 0 ? p->runs_budget
                                                            : kRunsBudgetPerPoint * (long long)p->N * (n_cand + 1) / (2 * n_cand);
             // Lists that arrive with host-known length bounds (the rasteriser's: two entries per subtitle) settle the
-            // question on the host: within budget even at the bounds -> no flags kernel, no copy back, no wait.
+            // question on the host: within budget even at the bounds -> no flags kernel, no copy back, no wait.  A bound of
+            // RUNS_CAP or more (16-bit histogram cells, as in k_runs_chunk_flags) proves nothing: the device decides.
             bool proven = !need_extract && vec_bound != nullptr;
             for (int pi = 0; proven && pi < n_pairs; ++pi) {
                 const size_t bq = (size_t)pi * stride;
@@ -1657,7 +1671,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                     const CandDesc& cd = hc[(size_t)pi * n_cand + j];
                     if (vec_bound[bq + 1 + j] <= 0 ||
                         (!(cd.flags & CAND_NO_LAGS) &&
-                         runs_over_budget(vec_bound[bq + 1 + j], vec_bound[bq], INT64_MAX, INT64_MAX, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget)))
+                         runs_over_budget(vec_bound[bq + 1 + j], vec_bound[bq], RUNS_CAP, RUNS_CAP, (long long)cd.d_hi - cd.d_lo + 1, cd.R, budget)))
                         proven = false;
                 }
             }
@@ -1975,12 +1989,21 @@ int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, 
     ExpandVec ev{(const int2*)((const char*)list_dev + 16), (const int2*)list_dev, (unsigned*)bits_out_dev, (int32_t)len, 0};
     ExpandVec* d_ev = nullptr;
     HIP_TRY(hipMallocAsync((void**)&d_ev, sizeof ev, st));
-    HIP_TRY(hipMemcpyAsync(d_ev, &ev, sizeof ev, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // (ev is a stack temporary)
+    {
+        hipError_t hu = hipMemcpyAsync(d_ev, &ev, sizeof ev, hipMemcpyHostToDevice, st);
+        if (hu == hipSuccess) hu = hipStreamSynchronize(st);  // (ev is a stack temporary)
+        if (hu != hipSuccess) {
+            (void)hipFreeAsync(d_ev, st);
+            HIP_TRY(hu);
+        }
+    }
     const int chunks = (int)(((len + 31) / 32 + 255) / 256);
-    hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)chunks), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipFreeAsync(d_ev, st));
+    // (asynchronous: a block whose header does not fit it is never followed past its capacity -- the bits are then garbage)
+    hipLaunchKernelGGL(k_runs_expand, dim3((unsigned)chunks), dim3(256), 0, st, (const ExpandVec*)d_ev, chunks, (int*)nullptr);
+    const hipError_t he = hipGetLastError();
+    const hipError_t hf = hipFreeAsync(d_ev, st);
+    HIP_TRY(he);
+    HIP_TRY(hf);
     return FFS_OK;
 }
 

@@ -302,6 +302,41 @@ def test_truncated_list_is_an_error(torch):
     with pytest.raises(_native.NativeError) as err:
         _solve(dl, db.required_fft_length(6000), 6000, "auto", pairs_in_flight=1)
     assert "truncated" in str(err.value)
+    # the same error (not an out-of-bounds read) when the lists only get expanded for the transforms
+    with pytest.raises(_native.NativeError) as err:
+        _solve(dl, db.required_fft_length(6000), 6000, "fft", pairs_in_flight=1)
+    assert "truncated" in str(err.value)
+    # ffs_runs_to_bits on a truncated block: asynchronous, so no error -- but nothing is read or written past the block
+    blk = dl.data[int(dl.offs[0, 0]):]
+    guard = torch.full((int(dl.lens[0, 0] + 31) // 32 + 8,), -7, dtype=torch.int32, device="cuda")
+    _native.runs_to_bits(blk, int(dl.lens[0, 0]), out=guard)
+    assert (guard[int(dl.lens[0, 0] + 31) // 32:] == -7).all()
+
+
+def test_host_bounds_of_a_full_histogram_cell_prove_nothing(torch):
+    """a candidate list of 32 768 entries or more (16-bit histogram cells) must not take k_runs_corr even when
+    the caller's bounds put its coincidence count within the budget (a sparse reference): the host-side shortcut leaves
+    the decision to the device, the sub-batch goes through the transforms, records as from the bits."""
+    from ffsubsync_amd import batch
+    from ffsubsync_amd.constants import candidate_ratios
+    from workloads import synth
+
+    ratios = candidate_ratios()
+    n_sub = 17_000  # non-overlapping 0.1 s subtitles every 0.4 s: 34 000 boundaries > RUNS_CAP
+    s = (np.arange(n_sub, dtype=np.int64) * 400_000) + 1_000_000
+    cand = (s, s + 100_000, np.zeros(n_sub, dtype=np.uint8))
+    rs = np.arange(40, dtype=np.int64) * 150_000_000 + 7_000_000  # forty 20 s runs: a sparse reference
+    ref = (rs, rs + 20_000_000, np.zeros(40, dtype=np.uint8))
+    sparse = synth.make_subtitle_records(31, duration_s=6800.0)
+    recs = [(ref, cand), (ref, sparse)]
+    d_bits = batch.pairs_from_intervals(recs, ratios)
+    d_runs = batch.pairs_from_intervals(recs, ratios, lists=True)
+    assert int(d_runs.bounds[0, 1]) >= 32768
+    n_fft = d_bits.required_fft_length(6000)
+    want, _ = _solve(d_bits, n_fft, 6000, "fft", pairs_in_flight=1)
+    got, st = _solve(d_runs, n_fft, 6000, "auto", pairs_in_flight=1)
+    assert st[:3] == (1, 2, 1)  # pair 0 through the transforms, pair 1 on the run-boundary path
+    _same_records_but_f32(want, got)
 
 
 def test_interval_lists_to_records_without_a_bitmap(torch):
@@ -325,6 +360,73 @@ def test_interval_lists_to_records_without_a_bitmap(torch):
     b, st = _solve(d_runs, n_fft, 6000, "auto", pairs_in_flight=12)
     assert st[2] == 0
     _same_records(a, b)
+
+
+def test_negative_start_seconds_reaches_the_list_rasteriser(torch):
+    """``TrackSet.rasterize_runs`` takes ``start_seconds`` (speech_transformers.py:968-972) like the bit
+    rasteriser: lists and bits of the same tracks with ``start_seconds = -3`` are the same vectors (lists expanded ==
+    bits), ``pairs_from_intervals(lists=True)`` gives the records of the bit path, and both equal the restated rasteriser
+    + aligner on the host; a positive ``start_seconds`` is refused for lists."""
+    from ffsubsync_amd import _native, batch
+    from ffsubsync_amd.constants import candidate_ratios
+    from oracle import aligners_oracle as orc
+    from oracle import raster_oracle as ro
+    from workloads import synth
+
+    ratios = candidate_ratios()
+    recs = []
+    for i in range(6):
+        ref = synth.make_subtitle_records(300 + i, duration_s=900.0)
+        s, e, m = synth.make_subtitle_records(400 + i, duration_s=900.0)
+        recs.append((ref, (s + 2_110_000, e + 2_110_000, m)))
+    for ss in (-3, -0.5):
+        d_bits = batch.pairs_from_intervals(recs, ratios, start_seconds=ss)
+        d_runs = batch.pairs_from_intervals(recs, ratios, start_seconds=ss, lists=True)
+        assert np.array_equal(d_bits.lens, d_runs.lens)
+        for p in range(len(recs)):
+            for v in range(1 + len(ratios)):
+                n = int(d_bits.lens[p, v])
+                o_b, o_r = int(d_bits.offs[p, v]), int(d_runs.offs[p, v])
+                want = d_bits.data[o_b: o_b + (n + 31) // 32 * 4].view(torch.int32)
+                got = _native.runs_to_bits(d_runs.data[o_r:], n)[: (n + 31) // 32]
+                assert torch.equal(got, want), (ss, p, v)
+        n_fft = d_bits.required_fft_length(6000)
+        a, _ = _solve(d_bits, n_fft, 6000, "auto", pairs_in_flight=6)
+        b, st = _solve(d_runs, n_fft, 6000, "auto", pairs_in_flight=6)
+        assert st[2] == 0
+        _same_records(a, b)
+        # pair 0, every ratio: the restated rasteriser (the reference's own arithmetic, raster_golden-pinned) + aligner
+        (rs, re_, rm), (cs, ce, cm) = recs[0]
+        host_ref = ro.rasterize(rs, re_, rm, 1.0, 100, ss)
+        for j, ratio in enumerate(ratios):
+            o_s, o_o = orc.fft_align(host_ref, ro.rasterize(cs, ce, cm, ratio, 100, ss), 6000)
+            assert int(b[0][0, j]["offset"]) == o_o and float(b[0][0, j]["score"]) == pytest.approx(o_s, rel=1e-9), (ss, j)
+    with pytest.raises(ValueError):
+        batch.pairs_from_intervals(recs, ratios, start_seconds=2, lists=True)
+    with pytest.raises(ValueError):
+        batch.TrackSet([recs[0][1]]).rasterize_runs([0], [1.0], 100, 1.5)
+
+
+def test_batched_gss_with_a_negative_start_seconds(torch):
+    """``fit_gss_batch(start_seconds=-3)`` stays on the lists (use_lists = start_seconds <= 0) and must rasterise them with
+    that start: same recorded evaluations as the per-file search through the bit rasteriser."""
+    from ffsubsync_amd import batch_gss
+    from oracle import raster_oracle as ro
+    from workloads import synth
+
+    refs, subs = [], []
+    for i in range(5):
+        s, e, m = synth.make_subtitle_records(520 + i, duration_s=900.0)
+        truth = ro.rasterize(s, e, m, 1.0 + 0.01 * (i - 2), 100, -3)
+        refs.append(np.concatenate([np.zeros(150 + 20 * i), (truth > 0).astype(float), np.zeros(300)]))
+        subs.append((s, e, m))
+    stats = {}
+    got = batch_gss.fit_gss_batch(refs, subs, 6000, 100, -3, stats=stats)
+    assert stats["lists"] is True
+    want = batch_gss._fit_gss_batch_per_file(refs, subs, 6000, 100, -3)
+    assert [(float(s_), o, r) for (s_, o), r in got] == [(float(s_), o, r) for (s_, o), r in want]
+    zero = batch_gss.fit_gss_batch(refs, subs, 6000, 100, 0)
+    assert [o for (_, o), _ in zero] != [o for (_, o), _ in got]  # (the start does move the answer: 300 samples)
 
 
 def test_dense_stream_is_probed_and_sparse_data_returns_to_the_lists(torch):
