@@ -435,23 +435,6 @@ FFS_DEV void runs_write_cand(const CandDesc& cd, CandResult* __restrict__ cres, 
     cres[ci] = r;
 }
 
-// reference boundaries as the walk reads them: staged in LDS (pointer already moved back by the slice's first index) ...
-struct QLds {
-    const int* p;
-    FFS_DEV int one(int k) const { return p[k]; }
-    FFS_DEV int2 two(int k) const { return *reinterpret_cast<const int2*>(p + k); }  // k even
-};
-// ... or straight from the list in global memory (a reference far denser than the candidate)
-struct QGlb {
-    GEntries e;
-    int n;
-    FFS_DEV int one(int k) const {
-        const int v = k <= n ? e[k].pos : RUNS_QSENT;
-        return v < RUNS_QSENT ? v : RUNS_QSENT;
-    }
-    FFS_DEV int2 two(int k) const { return make_int2(one(k), one(k + 1)); }
-};
-
 // ---------------------------------------------------------------------------------------------------------------
 // Multi-level references (round 5).  The `weighted` fused VAD hands the aligner 0.6 * silero + 0.4 * webrtc
 // (speech_transformers.py:290-293): four levels {l, .4 + .6 l, .6 + .4 l, 1} (l = non_speech_label), a float vector.
@@ -682,23 +665,33 @@ FFS_DEV unsigned lds_list_bits32(const int* ent, int k0, int cnt, long long star
     return m;
 }
 
-// grid = (candidates of the call, tiles_max); block = 512 threads, four workgroups per CU (<= 64 VGPRs, 39 KB of LDS);
-// tile t of a candidate covers the lags [d_lo + t*RUNS_T, ...] of its window.
+// grid = (pairs * split, tiles_max); block = 512 threads, four workgroups per CU (<= 64 VGPRs, 39 KB of LDS).  Workgroup
+// (pair, j0) solves the candidates j0, j0 + split, ... of its pair one after the other (split = n_cand: one candidate per
+// workgroup; split = 1: the whole pair) -- the reference's boundary list is staged in LDS ONCE for all of them; tile t of
+// a candidate covers the lags [d_lo + t*RUNS_T, ...] of its window.  Per candidate:
 //   0. the four 32-sample windows of the two vectors a thread needs for the one-sided counts (the samples that enter /
 //      leave the overlap at its RUNS_LPT lags) are requested first -- from the bits, or, for a vector that exists as a
 //      list only, from the stretch of its list that the tile's lags can touch (four waves stage one stretch each);
 //   1. zero the tile's second-difference array (16 bits per lag in 32-bit LDS words: the sum of all additions to a
-//      word is v_lo + 65536 * v_hi as an integer, so both halves are recovered exactly whatever the borrows did), stage
-//      the reference's boundary list in LDS (all global loads of a thread in flight together);
-//   2. ONE candidate boundary p per lane, 64 consecutive ones per wave task, RUNS_TPW tasks of a wave advanced together:
-//      a binary search into the staged list gives the first boundary q >= p + D0 AND (through the list's ones-in-front
-//      column) the ones of the reference in front of p + D0 -- summed over p that is n11(D0), and g(D0) is the sum of
-//      the parities -- then the lane walks the q's up to p + D1 two at a time (an aligned 8-byte LDS read = one run of
-//      the reference: start +, end -) and adds +-1 at lag q - p (ds_add_u32, fire and forget).  An LDS atomic costs the
-//      same ~7.5 cycles per wave-instruction whatever its active lanes or banks (profiles/lds_atomic_ceiling.hip), so
-//      what matters is that the lanes of a wave have windows of similar length -- consecutive p's do;
-//   3. two block scans (DPP inside a wave, one barrier each) turn h into g and n11 for the thread's RUNS_LPT consecutive
-//      lags; the one-sided counts follow from their values at D0 and the windows of step 0;
+//      word is v_lo + 65536 * v_hi as an integer, so both halves are recovered exactly whatever the borrows did); the
+//      reference's list sits in LDS with its positions DOUBLED (lag differences then come out doubled: the histogram
+//      word's byte address is d2 & ~3 and the 16-bit half (d2 & 2) << 3 -- one instruction each);
+//   2. ONE candidate boundary p per lane, 64 consecutive ones per wave task, RUNS_TPW tasks of a wave advanced together,
+//      UNIFORM CONTROL FLOW (round 6): a binary search of a fixed number of steps gives the first boundary q >= p + D0 AND
+//      (through the list's ones-in-front column) the ones of the reference in front of p + D0 -- summed over p that is
+//      n11(D0), and g(D0) is the sum of the parities -- then every lane walks the q's two at a time (an aligned 8-byte LDS
+//      read = one run of the reference: start +, end -) and adds +-1 at lag q - p when that lag lies in the tile
+//      (ds_add_u32, fire and forget); a lane that has passed its window keeps reading (its lags are out of range, its
+//      list index stops at the sentinel pair) until no lane of the wave's tasks has anything left -- no per-task masks,
+//      no per-lane branches: the round-5 loop spent two scalar instructions per vector instruction on exec-mask
+//      bookkeeping (98 k SALU per pair).  An LDS atomic to random words costs ~7.4 cycles per wave-instruction (bank
+//      conflicts; 4.1 conflict-free: profiles/lds_issue_rates.hip), so what matters is that the lanes of a wave have
+//      windows of similar length -- consecutive p's do;
+//   3. ONE block scan (DPP inside a wave, one barrier) turns h into g and n11 at every thread's first lag: with
+//      hs = sum of the thread's h, ws = sum_k (LPT - k) h[k] and the thread index t,
+//          g_c = g_0 - A,   n11_c = n11_0 + LPT t g_0 - LPT ((t - 1) A - B) - C,
+//      A / B / C the exclusive prefixes of hs / t hs / ws (round 5: two dependent scans and two passes over h); the
+//      one-sided counts follow from their values at D0 and the windows of step 0 (same scan);
 //   4. every lag is scored in fp32 (4 fused multiply-adds, branch-free); lags within the rounding-error bound of the
 //      block's best fp32 value are re-evaluated with exact_score()'s fp64 expression; block argmax over those, ties to the
 //      largest lag;
@@ -709,53 +702,120 @@ constexpr int RUNS_EDGE = 96;  // list entries staged per edge window stretch (d
 #ifndef FFS_RUNS_WPS
 #define FFS_RUNS_WPS 8
 #endif
+constexpr int RUNS_X_NONE = 0x7fffffff;  // doubled position of a lane without a boundary: beyond the doubled sentinel
+
+// reference boundaries as the walk reads them, positions DOUBLED: staged in LDS (pointer already moved back by the slice's
+// first index) ...
+struct QLds2 {
+    const int* p;
+    FFS_DEV int one(int k) const { return p[k]; }
+    FFS_DEV int2 two(int k) const { return *reinterpret_cast<const int2*>(p + k); }  // k even
+};
+// ... or straight from the list in global memory (a reference far denser than the candidate)
+struct QGlb2 {
+    GEntries e;
+    int n;
+    FFS_DEV int one(int k) const {
+        const int v = k <= n ? e[k].pos : RUNS_QSENT;
+        return 2 * (v < RUNS_QSENT ? v : RUNS_QSENT);
+    }
+    FFS_DEV int2 two(int k) const { return make_int2(one(k), one(k + 1)); }
+};
+
+// exclusive scan over the NW * 64 threads of a block of five ints at once (s_tmp: NW x 8 ints); wrap-around arithmetic; ONE
+// barrier (the caller alternates between two s_tmp buffers, so a second scan cannot overwrite totals still being read)
+template <int NW>
+FFS_DEV void block_excl_scan5_dpp(int (&v)[5], int* s_tmp, int lane, int wave) {  // (wave: uniform, in a scalar register)
+    int in[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) in[k] = (int)wave_incl_scan_u32((unsigned)v[k]);
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) s_tmp[wave * 8 + k] = in[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 5; ++k) v[k] = in[k] - v[k];
+#pragma unroll
+    for (int i = 0; i < NW - 1; ++i)
+        if (i < wave) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += s_tmp[i * 8 + k];
+        }
+}
+
 // ML: the reference is a multi-level vector given as up to three threshold lists refs[n_vec_all + 3 pair + k] with the
 // multiplicities of linfo[pair] (see LevelInfo); the levels are processed one after the other into the same histogram.
 template <bool ML>
 FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs,
                             CandResult* __restrict__ cres, RunsBest* __restrict__ best, int tiles_max,
                             const int* __restrict__ chunk_flags, int pairs_per_chunk, const LevelInfo* __restrict__ linfo,
-                            int n_vec_all) {
+                            int n_vec_all, int split) {
     __shared__ __attribute__((aligned(16))) unsigned hist[RUNS_T / 2 + 4];  // second difference h of the tile's lags, 16 bits per lag
-    __shared__ __attribute__((aligned(16))) int q_lds[RUNS_QCAP + 4];
+    __shared__ __attribute__((aligned(16))) int q_lds[RUNS_QCAP + 4];       // DOUBLED positions
     __shared__ int s_edge[4][RUNS_EDGE];
     __shared__ int s_ek0[4], s_ecnt[4];
-    __shared__ int s_tmp[2][RUNS_WAVES * 4];
+    __shared__ __attribute__((aligned(16))) int s_tmp[2][RUNS_WAVES * 8];
     __shared__ double s_sc[RUNS_WAVES];
     __shared__ int s_d[RUNS_WAVES];
     __shared__ float s_m[RUNS_WAVES];
-    const int ci = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pair = ci / n_cand;
+    const int tile = blockIdx.y, tid0 = threadIdx.x;
+    const int pair = (int)blockIdx.x / split, j_first = (int)blockIdx.x - pair * split;
     if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
-    const int vr = pair * (n_cand + 1), vs = vr + 1 + (ci - pair * n_cand);
+    const int vr = pair * (n_cand + 1);
     const int vr0 = ML ? n_vec_all + 3 * pair : vr;  // (first) list of the reference
     RunsRef rr = refs[vr0];
-    const RunsRef rs_ = refs[vs];  // (independent of the descriptor: the three loads travel together)
-    const CandDesc cd = cands[ci];
     LevelInfo li;
     int n_lv = 1;
     if (ML) {
         li = linfo[pair];
         n_lv = li.n_levels - 1;
     }
+    GEntries Qe = (GEntries)rr.e;
+    GWords rbits = (GWords)rr.bits;
+    int n_q = ((GInts)rr.hdr)[0];
+    // the reference's whole list in LDS, once for every candidate of this workgroup (ML: one list per level and candidate)
+    const bool pair_staged = !ML && n_q <= RUNS_QCAP;
+    auto stage_whole = [&](int tid) {
+        constexpr int NST = (RUNS_QCAP + 2 + RUNS_THREADS - 1) / RUNS_THREADS;
+        int qv[NST];
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int k = tid + u * RUNS_THREADS;
+            qv[u] = k <= n_q ? Qe[k].pos : RUNS_QSENT;
+        }
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int k = tid + u * RUNS_THREADS;
+            if (k <= n_q + 1) q_lds[k] = 2 * (qv[u] < RUNS_QSENT ? qv[u] : RUNS_QSENT);
+        }
+    };
+    if (pair_staged) stage_whole(tid0);  // (the first candidate's barrier behind the zeroing covers it)
+    bool first_cand = true;
+    for (int jc = j_first; jc < n_cand; jc += split) {
+    // (the thread index is made opaque once per candidate: everything derived from it -- LDS addresses, lane masks of the
+    // wave-prefix sums -- would otherwise be hoisted out of this loop and spilled: 38 VGPRs + 48 SGPRs)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ci = pair * n_cand + jc, vs = vr + 1 + jc;
+    const RunsRef rs_ = refs[vs];
+    const CandDesc cd = cands[ci];
     if (cd.flags & CAND_NO_LAGS) {
         if (tile == 0 && tid == 0) {
             runs_write_cand(cd, cres, ci, 0.0, 0, true);
         }
-        return;
+        continue;
     }
     const int W = cd.d_hi - cd.d_lo + 1;
     const int n_tiles = (W + RUNS_T - 1) / RUNS_T;
-    if (tile >= n_tiles) return;
+    if (tile >= n_tiles) continue;
     const int S = cd.S, R = cd.R;
     const int D0 = cd.d_lo + tile * RUNS_T;
     const int Wt = (cd.d_hi - D0 + 1) < RUNS_T ? (cd.d_hi - D0 + 1) : RUNS_T;
     const GEntries Pe = (GEntries)rs_.e;
-    GEntries Qe = (GEntries)rr.e;
     const GWords sbits = (GWords)rs_.bits;
-    GWords rbits = (GWords)rr.bits;
     const int n_p = ((GInts)rs_.hdr)[0];
-    int n_q = ((GInts)rr.hdr)[0];
     const int c = tid * RUNS_LPT;  // this thread's lags: D0 + c .. D0 + c + RUNS_LPT - 1
     // the samples that enter (+) and leave (-) the two one-sided counts when the lag grows by one, lag c + i = bit i:
     //   n1x(d+1) = n1x(d) + b[-d-1] - b[R-d-1],   nx1(d+1) = nx1(d) - rho[d] + rho[S+d]   (zero outside the vectors)
@@ -785,6 +845,8 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         m_outx1 = fetch32(rbits, R, dc);
         m_inx1 = fetch32(rbits, R, (long long)S + dc);
     }
+    if (!first_cand) __syncthreads();  // the previous candidate's readers of hist / s_edge / s_tmp / s_sc are done
+    first_cand = false;
     if (!ML && (!sbits || !rbits) && wave < 4) {
         // list-only vectors: wave w stages the stretch of the list that window w of ANY thread of the tile can touch
         // (windows: 0 b[-d-1], 1 b[R-d-1], 2 rho[d], 3 rho[S+d] over the tile's lags D0 .. D0 + RUNS_T - 1)
@@ -810,6 +872,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
     const int wmax = Wt - 2;                      // h is needed for the lags D0 .. D1 - 1
     const int wlim = wmax >= 0 ? wmax : 0;        // (a one-lag tile never reads h: a stray add at 0 is harmless)
+    const unsigned wlim2 = 2u * (unsigned)wlim;   // (positions are doubled in the walk)
     int n11p = 0, gp = 0, bsum = 0, rsum_all = 0;
     bool any_sliced = false;
     for (int lv = 0; lv < n_lv; ++lv) {  // (one pass unless ML)
@@ -826,27 +889,17 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     }
     const bool whole = n_q <= RUNS_QCAP;  // the reference's whole list fits the staging area
     any_sliced |= !whole;
+    if (whole && !pair_staged) stage_whole(tid);
+    __syncthreads();  // hist is zero, the list is staged
     // ones of rho in [0, x) = sum_k sgn_k * min(x, Q[k]) (sgn = -1 at run starts, +1 at run ends): the two positions
     // that bound the overlap at lag D0
     const int r_lo = D0 > 0 ? D0 : 0, r_hi = (S + D0) < R ? (S + D0) : R;
     int rsum = 0;
     if (whole) {
-        constexpr int NST = (RUNS_QCAP + 2 + RUNS_THREADS - 1) / RUNS_THREADS;
-        int qv[NST];
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int k = tid + u * RUNS_THREADS;
-            qv[u] = k <= n_q ? Qe[k].pos : RUNS_QSENT;
-        }
-#pragma unroll
-        for (int u = 0; u < NST; ++u) {
-            const int k = tid + u * RUNS_THREADS;
-            const int q1 = qv[u] < RUNS_QSENT ? qv[u] : RUNS_QSENT;
-            if (k <= n_q + 1) q_lds[k] = q1;
-            if (k < n_q) {
-                const int m_hi = q1 < r_hi ? q1 : r_hi, m_lo = q1 < r_lo ? q1 : r_lo;
-                rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
-            }
+        for (int k = tid; k < n_q; k += RUNS_THREADS) {
+            const int q1 = q_lds[k] >> 1;
+            const int m_hi = q1 < r_hi ? q1 : r_hi, m_lo = q1 < r_lo ? q1 : r_lo;
+            rsum += (k & 1) ? (m_hi - m_lo) : (m_lo - m_hi);
         }
     } else {
         for (int k = tid; k < n_q; k += RUNS_THREADS) {
@@ -856,7 +909,6 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         }
     }
     rsum_all += wk * rsum;
-    __syncthreads();
 #if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 1
     if (n_q >= 0) return;
 #endif
@@ -880,79 +932,82 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     }
     // RUNS_TPW wave tasks at a time -- 64 consecutive candidate boundaries each, one per lane, task t of a wave = boundaries
     // r0 + (t * RUNS_WAVES + wave) * 64 + lane -- advanced TOGETHER: every step of the binary searches and of the walks
-    // issues the tasks' LDS reads back to back and waits once, so a wave is stalled for one LDS latency per step instead of
-    // one per task and step.  [lo, hi] = stretch of the reference's list readable through Q.
-    auto tasks = [&](auto Q, int r0, int r1, int lo, int hi) {
-        int x[RUNS_TPW], j[RUNS_TPW], sa[RUNS_TPW], lb[RUNS_TPW], a[RUNS_TPW], b[RUNS_TPW], ones[RUNS_TPW];
-        bool valid[RUNS_TPW], more[RUNS_TPW];
+    // issues the tasks' LDS reads back to back and waits once.  [lo, hi] = stretch of the reference's list readable
+    // through Q (Q(hi) lies beyond every window of the round), jmax = even index of a readable pair beyond every window.
+    // Doubled positions throughout (x2 = 2 (p + D0)); a lane without a boundary carries x2 = RUNS_X_NONE: its search ends at
+    // hi + 1 (readable), every lag of its walk is out of range.
+    auto tasks = [&](auto Q, int r0, int r1, int lo, int hi, int jmax) {
+        int x2[RUNS_TPW], j[RUNS_TPW], ones[RUNS_TPW], a[RUNS_TPW], b[RUNS_TPW];
+        const int sgn = (lane & 1) ? -wk : wk;  // db[p] (times the level's multiplicity): r0 and the task bases are even
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
             const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
-            valid[t] = i < r1;
-            x[t] = valid[t] ? Pe[i].pos + D0 : 0;
-            a[t] = lo, b[t] = valid[t] ? hi : lo;  // first k in [lo, hi] with Q(k) >= x
-            sa[t] = ((i & 1) ? -1 : 1) * wk;       // db[p] (times the level's multiplicity)
+            x2[t] = i < r1 ? Pe[i].pos : -1;
         }
-        for (;;) {
-            bool any = false;
+#pragma unroll
+        for (int t = 0; t < RUNS_TPW; ++t) {
+            const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
+            x2[t] = i < r1 ? 2 * (x2[t] + D0) : RUNS_X_NONE;
+            a[t] = lo, b[t] = hi;  // first k in [lo, hi] with Q(k) >= x
+        }
+        const int steps = hi > lo ? 32 - __clz(hi - lo) : 0;  // (uniform: no per-lane exit test)
+        for (int s_ = 0; s_ < steps; ++s_) {
             int m[RUNS_TPW], qm[RUNS_TPW];
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) {
                 m[t] = (a[t] + b[t]) >> 1;
-                qm[t] = a[t] < b[t] ? Q.one(m[t]) : 0;
+                qm[t] = Q.one(m[t]);
             }
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) {
-                if (a[t] < b[t]) {
-                    if (qm[t] < x[t])
-                        a[t] = m[t] + 1;
-                    else
-                        b[t] = m[t];
-                    any |= a[t] < b[t];
-                }
+                const bool lt = qm[t] < x2[t];
+                a[t] = lt ? m[t] + 1 : a[t];
+                b[t] = lt ? b[t] : m[t];
             }
-            if (!__any(any)) break;
         }
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
-            lb[t] = a[t];
-            ones[t] = valid[t] ? Qe[lb[t]].ones : 0;  // (the sentinel entry holds all ones); consumed after the walks
-            j[t] = lb[t] & ~1;  // the reference's run that contains or follows x: (start, end) = entries (j, j + 1)
-            more[t] = valid[t];
+            const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
+            const bool valid = i < r1;
+            const int lb = a[t];
+            ones[t] = valid ? Qe[lb].ones : 0;  // (the sentinel entry holds all ones); consumed after the walks
+            const int odd = lb & 1;
+            // inside a run: the run's ones from x on are not in front of x
+            const int corr = (valid && odd) ? (Q.one(lb) - x2[t]) >> 1 : 0;
+            const int sv = valid ? sgn : 0;
+            n11p += sv * corr;
+            gp -= sv * odd;
+            if (!ML || lv == 0) {  // (the candidate's own count: once, without the multiplicity)
+                const int p = (x2[t] >> 1) - D0;
+                const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
+                if (valid) bsum -= ((lane & 1) ? -1 : 1) * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
+            }
+            j[t] = lb & ~1;  // the reference's run that contains or follows x: (start, end) = entries (j, j + 1)
+            j[t] = j[t] < jmax ? j[t] : jmax;
         }
-        for (;;) {
+        // (every trip moves each lane two entries on until it sits on the pair at jmax: at most (jmax - lo) / 2 + 1 trips do
+        // anything -- the bound only guards against a kernel that cannot end)
+        for (int trips = ((jmax - (lo & ~1)) >> 1) + 2; trips > 0; --trips) {
             int2 qq[RUNS_TPW];
 #pragma unroll
-            for (int t = 0; t < RUNS_TPW; ++t) qq[t] = more[t] ? Q.two(j[t]) : make_int2(0, 0);
+            for (int t = 0; t < RUNS_TPW; ++t) qq[t] = Q.two(j[t]);
             bool any = false;
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) {
-                if (more[t]) {
-                    const int da = qq[t].x - x[t], db = qq[t].y - x[t];
-                    // + at run starts (even entries), - at run ends; lag d = bits 16 (d & 1) .. of word d >> 1
-                    if ((unsigned)da <= (unsigned)wlim) atomicAdd(&hist[da >> 1], (unsigned)sa[t] << ((da & 1) * 16));
-                    if ((unsigned)db <= (unsigned)wlim) atomicAdd(&hist[db >> 1], (unsigned)(-sa[t]) << ((db & 1) * 16));
-                    more[t] = db <= wlim;  // an end beyond the window: so is everything behind it
-                    j[t] += 2;
-                    any |= more[t];
-                }
+                const int da = qq[t].x - x2[t], db = qq[t].y - x2[t];  // doubled lags
+                // + at run starts (even entries), - at run ends; lag d = bits 16 (d & 1) .. of word d >> 1
+                if ((unsigned)da <= wlim2) atomicAdd(&hist[(unsigned)da >> 2], (unsigned)sgn << ((da & 2) << 3));
+                if ((unsigned)db <= wlim2) atomicAdd(&hist[(unsigned)db >> 2], (unsigned)(-sgn) << ((db & 2) << 3));
+                // an end beyond the window: so is everything behind it (unsigned: a lane without a boundary sits below
+                // every entry -- negative -- and must not keep the loop alive; a boundary's own first end is never negative)
+                any |= (unsigned)db <= wlim2;
+                const int jn = j[t] + 2;
+                j[t] = jn < jmax ? jn : jmax;
             }
             if (!__any(any)) break;
         }
 #pragma unroll
-        for (int t = 0; t < RUNS_TPW; ++t) {
-            if (valid[t]) {
-                int o = ones[t];
-                if (lb[t] & 1) o -= Q.one(lb[t]) - x[t];  // inside a run: the run's ones from x on are not in front of x
-                n11p -= sa[t] * o;
-                gp -= sa[t] * (lb[t] & 1);
-                if (!ML || lv == 0) {  // (the candidate's own count: once, without the multiplicity)
-                    const int p = x[t] - D0;
-                    const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
-                    bsum -= (sa[t] < 0 ? -1 : 1) * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
-                }
-            }
-        }
+        for (int t = 0; t < RUNS_TPW; ++t) n11p -= sgn * ones[t];  // (ones = 0 for a lane without a boundary)
     };
     // Rounds of RUNS_ROUND consecutive candidate boundaries.  A reference list that does not fit the staging area is staged
     // slice by slice: the q's a round can meet are one stretch [first q >= P[first] + D0, first q beyond P[last] + D1],
@@ -974,16 +1029,16 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             st_lo = s_tmp[0][0] & ~1, st_hi = s_tmp[0][1];
             staged_ok = st_hi - st_lo <= RUNS_QCAP;
             if (staged_ok)
-                for (int k = st_lo + tid; k <= st_hi + 1; k += RUNS_THREADS) {
+                for (int k = st_lo + tid; k <= st_hi + 2; k += RUNS_THREADS) {  // (two entries beyond: the pair at jmax)
                     const int qv = k <= n_q ? Qe[k].pos : RUNS_QSENT;
-                    q_lds[k - st_lo] = qv < RUNS_QSENT ? qv : RUNS_QSENT;
+                    q_lds[k - st_lo] = 2 * (qv < RUNS_QSENT ? qv : RUNS_QSENT);
                 }
             __syncthreads();
         }
         if (staged_ok)
-            tasks(QLds{q_lds - st_lo}, r0, r1, st_lo, st_hi);
+            tasks(QLds2{q_lds - st_lo}, r0, r1, st_lo, st_hi, whole ? n_q : ((st_hi + 1) & ~1));
         else
-            tasks(QGlb{Qe, n_q}, r0, r1, 0, n_q);
+            tasks(QGlb2{Qe, n_q}, r0, r1, 0, n_q, n_q);
     }
     }  // levels
     int rsum = rsum_all;
@@ -997,58 +1052,45 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         wave_incl_scan3(rsum, z, z);
     }
     if (any_sliced) __syncthreads();  // (s_tmp[0] held the slice bounds)
-    if (lane == 63) s_tmp[0][wave * 4] = n11p, s_tmp[0][wave * 4 + 1] = gp, s_tmp[0][wave * 4 + 2] = bsum, s_tmp[0][wave * 4 + 3] = rsum;
+    if (lane == 63) s_tmp[0][wave * 8] = n11p, s_tmp[0][wave * 8 + 1] = gp, s_tmp[0][wave * 8 + 2] = bsum, s_tmp[0][wave * 8 + 3] = rsum;
     __syncthreads();  // also: every addition to hist has landed
     int n11_0 = 0, g_0 = 0, n1x_0 = 0, nx1_0 = 0;
 #pragma unroll
     for (int wv = 0; wv < RUNS_WAVES; ++wv)
-        n11_0 += s_tmp[0][wv * 4], g_0 += s_tmp[0][wv * 4 + 1], n1x_0 += s_tmp[0][wv * 4 + 2], nx1_0 += s_tmp[0][wv * 4 + 3];
+        n11_0 += s_tmp[0][wv * 8], g_0 += s_tmp[0][wv * 8 + 1], n1x_0 += s_tmp[0][wv * 8 + 2], nx1_0 += s_tmp[0][wv * 8 + 3];
 
     // The thread's lags are walked four at a time (one aligned 8-byte LDS read = two words = four lags) in ROLLED loops:
-    // unrolled, the four passes below keep dozens of unpacked values alive and the kernel spills at 64 registers.
+    // unrolled, the passes below keep dozens of unpacked values alive and the kernel spills at 64 registers.
     const uint2* hq = reinterpret_cast<const uint2*>(hist + (c >> 1));
     auto unpack4 = [&](int q4, int (&h)[4]) {
         const uint2 w = hq[q4];
         const int a0 = (int)(short)(w.x & 0xffffu), b0 = (int)(short)(w.y & 0xffffu);
         h[0] = a0, h[1] = (int)(w.x - (unsigned)a0) >> 16, h[2] = b0, h[3] = (int)(w.y - (unsigned)b0) >> 16;
     };
-    int hs = 0;
+    int hs = 0, ws = 0;  // sum of the thread's h; sum_k (LPT - k) h[k]
 #pragma unroll 1
     for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
         int h[4];
         unpack4(q4, h);
-        hs += (h[0] + h[1]) + (h[2] + h[3]);
+        const int s4 = (h[0] + h[1]) + (h[2] + h[3]);
+        hs += s4;
+        ws += (RUNS_LPT - 4 * q4) * s4 - (h[1] + 2 * h[2] + 3 * h[3]);
     }
     constexpr unsigned lpt_mask = RUNS_LPT == 32 ? 0xffffffffu : ((1u << RUNS_LPT) - 1u);
-    int d1x = __popc(m_in1x & lpt_mask) - __popc(m_out1x & lpt_mask);
-    int dx1 = __popc(m_inx1 & lpt_mask) - __popc(m_outx1 & lpt_mask);
+    int sc5[5];
+    sc5[0] = hs, sc5[1] = tid * hs, sc5[2] = ws;
+    sc5[3] = __popc(m_in1x & lpt_mask) - __popc(m_out1x & lpt_mask);
+    sc5[4] = __popc(m_inx1 & lpt_mask) - __popc(m_outx1 & lpt_mask);
     if (ML) {
-        dx1 = 0;
+        sc5[4] = 0;
 #pragma unroll
-        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) dx1 += wx1g[g4];
+        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) sc5[4] += wx1g[g4];
     }
-    int hpre = hs;
-    block_excl_scan3_dpp<RUNS_WAVES>(hpre, d1x, dx1, s_tmp[1]);  // exclusive prefixes
-    const int g_c = g_0 - hpre;  // g at the thread's first lag
-    int gs = 0;
-    {
-        int g = g_c;
-#pragma unroll 1
-        for (int q4 = 0; q4 < RUNS_LPT / 4; ++q4) {
-            int h[4];
-            unpack4(q4, h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                g -= h[e];
-                gs += g;
-            }
-        }
-    }
-    {
-        int z0 = 0, z1 = 0;
-        block_excl_scan3_dpp<RUNS_WAVES>(gs, z0, z1, s_tmp[0]);
-    }
-    const int n11_c = n11_0 + gs, n1x_c = n1x_0 + d1x, nx1_c = nx1_0 + dx1;  // the counts at the thread's first lag
+    block_excl_scan5_dpp<RUNS_WAVES>(sc5, s_tmp[1], lane, wave);  // exclusive prefixes A, B, C and of the one-sided counts' changes
+    const int g_c = g_0 - sc5[0];  // g at the thread's first lag
+    // n11 at the thread's first lag (wrap-around arithmetic: exact whenever the result fits, which it does)
+    const int n11_c = n11_0 + RUNS_LPT * tid * g_0 - RUNS_LPT * ((tid - 1) * sc5[0] - sc5[1]) - sc5[2];
+    const int n1x_c = n1x_0 + sc5[3], nx1_c = nx1_0 + sc5[4];  // the counts at the thread's first lag
 #if defined(FFS_RUNS_STOP) && FFS_RUNS_STOP == 4
     if (n_q >= 0) {
         if (n11_c == 0x7fffffff) best[0].d = n1x_c + nx1_c;
@@ -1081,7 +1123,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         return fmaf(f1x, (float)a1x, fmaf(fx1, (float)ax1, f0 * (float)ov));
     };
     float tmax = -INFINITY;
-    {
+    auto prefilter = [&](auto masked) {  // (masked: the thread's lags beyond `lim` do not count -- the tile's last threads only)
         int g = g_c, a11 = n11_c, a1x = n1x_c, ax1 = nx1_c;
         unsigned mi1 = m_in1x, mo1 = m_out1x, mix = m_inx1, mox = m_outx1;
 #pragma unroll 1
@@ -1092,7 +1134,10 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float f = fmaf(f11, (float)a11, e32);
-                tmax = fmaxf(tmax, (4 * q4 + e) < lim ? f : -INFINITY);
+                if (decltype(masked)::value)
+                    tmax = fmaxf(tmax, (4 * q4 + e) < lim ? f : -INFINITY);
+                else
+                    tmax = fmaxf(tmax, f);
                 g -= h[e];
                 a11 += g;
             }
@@ -1107,7 +1152,11 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             }
             mi1 >>= 4, mo1 >>= 4, mix >>= 4, mox >>= 4;
         }
-    }
+    };
+    if (lim >= RUNS_LPT)
+        prefilter(std::false_type{});
+    else if (lim > 0)
+        prefilter(std::true_type{});
     float wm = tmax;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) wm = fmaxf(wm, __shfl_xor(wm, s, 64));
@@ -1183,19 +1232,19 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     }
 #endif
     // block argmax: larger score, then larger lag
-    double ws = bs;
+    double ws_ = bs;
     int wd = bd;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
-        const double os = __shfl_xor(ws, s, 64);
+        const double os = __shfl_xor(ws_, s, 64);
         const int od = __shfl_xor(wd, s, 64);
-        if (os > ws || (os == ws && od > wd)) ws = os, wd = od;
+        if (os > ws_ || (os == ws_ && od > wd)) ws_ = os, wd = od;
     }
-    if (lane == 0) s_sc[wave] = ws, s_d[wave] = wd;
+    if (lane == 0) s_sc[wave] = ws_, s_d[wave] = wd;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < RUNS_WAVES; ++i)
-        if (s_sc[i] > ws || (s_sc[i] == ws && s_d[i] > wd)) ws = s_sc[i], wd = s_d[i];
+        if (s_sc[i] > ws_ || (s_sc[i] == ws_ && s_d[i] > wd)) ws_ = s_sc[i], wd = s_d[i];
     if (bd == wd && wd != INT32_MIN) {  // the one thread that owns the winning lag
         if (n_tiles == 1) {
             runs_write_cand(cd, cres, ci, bs, bd, false);
@@ -1204,19 +1253,20 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             o.score = bs, o.d = bd;
         }
     }
+    }  // candidates of this workgroup
 }
 
 __global__ __launch_bounds__(RUNS_THREADS, FFS_RUNS_WPS) void k_runs_corr(
     const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
-    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk) {
-    runs_corr_body<false>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, nullptr, 0);
+    RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk, int split) {
+    runs_corr_body<false>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, nullptr, 0, split);
 }
 // multi-level references (threshold lists + LevelInfo); a few more registers: three workgroups per CU
 __global__ __launch_bounds__(RUNS_THREADS, 6) void k_runs_corr_ml(
     const CandDesc* __restrict__ cands, int n_cand, const RunsRef* __restrict__ refs, CandResult* __restrict__ cres,
     RunsBest* __restrict__ best, int tiles_max, const int* __restrict__ chunk_flags, int pairs_per_chunk,
     const LevelInfo* __restrict__ linfo, int n_vec_all) {
-    runs_corr_body<true>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, linfo, n_vec_all);
+    runs_corr_body<true>(cands, n_cand, refs, cres, best, tiles_max, chunk_flags, pairs_per_chunk, linfo, n_vec_all, n_cand);
 }
 
 // Multi-level flags: sub-batch = 1 when a reference of it is not usable (LevelInfo.ok == 0, a truncated threshold list, a

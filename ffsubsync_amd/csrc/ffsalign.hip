@@ -95,6 +95,8 @@ constexpr unsigned kPoolCapacity = 1u << 20;
 // +-60 s window: ~20 per point of N = 3 * 2^18 (lists of 17 k x 20 k boundaries); no window: ~13 per point of N = 3 * 2^19
 // (118 lag tiles per candidate cost as much as 6 M coincidences).  Twelve keeps the choice on the winning side in both.
 constexpr long long kRunsBudgetPerPoint = 12;
+// k_runs_corr: calls of at least this many pairs give every workgroup a whole pair (4 resident workgroups x 256 CUs x 2)
+constexpr int kRunsPairsPerWorkgroupFrom = 2048;
 constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
@@ -213,6 +215,7 @@ struct ffs_plan {
     // transforms; FFS_ALGO_FFT never uses it; FFS_ALGO_RUNS ignores the coincidence budget (truncated lists still go
     // through the transforms).  Buffers grown on demand.
     int algo = FFS_ALGO_AUTO;
+    int runs_split = 0;                 // FFS_RUNS_SPLIT: workgroups per pair in k_runs_corr (0: the rule at the launch site)
     long long runs_budget = -1;         // FFS_RUNS_BUDGET: boundary coincidences per candidate above which the transforms take over (-1: the rule in ffs_plan_create)
     int2* runs_e = nullptr;             // [vectors][RUNS_CAP] (boundary position, ones in front of it) of the vectors that arrive as bits
     int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
@@ -1020,6 +1023,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         // within ~10 % of the other around the threshold.  FFS_RUNS_BUDGET=<coincidences> overrides it.
         p->runs_budget = -1;
         if (const char* eb = getenv("FFS_RUNS_BUDGET")) p->runs_budget = atoll(eb);
+        if (const char* es = getenv("FFS_RUNS_SPLIT")) p->runs_split = atoi(es);
         if (const char* et = getenv("FFS_HOST_TIMING")) p->host_timing = et[0] == '1';
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
@@ -1728,9 +1732,16 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                     hipLaunchKernelGGL(k_runs_corr_ml, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st, dc, n_cand,
                                        (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight,
                                        (const LevelInfo*)(db + o_li), (int)n_vec);
-                else
-                hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)n_cands, (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st, dc, n_cand,
-                                   (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight);
+                else {
+                    // One workgroup per PAIR when the call has enough pairs to fill the chip that way (the reference's list is
+                    // then staged once for the pair's candidates), one per candidate otherwise (and for windows of several
+                    // tiles).  FFS_RUNS_SPLIT overrides (A/B).
+                    int split = (tiles_max == 1 && n_pairs >= kRunsPairsPerWorkgroupFrom) ? 1 : n_cand;
+                    if (p->runs_split > 0) split = p->runs_split < n_cand ? p->runs_split : n_cand;
+                    hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)((size_t)n_pairs * split), (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st,
+                                       dc, n_cand, (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight,
+                                       split);
+                }
                 if (tiles_max > 1)
                     hipLaunchKernelGGL(k_runs_pick, dim3((unsigned)((n_cands + 255) / 256)), dim3(256), 0, st, dc, (int)n_cands, n_cand,
                                        p->runs_best, tiles_max, cres, d_flags, p->pairs_in_flight);
