@@ -36,7 +36,7 @@ constexpr int RUNS_LPT = RUNS_T / RUNS_THREADS;   // consecutive lags per thread
 constexpr int RUNS_QCAP = 3070;                   // reference boundaries staged in LDS at a time (longer lists: slice by slice)
 constexpr int RUNS_CAP = 32768;                   // boundary-list entries per vector incl. the sentinel (plan-owned lists)
 #ifndef FFS_RUNS_TPW
-#define FFS_RUNS_TPW 4
+#define FFS_RUNS_TPW 2
 #endif
 constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate boundaries each) a wave advances together
 constexpr int RUNS_QSENT = 0x3fffffff;            // staged sentinel: beyond every position (vectors are shorter than 2^30)
@@ -132,6 +132,20 @@ FFS_DEV unsigned wave_incl_scan_u32(unsigned v) {  // inclusive prefix sum over 
     // (the same six steps as one inline-asm v_add_u32_dpp each -- with the s_nop the DPP hazard needs -- measured 10 % slower)
 #undef FFS_DPP_ADD
     return v;
+}
+
+// maximum over the 64 lanes of a wave, DPP only (no ds_bpermute round trips): the same six steps as the prefix sum; every
+// lane receives the result of lane 63 (a uniform value: v_readlane)
+FFS_DEV float wave_max_f32(float v) {
+#define FFS_DPP_MAX(ctrl, rows) v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), ctrl, rows, 0xf, false)))
+    FFS_DPP_MAX(0x111, 0xf);  // row_shr:1 (lanes without a source keep their own value: old = v)
+    FFS_DPP_MAX(0x112, 0xf);
+    FFS_DPP_MAX(0x114, 0xf);
+    FFS_DPP_MAX(0x118, 0xf);
+    FFS_DPP_MAX(0x142, 0xa);  // row_bcast:15
+    FFS_DPP_MAX(0x143, 0xc);  // row_bcast:31
+#undef FFS_DPP_MAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int len, int2* __restrict__ e, int2* __restrict__ hdr,
@@ -702,7 +716,8 @@ constexpr int RUNS_EDGE = 96;  // list entries staged per edge window stretch (d
 #ifndef FFS_RUNS_WPS
 #define FFS_RUNS_WPS 8
 #endif
-constexpr int RUNS_X_NONE = 0x7fffffff;  // doubled position of a lane without a boundary: beyond the doubled sentinel
+constexpr int RUNS_X_NONE = -(1 << 26);  // doubled position of a lane without a run: far in front of every list (every lag of its walk
+                                         // lies beyond the 2 * RUNS_T doubled lags of a tile; vectors are shorter than 2^24 samples on this path)
 
 // reference boundaries as the walk reads them, positions DOUBLED: staged in LDS (pointer already moved back by the slice's
 // first index) ...
@@ -765,12 +780,17 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     const int vr = pair * (n_cand + 1);
     const int vr0 = ML ? n_vec_all + 3 * pair : vr;  // (first) list of the reference
     RunsRef rr = refs[vr0];
-    LevelInfo li;
-    int n_lv = 1;
+    // (the LevelInfo fields as scalars, the multiplicity of level k by selects: a struct copy indexed with a loop variable
+    // lives in scratch memory -- round 5's 80 bytes per lane)
+    double lev_lam0 = 0.0, lev_q = 0.0;
+    int n_lv = 1, lev_m0 = 0, lev_m1 = 0, lev_m2 = 0;
     if (ML) {
-        li = linfo[pair];
-        n_lv = li.n_levels - 1;
+        const LevelInfo* lp = linfo + pair;
+        lev_lam0 = lp->lam[0], lev_q = lp->q;
+        n_lv = lp->n_levels - 1;
+        lev_m0 = lp->m[0], lev_m1 = lp->m[1], lev_m2 = lp->m[2];
     }
+    auto lev_m = [&](int k) -> int { return k == 0 ? lev_m0 : (k == 1 ? lev_m1 : lev_m2); };
     GEntries Qe = (GEntries)rr.e;
     GWords rbits = (GWords)rr.bits;
     int n_q = ((GInts)rr.hdr)[0];
@@ -825,17 +845,30 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         m_in1x = __brev(fetch32(sbits, S, -dc - 32));
         m_out1x = __brev(fetch32(sbits, S, (long long)R - dc - 32));
     }
-    // ML: per group of four lags, sum over the threshold planes of m_k (samples entering - leaving nx1): wx1g
-    int wx1g[ML ? RUNS_LPT / 4 : 1];
+    // ML: per group of four lags, sum over the threshold planes of m_k (samples entering - leaving nx1), |value| <= 4 * 3 *
+    // LEVELS_MAX_MULT = 96: one signed BYTE per group, packed in two registers (round 5 kept six ints, in scratch memory)
+    static_assert(RUNS_LPT / 4 <= 8 && 4 * 3 * LEVELS_MAX_MULT < 128, "one signed byte per group of four lags");
+    unsigned long long wx1p = 0ull;
+    int wx1_sum = 0;
+    auto wx1_of = [&](int g4) -> int {  // sign-extended byte g4 (g4 may be a loop variable: two 64-bit shifts, no array)
+        return (int)((long long)(wx1p << (56 - 8 * g4)) >> 56);
+    };
     if (ML) {
+        int acc[RUNS_LPT / 4];
 #pragma unroll
-        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wx1g[g4] = 0;
+        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) acc[g4] = 0;
         for (int k = 0; k < n_lv; ++k) {
             const GWords pb = (GWords)refs[vr0 + k].bits;
             const unsigned mo = fetch32(pb, R, dc), mi = fetch32(pb, R, (long long)S + dc);
+            const int mk = lev_m(k);
 #pragma unroll
             for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4)
-                wx1g[g4] += li.m[k] * (__popc((mi >> (4 * g4)) & 15u) - __popc((mo >> (4 * g4)) & 15u));
+                acc[g4] += mk * (__popc((mi >> (4 * g4)) & 15u) - __popc((mo >> (4 * g4)) & 15u));
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) {
+            wx1p |= (unsigned long long)((unsigned)acc[g4] & 0xffu) << (8 * g4);
+            wx1_sum += acc[g4];
         }
         if (!sbits) {  // a list-only candidate against a multi-level reference: its windows straight from the list
             m_in1x = __brev(list_bits32(Pe, n_p, -dc - 32));
@@ -867,7 +900,9 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     }
     {
         uint4* hz = reinterpret_cast<uint4*>(hist);
-        for (int i = tid; i < (RUNS_T / 2 + 4) / 4; i += RUNS_THREADS) hz[i] = make_uint4(0u, 0u, 0u, 0u);
+        unsigned z = 0;
+        asm volatile("" : "+v"(z));  // (a zero the compiler does not keep alive -- and spill -- across the whole candidate)
+        for (int i = tid; i < (RUNS_T / 2 + 4) / 4; i += RUNS_THREADS) hz[i] = make_uint4(z, z, z, z);
     }
     const int i0 = D0 < 0 ? -D0 : 0, i1 = (R - D0) < S ? (R - D0) : S;
     const int wmax = Wt - 2;                      // h is needed for the lags D0 .. D1 - 1
@@ -885,7 +920,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             rbits = (GWords)rr.bits;
             n_q = ((GInts)rr.hdr)[0];
         }
-        wk = li.m[lv];
+        wk = lev_m(lv);
     }
     const bool whole = n_q <= RUNS_QCAP;  // the reference's whole list fits the staging area
     any_sliced |= !whole;
@@ -930,25 +965,40 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             m_inx1 = list_bits32(Qe, n_q, (long long)S + dc);
         }
     }
-    // RUNS_TPW wave tasks at a time -- 64 consecutive candidate boundaries each, one per lane, task t of a wave = boundaries
-    // r0 + (t * RUNS_WAVES + wave) * 64 + lane -- advanced TOGETHER: every step of the binary searches and of the walks
-    // issues the tasks' LDS reads back to back and waits once.  [lo, hi] = stretch of the reference's list readable
-    // through Q (Q(hi) lies beyond every window of the round), jmax = even index of a readable pair beyond every window.
-    // Doubled positions throughout (x2 = 2 (p + D0)); a lane without a boundary carries x2 = RUNS_X_NONE: its search ends at
-    // hi + 1 (readable), every lag of its walk is out of range.
+    // RUNS_TPW wave tasks at a time -- 64 consecutive candidate RUNS each, one run (start boundary, end boundary) per lane
+    // (round 6; round 5: one boundary per lane), task t of a wave = runs r0 + (t * RUNS_WAVES + wave) * 64 + lane -- advanced
+    // TOGETHER: every step of the binary searches and of the walks issues the tasks' LDS reads back to back and waits once.
+    // A lane reads every reference run of its window ONCE (one aligned 8-byte LDS read) and adds the run's four boundary
+    // coincidences: + at (start, start) and (end, end), - at (start, end) and (end, start) -- half the list reads, half
+    // the searches and half the loop trips of the boundary-per-lane walk for the same scatter-adds.
+    // [lo, hi] = stretch of the reference's list readable through Q (Q(hi) lies beyond every window of the round), jmax =
+    // even index of a readable pair beyond every window.  Doubled positions throughout (x2 = 2 (p + D0)); a lane without a
+    // run carries RUNS_X_NONE, a position far in front of the list: its search ends at `lo`, every lag of its walk is far
+    // beyond the tile, nothing keeps the loops alive.
     auto tasks = [&](auto Q, int r0, int r1, int lo, int hi, int jmax) {
-        int x2[RUNS_TPW], j[RUNS_TPW], ones[RUNS_TPW], a[RUNS_TPW], b[RUNS_TPW];
-        const int sgn = (lane & 1) ? -wk : wk;  // db[p] (times the level's multiplicity): r0 and the task bases are even
+        int xs2[RUNS_TPW], xe2[RUNS_TPW], j[RUNS_TPW], ones_d[RUNS_TPW], a[RUNS_TPW], b[RUNS_TPW];
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) v4i* GRunPairs;
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
             const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
-            x2[t] = i < r1 ? Pe[i].pos : -1;
+            v4i se = {0, 0, 0, 0};
+            if (i < r1) se = *(GRunPairs)(Pe + 2 * i);  // (start, ones in front, end, ones in front): one 16-byte load
+            xs2[t] = se.x, xe2[t] = se.z;
         }
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
             const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
-            x2[t] = i < r1 ? 2 * (x2[t] + D0) : RUNS_X_NONE;
-            a[t] = lo, b[t] = hi;  // first k in [lo, hi] with Q(k) >= x
+            const bool valid = i < r1;
+            if (!ML || lv == 0) {  // (the candidate's own count: once, without the multiplicity)
+                // ones of b in [i0, i1) = sum over its runs of (min(i1, end) - min(i0, end)) - (min(i1, start) - min(i0, start))
+                const int ps = xs2[t], pe = xe2[t];
+                const int ds = (ps < i1 ? ps : i1) - (ps < i0 ? ps : i0), de = (pe < i1 ? pe : i1) - (pe < i0 ? pe : i0);
+                if (valid) bsum += de - ds;
+            }
+            xs2[t] = valid ? 2 * (xs2[t] + D0) : RUNS_X_NONE;
+            xe2[t] = valid ? 2 * (xe2[t] + D0) : RUNS_X_NONE;
+            a[t] = lo, b[t] = hi;  // first k in [lo, hi] with Q(k) >= xs
         }
         const int steps = hi > lo ? 32 - __clz(hi - lo) : 0;  // (uniform: no per-lane exit test)
         for (int s_ = 0; s_ < steps; ++s_) {
@@ -960,31 +1010,42 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             }
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) {
-                const bool lt = qm[t] < x2[t];
+                const bool lt = qm[t] < xs2[t];
                 a[t] = lt ? m[t] + 1 : a[t];
                 b[t] = lt ? b[t] : m[t];
             }
+        }
+        // first k >= lb(start) with Q(k) >= xe: a few entries further (a candidate run rarely spans many reference runs)
+#pragma unroll
+        for (int t = 0; t < RUNS_TPW; ++t) b[t] = a[t];
+        for (int guard = hi - lo + 1; guard > 0; --guard) {
+            bool any = false;
+#pragma unroll
+            for (int t = 0; t < RUNS_TPW; ++t) {
+                const bool adv = b[t] < hi && Q.one(b[t]) < xe2[t];
+                b[t] += adv ? 1 : 0;
+                any |= adv;
+            }
+            if (!__any(any)) break;
         }
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
             const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
             const bool valid = i < r1;
-            const int lb = a[t];
-            ones[t] = valid ? Qe[lb].ones : 0;  // (the sentinel entry holds all ones); consumed after the walks
-            const int odd = lb & 1;
+            const int ls = a[t], le = b[t];
+            // ones of the reference in front of xe minus in front of xs (the sentinel entry holds all ones); the loads are
+            // consumed after the walks
+            ones_d[t] = valid ? Qe[le].ones - Qe[ls].ones : 0;
             // inside a run: the run's ones from x on are not in front of x
-            const int corr = (valid && odd) ? (Q.one(lb) - x2[t]) >> 1 : 0;
-            const int sv = valid ? sgn : 0;
-            n11p += sv * corr;
-            gp -= sv * odd;
-            if (!ML || lv == 0) {  // (the candidate's own count: once, without the multiplicity)
-                const int p = (x2[t] >> 1) - D0;
-                const int m1 = p < i1 ? p : i1, m0 = p < i0 ? p : i0;
-                if (valid) bsum -= ((lane & 1) ? -1 : 1) * (m1 - m0);  // ones of b in [i0, i1) = sum_k sgn_k * (min(i1, P[k]) - min(i0, P[k]))
+            const int cs = (ls & 1) ? (Q.one(ls) - xs2[t]) >> 1 : 0, ce = (le & 1) ? (Q.one(le) - xe2[t]) >> 1 : 0;
+            if (valid) {
+                n11p += wk * (cs - ce);           // sum over boundaries of db[p] (corr - ones), db = +1 at the start, -1 at the end
+                gp -= wk * ((ls & 1) - (le & 1));
             }
-            j[t] = lb & ~1;  // the reference's run that contains or follows x: (start, end) = entries (j, j + 1)
+            j[t] = ls & ~1;  // the reference's run that contains or follows xs: (start, end) = entries (j, j + 1)
             j[t] = j[t] < jmax ? j[t] : jmax;
         }
+        const unsigned vp = (unsigned)wk, vm = (unsigned)(-wk);
         // (every trip moves each lane two entries on until it sits on the pair at jmax: at most (jmax - lo) / 2 + 1 trips do
         // anything -- the bound only guards against a kernel that cannot end)
         for (int trips = ((jmax - (lo & ~1)) >> 1) + 2; trips > 0; --trips) {
@@ -992,36 +1053,44 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) qq[t] = Q.two(j[t]);
             bool any = false;
+            int lag[RUNS_TPW][4];  // doubled lags of the four coincidences: (start, start), (end q, start p), (start q, end p), (end, end)
 #pragma unroll
             for (int t = 0; t < RUNS_TPW; ++t) {
-                const int da = qq[t].x - x2[t], db = qq[t].y - x2[t];  // doubled lags
-                // + at run starts (even entries), - at run ends; lag d = bits 16 (d & 1) .. of word d >> 1
-                if ((unsigned)da <= wlim2) atomicAdd(&hist[(unsigned)da >> 2], (unsigned)sgn << ((da & 2) << 3));
-                if ((unsigned)db <= wlim2) atomicAdd(&hist[(unsigned)db >> 2], (unsigned)(-sgn) << ((db & 2) << 3));
-                // an end beyond the window: so is everything behind it (unsigned: a lane without a boundary sits below
-                // every entry -- negative -- and must not keep the loop alive; a boundary's own first end is never negative)
-                any |= (unsigned)db <= wlim2;
+                lag[t][0] = qq[t].x - xs2[t], lag[t][1] = qq[t].y - xs2[t], lag[t][2] = qq[t].x - xe2[t], lag[t][3] = qq[t].y - xe2[t];
+                // the smallest of the four lags (reference start - candidate end) beyond the tile: so is everything behind it
+                any |= lag[t][2] <= (int)wlim2;
                 const int jn = j[t] + 2;
                 j[t] = jn < jmax ? jn : jmax;
+            }
+            // (the scatter-adds behind every subtraction: nothing in this trip waits for an atomic to complete)
+#pragma unroll
+            for (int t = 0; t < RUNS_TPW; ++t) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    // lag d = bits 16 (d & 1) .. of word d >> 1: byte address d2 & ~3, shift (d2 & 2) << 3 = the low five bits of d2 << 3
+                    const unsigned d2 = (unsigned)lag[t][u];
+                    if (d2 <= wlim2) atomicAdd(&hist[d2 >> 2], ((u == 0 || u == 3) ? vp : vm) << ((d2 << 3) & 31u));
+                }
             }
             if (!__any(any)) break;
         }
 #pragma unroll
-        for (int t = 0; t < RUNS_TPW; ++t) n11p -= sgn * ones[t];  // (ones = 0 for a lane without a boundary)
+        for (int t = 0; t < RUNS_TPW; ++t) n11p += wk * ones_d[t];  // - sum db[p] ones(p): + at the end boundary, - at the start
     };
-    // Rounds of RUNS_ROUND consecutive candidate boundaries.  A reference list that does not fit the staging area is staged
-    // slice by slice: the q's a round can meet are one stretch [first q >= P[first] + D0, first q beyond P[last] + D1],
+    // Rounds of RUNS_ROUND consecutive candidate runs.  A reference list that does not fit the staging area is staged
+    // slice by slice: the q's a round can meet are one stretch [first q >= first start + D0, first q beyond last end + D1],
     // found by two wave-wide 64-ary searches; only a round whose stretch is still too long (a reference far denser than
     // the candidate) walks the list in global memory.
     constexpr int RUNS_ROUND = RUNS_THREADS * RUNS_TPW;
+    const int n_runs = n_p >> 1;  // (n_p is even: a run that reaches the end closes at position len)
     int st_lo = 0, st_hi = n_q;
     bool staged_ok = whole;
-    for (int r0 = 0; r0 < n_p; r0 += RUNS_ROUND) {
-        const int r1 = (r0 + RUNS_ROUND) < n_p ? (r0 + RUNS_ROUND) : n_p;
+    for (int r0 = 0; r0 < n_runs; r0 += RUNS_ROUND) {
+        const int r1 = (r0 + RUNS_ROUND) < n_runs ? (r0 + RUNS_ROUND) : n_runs;
         if (!whole) {
             __syncthreads();  // the previous round is done with the staged slice
             if (tid < 128) {
-                const int xq = (tid < 64) ? Pe[r0].pos + D0 : Pe[r1 - 1].pos + D0 + wlim + 1;
+                const int xq = (tid < 64) ? Pe[2 * r0].pos + D0 : Pe[2 * r1 - 1].pos + D0 + wlim + 1;
                 const int v = wave_lower_bound_e(Qe, n_q, xq);
                 if ((tid & 63) == 0) s_tmp[0][tid >> 6] = v;
             }
@@ -1081,11 +1150,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     sc5[0] = hs, sc5[1] = tid * hs, sc5[2] = ws;
     sc5[3] = __popc(m_in1x & lpt_mask) - __popc(m_out1x & lpt_mask);
     sc5[4] = __popc(m_inx1 & lpt_mask) - __popc(m_outx1 & lpt_mask);
-    if (ML) {
-        sc5[4] = 0;
-#pragma unroll
-        for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) sc5[4] += wx1g[g4];
-    }
+    if (ML) sc5[4] = wx1_sum;
     block_excl_scan5_dpp<RUNS_WAVES>(sc5, s_tmp[1], lane, wave);  // exclusive prefixes A, B, C and of the one-sided counts' changes
     const int g_c = g_0 - sc5[0];  // g at the thread's first lag
     // n11 at the thread's first lag (wrap-around arithmetic: exact whenever the result fits, which it does)
@@ -1102,7 +1167,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     // with the coefficients of the LevelInfo comment); fp32 first
     double k0 = cd.s0 * cd.r0, k1x = cd.r0 * (cd.s1 - cd.s0), kx1 = cd.s0 * (cd.r1 - cd.r0), k11 = (cd.s1 - cd.s0) * (cd.r1 - cd.r0);
     if (ML) {
-        const double base = 2.0 * li.lam[0] - 1.0, two_q = 2.0 * li.q;
+        const double base = 2.0 * lev_lam0 - 1.0, two_q = 2.0 * lev_q;
         k0 = base * cd.s0, k1x = base * (cd.s1 - cd.s0), kx1 = two_q * cd.s0, k11 = two_q * (cd.s1 - cd.s0);
     }
     const float f0 = (float)k0, f1x = (float)k1x, fx1 = (float)kx1, f11 = (float)k11;
@@ -1143,10 +1208,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             }
             a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
             if (ML) {
-                int wdelta = 0;
-#pragma unroll
-                for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wdelta = g4 == q4 ? wx1g[g4] : wdelta;
-                ax1 += wdelta;
+                ax1 += wx1_of(q4);
             } else {
                 ax1 += __popc(mix & 15u) - __popc(mox & 15u);
             }
@@ -1157,9 +1219,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         prefilter(std::false_type{});
     else if (lim > 0)
         prefilter(std::true_type{});
-    float wm = tmax;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) wm = fmaxf(wm, __shfl_xor(wm, s, 64));
+    const float wm = wave_max_f32(tmax);
     if (lane == 0) s_m[wave] = wm;
     __syncthreads();
     float bm = s_m[0];
@@ -1195,7 +1255,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
                         for (int k = 0; k < n_lv; ++k) {
                             const GWords pb = (GWords)refs[vr0 + k].bits;
                             const unsigned mo = fetch32(pb, R, dc) >> (4 * q4), mi = fetch32(pb, R, (long long)S + dc) >> (4 * q4);
-                            bx1 += li.m[k] * (__popc(mi & low) - __popc(mo & low));
+                            bx1 += lev_m(k) * (__popc(mi & low) - __popc(mo & low));
                         }
                         const int j0 = d < 0 ? -d : 0;
                         const int j1 = (R - d) < S ? (R - d) : S;
@@ -1215,10 +1275,7 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
             }
             a1x += __popc(mi1 & 15u) - __popc(mo1 & 15u);
             if (ML) {
-                int wdelta = 0;
-#pragma unroll
-                for (int g4 = 0; g4 < RUNS_LPT / 4; ++g4) wdelta = g4 == q4 ? wx1g[g4] : wdelta;
-                ax1 += wdelta;
+                ax1 += wx1_of(q4);
             } else {
                 ax1 += __popc(mix & 15u) - __popc(mox & 15u);
             }
@@ -1231,13 +1288,16 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         return;
     }
 #endif
-    // block argmax: larger score, then larger lag
-    double ws_ = bs;
-    int wd = bd;
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        const double os = __shfl_xor(ws_, s, 64);
-        const int od = __shfl_xor(wd, s, 64);
+    // block argmax: larger score, then larger lag.  Inside a wave only the few lanes that re-evaluated a lag take part (most
+    // waves have none): their values are read lane by lane into scalar registers -- no shuffle butterfly over 64 lanes
+    double ws_ = -INFINITY;
+    int wd = INT32_MIN;
+    for (unsigned long long mask = __ballot(bd != INT32_MIN); mask; mask &= mask - 1) {
+        const int l = __builtin_ctzll(mask);
+        const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(bs), l);
+        const int hi32 = __builtin_amdgcn_readlane(__double2hiint(bs), l);
+        const double os = __hiloint2double(hi32, (int)lo32);
+        const int od = __builtin_amdgcn_readlane(bd, l);
         if (os > ws_ || (os == ws_ && od > wd)) ws_ = os, wd = od;
     }
     if (lane == 0) s_sc[wave] = ws_, s_d[wave] = wd;

@@ -95,8 +95,6 @@ constexpr unsigned kPoolCapacity = 1u << 20;
 // +-60 s window: ~20 per point of N = 3 * 2^18 (lists of 17 k x 20 k boundaries); no window: ~13 per point of N = 3 * 2^19
 // (118 lag tiles per candidate cost as much as 6 M coincidences).  Twelve keeps the choice on the winning side in both.
 constexpr long long kRunsBudgetPerPoint = 12;
-// k_runs_corr: calls of at least this many pairs give every workgroup a whole pair (4 resident workgroups x 256 CUs x 2)
-constexpr int kRunsPairsPerWorkgroupFrom = 2048;
 constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
@@ -1733,10 +1731,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                                        (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight,
                                        (const LevelInfo*)(db + o_li), (int)n_vec);
                 else {
-                    // One workgroup per PAIR when the call has enough pairs to fill the chip that way (the reference's list is
-                    // then staged once for the pair's candidates), one per candidate otherwise (and for windows of several
-                    // tiles).  FFS_RUNS_SPLIT overrides (A/B).
-                    int split = (tiles_max == 1 && n_pairs >= kRunsPairsPerWorkgroupFrom) ? 1 : n_cand;
+                    // One workgroup per candidate.  The kernel can also walk several candidates of a pair in one workgroup
+                    // (FFS_RUNS_SPLIT = workgroups per pair; the reference's list is then staged once for them), measured in
+                    // round 6: 7 x fewer stagings, but the 7 x longer workgroups leave the chip idle longer at the end of a
+                    // launch -- 0.248 against 0.238 us per pair at 4096 pairs (profiles/r06_runs_experiments.json).
+                    int split = n_cand;
                     if (p->runs_split > 0) split = p->runs_split < n_cand ? p->runs_split : n_cand;
                     hipLaunchKernelGGL(k_runs_corr, dim3((unsigned)((size_t)n_pairs * split), (unsigned)tiles_max), dim3(RUNS_THREADS), 0, st,
                                        dc, n_cand, (const RunsRef*)(db + o_rv), cres, p->runs_best, tiles_max, d_flags, p->pairs_in_flight,
