@@ -148,41 +148,67 @@ FFS_DEV float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Round 6: the words that HOLD a boundary (one in eleven for subtitle-like vectors) are compacted before anything is done
+// bit by bit.  Round 5 ran the per-bit loop of every word slot on the whole wave -- with 64 lanes some lane nearly always
+// has a boundary in the slot, so every wave paid eight loop bodies per sweep for ~45 boundaries (17 VALU operations per
+// word, 0.55 of 8 TB/s).  Now a lane appends each of its boundary words as one 16-byte item (word index + the bit in front,
+// the word, ones and boundaries of the vector in front of it -- all known after the sweep's block scan) to a ring in LDS
+// that belongs to its WAVE (ranks from one DPP scan; LDS operations of a wave complete in order, so no barrier), and
+// whenever 64 items are waiting the wave turns them into list entries, one item per lane.
+constexpr int RUNS_XQ = 256;  // items per wave ring (a group of a sweep adds at most 256 per wave)
 FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int len, int2* __restrict__ e, int2* __restrict__ hdr,
                                const int cap) {
     const GWords w = (GWords)w_generic;
     constexpr int G = 2, SWEEP = 256 * 4 * G;  // words per sweep
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const gptr eb = (gptr)e;
     const int nw = (len + 31) >> 5;     // words that hold samples
     const int n_proc = (len >> 5) + 1;  // word len/32 holds position `len`, where a run that reaches the end closes
     const unsigned tail = (len & 31) ? ((1u << (len & 31)) - 1u) : 0xffffffffu;  // valid bits of word nw - 1
     __shared__ unsigned s_e[2][4], s_o[2][4];
+    __shared__ __attribute__((aligned(16))) uint4 s_q[4][RUNS_XQ];
+    uint4* const ring = s_q[wave];
+    unsigned q_head = 0, q_tail = 0;   // items [head, tail) of this wave's ring are waiting (wave-uniform)
     unsigned n_bound = 0, n_ones = 0;  // boundaries / ones in front of this sweep
     unsigned xn[G][4], pn[G];          // the next sweep's words; word in front of each group (lane 0 of a wave only)
+    // The loads go through a buffer resource that covers exactly the vector's words: a word behind the end reads as 0 (and
+    // so does "the word in front of word 0"), no fault, NO BRANCH -- round 5's request() chose between a 16-byte load and
+    // four guarded ones, and the compiler waited for the data at the join of the two paths: the "loads of the next sweep"
+    // were waited for on the spot, every sweep paid the full memory latency (0.55 of 8 TB/s at eight workgroups per CU).
+    // Only the partial last word needs its mask, applied where the words are used.
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(w_generic), 0, nw * 4, 0x00020000);
     auto request = [&](int base) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int w0 = base + (g * 256 + tid) * 4;
-            if (w0 + 4 < nw) {  // in front of the (masked) last word
-                typedef unsigned v4u __attribute__((ext_vector_type(4), aligned(4)));
-                const v4u t = *(const __attribute__((address_space(1))) v4u*)(w + w0);
-                xn[g][0] = t.x, xn[g][1] = t.y, xn[g][2] = t.z, xn[g][3] = t.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = w0 + k;
-                    unsigned t = i < nw ? w[i] : 0u;
-                    if (i == nw - 1) t &= tail;
-                    xn[g][k] = t;
-                }
-            }
+            typedef unsigned v4u __attribute__((ext_vector_type(4)));
+            // (nontemporal: the samples are read exactly once -- 0.165 -> 0.158 us per pair, profiles/r06_runs_experiments.json)
+            const v4u t = __builtin_amdgcn_raw_buffer_load_b128(vrs, w0 * 4, 0, 2);
+            xn[g][0] = t.x, xn[g][1] = t.y, xn[g][2] = t.z, xn[g][3] = t.w;
             pn[g] = 0;
-            if (lane == 0 && w0 > 0 && w0 - 1 < nw) {
-                pn[g] = w[w0 - 1];
-                if (w0 - 1 == nw - 1) pn[g] &= tail;
+            if (lane == 0) pn[g] = __builtin_amdgcn_raw_buffer_load_b32(vrs, w0 * 4 - 4, 0, 0);
+        }
+    };
+    // up to 64 waiting items -> list entries, one item per lane: entry k = (position, ones of the vector in front of it)
+    auto drain = [&]() {
+        const unsigned n = (q_tail - q_head) < 64u ? (q_tail - q_head) : 64u;
+        if ((unsigned)lane < n) {
+            const uint4 it = ring[(q_head + (unsigned)lane) & (RUNS_XQ - 1)];
+            unsigned eb_k = it.y ^ __builtin_amdgcn_alignbit(it.y, it.x, 31);  // x ^ (x << 1 | bit in front)
+            const int pos0 = (int)((it.x & 0x7fffffffu) << 5);
+            int k_out = (int)it.w;
+            while (eb_k) {
+                const int b = __builtin_ctz(eb_k);
+                if (k_out < cap) {  // (scalar list base + 32-bit byte offset: no 64-bit address arithmetic per store)
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    *(__attribute__((address_space(1))) v2i*)(eb + 8u * (unsigned)k_out) =
+                        (v2i){pos0 + b, (int)it.z + (int)__popc(it.y & ((1u << b) - 1u))};
+                }
+                ++k_out;
+                eb_k &= eb_k - 1;
             }
         }
+        q_head += n;
     };
     request(0);
     int buf = 0;
@@ -193,26 +219,41 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
             pv[g] = pn[g];
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[g][k] = xn[g][k];
+            // the partial last word: its bits behind the vector's end do not count (one thread of one sweep)
+            const int w0 = base + (g * 256 + tid) * 4;
+            if ((unsigned)(nw - 1 - w0) < 4u) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (w0 + k == nw - 1) x[g][k] &= tail;
+            }
+            if (w0 == nw) pv[g] &= tail;  // (lane 0's word in front is the last word)
         }
+        // The list entries of the items that are waiting are stored BEFORE the next sweep's loads are requested: gfx950 counts
+        // loads and stores in one in-order counter, so a store issued behind the loads would have to be acknowledged before
+        // the loads' data may be used -- a sweep then pays the write latency on top of the read latency.
+        while (q_tail - q_head >= 64u) drain();
         if (base + SWEEP < n_proc) request(base + SWEEP);
-        unsigned pe = 0, po = 0;
+        unsigned pe = 0, po = 0, pc = 0;  // per group, 16 bits each: boundaries, ones, boundary WORDS of this thread
+        unsigned fr[G];                    // bit 31 of the word in front of each group
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[g][3], 0x138, 0xf, 0xf, false);  // wave_shr:1
             if (lane == 0) prev = pv[g];
-            prev >>= 31;
-            unsigned ne = 0, no = 0;
+            fr[g] = prev;
+            unsigned ne = 0, no = 0, nc = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ee[g][k] = x[g][k] ^ ((x[g][k] << 1) | prev);
-                prev = x[g][k] >> 31;
+                ee[g][k] = x[g][k] ^ __builtin_amdgcn_alignbit(x[g][k], prev, 31);  // x ^ (x << 1 | bit 31 of the word in front)
+                prev = x[g][k];
                 ne += __popc(ee[g][k]);
                 no += __popc(x[g][k]);
+                nc += ee[g][k] != 0u ? 1u : 0u;
             }
             pe |= ne << (16 * g);
             po |= no << (16 * g);
+            pc |= nc << (16 * g);
         }
-        const unsigned ie = wave_incl_scan_u32(pe), io = wave_incl_scan_u32(po);
+        const unsigned ie = wave_incl_scan_u32(pe), io = wave_incl_scan_u32(po), ic = wave_incl_scan_u32(pc);
         if (lane == 63) s_e[buf][wave] = ie, s_o[buf][wave] = io;
         __syncthreads();  // (two buffers: the next sweep's totals cannot overwrite these while they are read)
         unsigned xe = ie - pe, xo = io - po, te = 0, to = 0;  // exclusive in-block prefixes, block totals
@@ -222,34 +263,38 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
             if (i < wave) xe += a, xo += b;
             te += a, to += b;
         }
+        const unsigned wc = (unsigned)__builtin_amdgcn_readlane((int)ic, 63);  // this wave's boundary words, per group
+        const unsigned rc = ic - pc;                                           // ranks inside the wave
         unsigned gb = n_bound, go = n_ones;  // boundaries / ones in front of group g of thread 0
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            int k_out = (int)(gb + ((xe >> (16 * g)) & 0xffffu));
-            int ones = (int)(go + ((xo >> (16 * g)) & 0xffffu));
+            unsigned k_out = gb + ((xe >> (16 * g)) & 0xffffu);
+            unsigned ones = go + ((xo >> (16 * g)) & 0xffffu);
             gb += (te >> (16 * g)) & 0xffffu;
             go += (to >> (16 * g)) & 0xffffu;
-            if ((pe >> (16 * g)) & 0xffffu) {
-                const int w0 = base + (g * 256 + tid) * 4;
+            const unsigned add = (wc >> (16 * g)) & 0xffffu;  // (<= 256 = the ring)
+            {
+            while (q_tail - q_head + add > (unsigned)RUNS_XQ) drain();
+            unsigned slot = q_tail + ((rc >> (16 * g)) & 0xffffu);
+            const unsigned w0 = (unsigned)(base + (g * 256 + tid) * 4);
+            unsigned prev = fr[g];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    unsigned eb_k = ee[g][k];
-                    while (eb_k) {
-                        const int b = __builtin_ctz(eb_k);
-                        if (k_out < cap) {  // (scalar list base + 32-bit byte offset: no 64-bit address arithmetic per store)
-                            typedef int v2i __attribute__((ext_vector_type(2)));
-                            *(__attribute__((address_space(1))) v2i*)(eb + 8u * (unsigned)k_out) =
-                                (v2i){32 * (w0 + k) + b, ones + (int)__popc(x[g][k] & ((1u << b) - 1u))};
-                        }
-                        ++k_out;
-                        eb_k &= eb_k - 1;
-                    }
-                    ones += __popc(x[g][k]);
+            for (int k = 0; k < 4; ++k) {
+                if (ee[g][k]) {
+                    ring[slot & (RUNS_XQ - 1)] = make_uint4((w0 + k) | (prev & 0x80000000u), x[g][k], ones, k_out);
+                    ++slot;
                 }
+                k_out += __popc(ee[g][k]);
+                ones += __popc(x[g][k]);
+                prev = x[g][k];
+            }
+            q_tail += add;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wave's own ring: written and read in order, no barrier)
             }
         }
         n_bound = gb, n_ones = go;
     }
+    while (q_tail != q_head) drain();
     if (tid == 0) {
         *hdr = make_int2((int)n_bound, (int)n_ones);
         if ((int)n_bound < cap) e[n_bound] = make_int2(INT32_MAX, (int)n_ones);
@@ -394,6 +439,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
     const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
     int over = 0, bad = 0;
     unsigned long long nb = 0;
+    int longest = 0;  // longest list among the vectors that arrived as bits (plan-owned lists: the host sizes their stride by it)
     for (int i = p0 * n_cand + (int)(blockIdx.y * 256 + threadIdx.x); i < p1 * n_cand; i += 256 * RUNS_FLAG_SPLIT) {
         const CandDesc& cd = cands[i];
         const int pair = i / n_cand, j = i - pair * n_cand;
@@ -406,6 +452,8 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
         const int cap_q = (estimates && rr.bits) ? 0x7fffffff : (rr.cap > 0 ? rr.cap : hq[3]);
         const int cap_p = (estimates && rs.bits) ? 0x7fffffff : (rs.cap > 0 ? rs.cap : hp[3]);
         nb += (unsigned)n_p + (j == 0 ? (unsigned)n_q : 0u);
+        if (rs.bits && n_p > longest) longest = n_p;
+        if (rr.bits && n_q > longest) longest = n_q;
         bad |= (!rs.bits && n_p >= cap_p) || (!rr.bits && n_q >= cap_q);
         if (cd.flags & CAND_NO_LAGS) continue;
         // (16-bit histogram cells: lists of 32 768 entries or more never take the run-boundary kernel, whoever owns them)
@@ -424,6 +472,14 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
         const int f = bad ? 2 : over;
         if (f) atomicMax(&flags[ch], f);
         if (!estimates) atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
+    }
+    if (!estimates) {
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {
+            const int o = __shfl_xor(longest, s, 64);
+            longest = o > longest ? o : longest;
+        }
+        if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax(stats + 1, (unsigned long long)longest);
     }
 }
 
@@ -1338,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags_ml(const CandDesc* __r
                                                              int* __restrict__ flags, unsigned long long* __restrict__ stats) {
     const int ch = blockIdx.x;
     const int p0 = ch * pairs_per_chunk, p1 = (p0 + pairs_per_chunk) < n_pairs ? (p0 + pairs_per_chunk) : n_pairs;
-    int over = 0;
+    int over = 0, longest = 0;
     unsigned long long nb = 0;
     for (int i = p0 * n_cand + (int)threadIdx.x; i < p1 * n_cand; i += 256) {
         const CandDesc& cd = cands[i];
@@ -1349,13 +1405,16 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags_ml(const CandDesc* __r
         const int cap_p = rs.cap > 0 ? rs.cap : ((GInts)rs.hdr)[3];
         nb += (unsigned)n_p;
         if (!li.ok || n_p >= cap_p || n_p >= RUNS_CAP) {
+            if (n_p > longest) longest = n_p;
             over = 1;
             continue;
         }
         long long coinc = 0, cell = 0;
+        if (n_p > longest) longest = n_p;
         for (int k = 0; k < li.n_levels - 1; ++k) {
             const RunsRef rk = refs[n_vec_all + 3 * pair + k];
             const int n_q = ((GInts)rk.hdr)[0];
+            if (n_q > longest) longest = n_q;
             if (j == 0) nb += (unsigned)n_q;
             if (n_q >= rk.cap) over = 1;
             coinc += (long long)n_p * n_q;
@@ -1374,6 +1433,12 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags_ml(const CandDesc* __r
         flags[ch] = over;
         atomicAdd(stats, s_nb[0] + s_nb[1] + s_nb[2] + s_nb[3]);
     }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const int o = __shfl_xor(longest, s, 64);
+        longest = o > longest ? o : longest;
+    }
+    if ((threadIdx.x & 63) == 0 && longest > 0) atomicMax(stats + 1, (unsigned long long)longest);
 }
 
 // candidates whose window spans several tiles: best tile result (larger score, then larger lag = later tile)

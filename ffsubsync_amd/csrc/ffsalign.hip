@@ -95,6 +95,11 @@ constexpr unsigned kPoolCapacity = 1u << 20;
 // +-60 s window: ~20 per point of N = 3 * 2^18 (lists of 17 k x 20 k boundaries); no window: ~13 per point of N = 3 * 2^19
 // (118 lag tiles per candidate cost as much as 6 M coincidences).  Twelve keeps the choice on the winning side in both.
 constexpr long long kRunsBudgetPerPoint = 12;
+// Plan-owned boundary lists (vectors that arrive as bits) start with room for this many entries each -- subtitle-like vectors
+// have ~2 000 -- and the stride grows (x 4, up to RUNS_CAP) when a call meets a longer list: that call's sub-batch goes through
+// the transforms (a list that fills its slot counts as over budget), the next call has the room.  A 256 KB stride for 16 KB
+// lists cost 4 % of k_runs_extract (65 536 lists spread over 16 GB of address space).
+constexpr int kRunsStride0 = 4096;
 constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
@@ -215,7 +220,9 @@ struct ffs_plan {
     int algo = FFS_ALGO_AUTO;
     int runs_split = 0;                 // FFS_RUNS_SPLIT: workgroups per pair in k_runs_corr (0: the rule at the launch site)
     long long runs_budget = -1;         // FFS_RUNS_BUDGET: boundary coincidences per candidate above which the transforms take over (-1: the rule in ffs_plan_create)
-    int2* runs_e = nullptr;             // [vectors][RUNS_CAP] (boundary position, ones in front of it) of the vectors that arrive as bits
+    int2* runs_e = nullptr;             // [vectors][runs_stride] (boundary position, ones in front of it) of the vectors that arrive as bits
+    int runs_stride = 4096;             // entries per plan-owned list (kRunsStride0; FFS_RUNS_STRIDE; grows up to RUNS_CAP)
+    size_t runs_e_entries = 0;          // entries allocated behind runs_e
     int2* runs_n = nullptr;             // [vectors] (boundaries, ones)
     size_t runs_vecs = 0;               // vectors the two buffers above have room for
     unsigned* pack_buf = nullptr;       // bit-packed images of a call's FFS_DTYPE_U8 vectors / of list-only vectors that need the transforms
@@ -320,24 +327,27 @@ int ensure_runs(ffs_plan* p, size_t n_vec, size_t n_best, size_t n_chunks) {
         return FFS_OK;
     };
     int rc;
-    if (n_vec > p->runs_vecs) {
+    if (n_vec > p->runs_vecs || n_vec * (size_t)p->runs_stride > p->runs_e_entries) {  // more vectors, or a longer stride
         if ((rc = quiesce())) return rc;
         (void)hipFree(p->runs_e);
         (void)hipFree(p->runs_n);
-        p->workspace_bytes -= (int64_t)(p->runs_vecs * (RUNS_CAP * sizeof(int2) + sizeof(int2)));
+        p->workspace_bytes -= (int64_t)(p->runs_e_entries * sizeof(int2) + p->runs_vecs * sizeof(int2));
         p->runs_e = nullptr;
         p->runs_n = nullptr;
         p->runs_vecs = 0;
-        const size_t cap = n_vec + n_vec / 4 + 64;
-        if (hipMalloc((void**)&p->runs_e, cap * RUNS_CAP * sizeof(int2)) != hipSuccess ||
+        p->runs_e_entries = 0;
+        const size_t cap = (n_vec > p->runs_vecs ? n_vec : p->runs_vecs) + n_vec / 4 + 64;
+        const size_t entries = cap * (size_t)p->runs_stride;
+        if (hipMalloc((void**)&p->runs_e, entries * sizeof(int2)) != hipSuccess ||
             hipMalloc((void**)&p->runs_n, cap * sizeof(int2)) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipFree(p->runs_e);
             p->runs_e = nullptr;
-            return fail(FFS_E_NOMEM, "boundary lists for %zu vectors (%zu bytes) could not be allocated", cap, cap * RUNS_CAP * sizeof(int2));
+            return fail(FFS_E_NOMEM, "boundary lists for %zu vectors (%zu bytes) could not be allocated", cap, entries * sizeof(int2));
         }
         p->runs_vecs = cap;
-        p->workspace_bytes += (int64_t)(cap * (RUNS_CAP * sizeof(int2) + sizeof(int2)));
+        p->runs_e_entries = entries;
+        p->workspace_bytes += (int64_t)(entries * sizeof(int2) + cap * sizeof(int2));
     }
     if (n_best > p->runs_best_n) {
         if ((rc = quiesce())) return rc;
@@ -356,8 +366,8 @@ int ensure_runs(ffs_plan* p, size_t n_vec, size_t n_best, size_t n_chunks) {
         if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
         p->runs_flags = p->runs_zero_flags = p->runs_flags_host = nullptr;
         p->runs_flags_n = 0;
-        const size_t cap = n_chunks + 64;  // (the 8-byte boundary counter sits behind the flags, 8-byte aligned)
-        const size_t bytes = ((cap * sizeof(int) + 7) & ~(size_t)7) + 8;
+        const size_t cap = n_chunks + 64;  // (two 8-byte statistics sit behind the flags, 8-byte aligned: boundaries, longest list)
+        const size_t bytes = ((cap * sizeof(int) + 7) & ~(size_t)7) + 16;
         HIP_TRY(hipMalloc((void**)&p->runs_flags, bytes));
         HIP_TRY(hipMalloc((void**)&p->runs_zero_flags, bytes));
         HIP_TRY(hipMemset(p->runs_zero_flags, 0, bytes));
@@ -1022,6 +1032,11 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
         p->runs_budget = -1;
         if (const char* eb = getenv("FFS_RUNS_BUDGET")) p->runs_budget = atoll(eb);
         if (const char* es = getenv("FFS_RUNS_SPLIT")) p->runs_split = atoi(es);
+        p->runs_stride = kRunsStride0;
+        if (const char* es = getenv("FFS_RUNS_STRIDE")) {
+            const int v = atoi(es);
+            p->runs_stride = v < 64 ? 64 : (v > RUNS_CAP ? RUNS_CAP : v);
+        }
         if (const char* et = getenv("FFS_HOST_TIMING")) p->host_timing = et[0] == '1';
         const char* e3 = getenv("FFS_PASS_A_PREFETCH");
         if (e3) p->pass_a_prefetch = p->pass_a_prefetch_bits = atoi(e3);
@@ -1425,9 +1440,9 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             if (dt == FFS_DTYPE_RUNS)  // caller-owned block: 16-byte header (n, ones, len, capacity), then the entries
                 hrv[i] = RunsRef{(const int2*)((const char*)vec_ptr[i] + 16), (const int2*)vec_ptr[i], nullptr, (int32_t)vec_len[i], 0};
             else if (dt == FFS_DTYPE_U1)
-                hrv[i] = RunsRef{p->runs_e + i * RUNS_CAP, p->runs_n + i, (const unsigned*)vec_ptr[i], (int32_t)vec_len[i], RUNS_CAP};
+                hrv[i] = RunsRef{p->runs_e + i * (size_t)p->runs_stride, p->runs_n + i, (const unsigned*)vec_ptr[i], (int32_t)vec_len[i], p->runs_stride};
             else  // a multi-level reference: its threshold planes follow the vectors
-                hrv[i] = RunsRef{nullptr, p->runs_n + i, nullptr, (int32_t)vec_len[i], RUNS_CAP};
+                hrv[i] = RunsRef{nullptr, p->runs_n + i, nullptr, (int32_t)vec_len[i], p->runs_stride};
         }
         if (ml_on) {
             std::vector<size_t> poff((size_t)n_pairs + 1, 0);
@@ -1459,7 +1474,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 h_pw[pi] = pw;
                 for (int k = 0; k < 3; ++k) {
                     const size_t r = n_vec + 3 * (size_t)pi + k;
-                    hrv[r] = RunsRef{p->runs_e + r * RUNS_CAP, p->runs_n + r, planes + (size_t)k * pw, (int32_t)vec_len[b], RUNS_CAP};
+                    hrv[r] = RunsRef{p->runs_e + r * (size_t)p->runs_stride, p->runs_n + r, planes + (size_t)k * pw, (int32_t)vec_len[b], p->runs_stride};
                 }
             }
             HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, o_xf - o_rv, hipMemcpyHostToDevice, st));
@@ -1677,8 +1692,8 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                         proven = false;
                 }
             }
-            const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 8;
-            unsigned long long* d_stats = (unsigned long long*)((char*)p->runs_flags + flag_bytes - 8);
+            const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 16;
+            unsigned long long* d_stats = (unsigned long long*)((char*)p->runs_flags + flag_bytes - 16);  // [boundaries, longest list]
             const int* d_flags = proven ? p->runs_zero_flags : p->runs_flags;
             bool skip_runs = false;  // the probe says every sub-batch is dense: transforms only, nothing extracted
             if (probe_first) {
@@ -1768,7 +1783,23 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                     if (f == 2) bad = true;
                     if (f) chunk_fft[ch] = 1, any_fft = true;
                 }
-                memcpy(&p->runs_last_boundaries, (char*)p->runs_flags_host + flag_bytes - 8, 8);
+                memcpy(&p->runs_last_boundaries, (char*)p->runs_flags_host + flag_bytes - 16, 8);
+                {
+                    // A plan-owned list filled its slot: the call is solved again with four times the room (at most twice:
+                    // 4096 -> 16 384 -> 32 768 entries; what the first attempt wrote is overwritten in stream order), and the
+                    // plan keeps the longer stride.  Which path solves what therefore does not depend on the stride.
+                    long long longest = 0;
+                    memcpy(&longest, (char*)p->runs_flags_host + flag_bytes - 8, 8);
+                    if (need_extract && longest >= p->runs_stride && p->runs_stride < RUNS_CAP) {
+                        p->runs_stride = p->runs_stride * 4 < RUNS_CAP ? p->runs_stride * 4 : RUNS_CAP;
+                        p->runs_calls -= 1;
+                        p->runs_chunks -= n_chunks;
+                        leave.armed = false;
+                        if ((rc = leave_stream(p, st))) return rc;
+                        return align_impl(p, n_pairs, n_cand, ref_dt, dtype, vec_ptr, vec_len, vec_lo, vec_hi, vec_bound, max_offset_samples,
+                                          filter_max_offset, cand_out_dev, pair_out_dev, hip_stream);
+                    }
+                }
                 if (bad)
                     return fail(FFS_E_INVALID, "a boundary list of the call is truncated (more entries than its block holds): "
                                 "nothing can solve it -- pass the vector as bits");

@@ -138,6 +138,28 @@ def test_seven_ratios_without_a_window(headline):
     assert float(score) == pytest.approx(float(g0["score"]), rel=1e-5)
 
 
+def test_plan_owned_lists_grow_with_the_data(torch):
+    """Round 6: the plan's boundary lists (vectors that arrive as bits) start at 4 096 entries per vector and the call is
+    solved again with four times the room when a vector has more (at most twice, up to 32 768): vectors with ~6 800 and
+    ~13 600 boundaries take the run-boundary path on the FIRST call exactly as vectors with ~1 700 do, records identical to
+    the transforms'; the plan keeps the longer stride (the second call extracts once)."""
+    from ffsubsync_amd import batch
+    from workloads import synth
+
+    for scale in (0.25, 0.125):
+        db = synth.build_device_batch([synth.make_pair_spec(7100 + i, run_scale=scale) for i in range(6)])
+        n_fft = db.required_fft_length(6000)
+        want, _ = _solve(db, n_fft, 6000, "fft", pairs_in_flight=6)
+        al = batch.BatchAligner(n_fft, 7, 6000, pairs_in_flight=6, algorithm="runs")
+        for call in range(2):
+            got = al.solve(db)
+            assert al.plan.runs_stats() == (call + 1, call + 1, 0)  # run-boundary path, nothing through the transforms
+            _same_records(got, want)
+            # (boundaries of the call's 48 vectors: every list is longer than the first stride)
+            assert al.plan.runs_boundaries_last_call() > 48 * 4096 * (1 if scale == 0.25 else 2)
+        al.close()
+
+
 @pytest.mark.parametrize("name", sorted(SMALL))
 def test_golden_cases_through_the_dropin_classes(torch, name, monkeypatch):
     """Every reference golden (KATs, lag-window semantics incl. Python negative slices and all-masked windows, float
