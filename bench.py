@@ -110,7 +110,7 @@ def compact_record(result, detail_path=None):
         if not isinstance(r, dict):
             return None
         keep = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "wasted", "avg_launch_ms",
-                "share_of_kernel_time", "per_launch", "peak_source", "lds_conflict_frac")
+                "share_of_kernel_time", "per_launch", "peak_source", "lds_conflict_frac", "frac_of_conflict_free_rate")
         return {k: _num(r[k]) for k in keep if k in r}
 
     for k in ("gathered_records", "gathered_best_cand_valid"):  # N > 1: every rank's records arrived
@@ -1167,17 +1167,20 @@ def main():
         return tot / max(1, n_s), n_s
 
     def lds_roofline(per_kernel, pairs, steps):
-        """`roofline` of k_runs_corr: bound by the LDS scatter-add rate (profiles/lds_atomic_ceiling.hip measures what the
-        chip sustains for uniformly random words: whatever the bank pattern or the active lanes, a ds_add_u32
-        wave-instruction costs ~7.5 LDS cycles, so the ceiling is reached only with all 64 lanes adding)."""
+        """`roofline` of k_runs_corr: bound by the LDS scatter-add rate for uniformly random words (the ceiling is reached
+        only with all 64 lanes adding; `frac_of_conflict_free_rate` prices the same adds against the conflict-free rate)."""
         k = per_kernel["runs_corr"]
         per_pair, n_s = coincidences_per_pair()
         pairs_per_launch = pairs * steps / k["launches"]
-        peak, src = None, os.path.join(ROOT, "profiles", "lds_atomic_ceiling.json")
+        # Ceiling: profiles/lds_issue_rates.hip (round 6: NO vector ALU work between the DS operations; its ds_write_b32 control
+        # reproduces the guide's 4 cycles per wave-instruction).  ds_add_u32 costs 4.08 cycles conflict-free and 7.36 for
+        # uniformly random words (bank conflicts: 32 random addresses per 32 banks) -- the histogram's situation.
+        peak, peak_free, src = None, None, os.path.join(ROOT, "profiles", "lds_issue_rates.json")
         if os.path.exists(src):
             cj = json.load(open(src))
-            cfg_ = cj.get("ds_add_u32_4x512_per_cu") or cj.get("ds_add_u32_2x512_per_cu")
-            peak = (cfg_.get("random_words_packed16_value") or cfg_["random_words"])["lanes_64_Gps"]
+            row = cj["ds_add_u32_32_waves_per_cu"]
+            per_s = 64.0 * cj["cus"] * cj["clock_MHz"] * 1e6
+            peak, peak_free = per_s / row["random_words"] / 1e9, per_s / row["conflict_free"] / 1e9
         achieved = per_pair * pairs_per_launch / (k["avg_ms"] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_per_pair.json")
@@ -1189,7 +1192,10 @@ def main():
                "frac": (achieved / peak) if peak else None, "traffic": traffic,
                "per_launch": per_pair * pairs_per_launch, "avg_launch_ms": k["avg_ms"],
                "share_of_kernel_time": k["total_ms"] / sum(v["total_ms"] for v in per_kernel.values()),
-               "peak_source": "profiles/lds_atomic_ceiling.json: ds_add_u32, uniformly random words, 64 active lanes, whole chip",
+               "frac_of_conflict_free_rate": (achieved / peak_free) if peak_free else None,
+               "peak_source": "profiles/lds_issue_rates.json (VALU-free harness; ds_write_b32 control = the guide's 4 cycles): "
+                              "ds_add_u32 to uniformly random words = 7.36 cycles per wave-instruction (bank conflicts), "
+                              "conflict-free 4.08; 64 lanes x 256 CUs x 2.4 GHz",
                "note": "achieved = boundary coincidences inside the lag window per launch (exact count on the host for the first "
                        "%d pairs x pairs per launch) / average launch duration (HIP events); traffic = PMC-measured HBM bytes "
                        "per launch (the kernel reads the boundary lists: not what bounds it)" % n_s}

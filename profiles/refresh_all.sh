@@ -35,6 +35,7 @@ cp gpurun_out/trace_${TAG}fft/bench_under_rocprof.json "$O/${TAG}_bench_under_ro
 find gpurun_out/trace_${TAG}fft -name "*kernel_stats.csv" -exec cp {} "$O/${TAG}_kernel_stats_fft.csv" \;
 rm -rf gpurun_out/trace_${TAG}fft/*/*.db 2>/dev/null
 profiles/_bin/lds_atomic_ceiling > "$O/lds_atomic_ceiling.json" 2> /dev/null
+for b in lds_issue_rates extract_pattern_ceiling wg_dispatch_rate; do timeout 120 profiles/_bin/$b > "$O/$b.json" 2> /dev/null; done
 # secondary kernels: one kernel trace, two PMC passes
 S=$GRAFT_REPO_ROOT/$O/secondary
 mkdir -p "$S"
