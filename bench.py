@@ -622,8 +622,13 @@ def ingest_inclusive_figures(torch, _native, n_pairs=256, minutes=120.0):
         # memory -- is faster per call when calls are synchronised, 0.31 vs 0.43 ms, but slower in a stream of unsynchronised
         # batches, 0.92 vs 0.52 ms of host time per call: profiles/ingest_profile.py)
 
+        arenas = [None, None]  # (per_batch: the host tables of batch k - 2 are filled again -- its call has long returned)
+
         def run(k):
-            ts = held if held is not None else batch.TrackSet(tracks)
+            if held is not None:
+                ts = held
+            else:
+                ts = arenas[k % 2] = batch.TrackSet(tracks, arena=arenas[k % 2])
             data, offs, lens, bounds = ts.rasterize_runs(track_of, ratio)
             db = batch.DeviceBatch(data, offs.reshape(n_pairs, 8), lens.reshape(n_pairs, 8), np.zeros_like(hi), hi,
                                    _native.FFS_DTYPE_RUNS, None, bounds.reshape(n_pairs, 8))

@@ -128,18 +128,37 @@ class TrackSet:
     concatenated interval tables and each track's extent stay on the host, ``rasterize`` turns any selection of
     (track, ratio) vectors into bit-packed rasters with ONE ``ffs_rasterize_batch_bits`` call."""
 
-    def __init__(self, tracks) -> None:
-        self.counts = np.array([len(t[0]) for t in tracks], dtype=np.int64)
-        self.firsts = (np.concatenate([[0], np.cumsum(self.counts)[:-1]]).astype(np.int64) if len(tracks)
-                       else np.zeros(0, np.int64))
-        cat = lambda k, dt: (np.concatenate([np.asarray(t[k], dtype=dt) for t in tracks]) if len(tracks) else np.zeros(0, dt))
-        self.start_us, self.end_us = cat(0, np.int64), cat(1, np.int64)
+    def __init__(self, tracks, arena: "Optional[TrackSet]" = None) -> None:
+        """``arena``: an earlier TrackSet whose host tables may be overwritten (the caller is done with it: its rasteriser
+        calls have returned -- ``ffs_rasterize_batch_*`` stages pageable tables before it returns) -- a stream of batches
+        then fills the same few megabytes again instead of faulting in fresh pages for every batch."""
+        n = len(tracks)
+        self.counts = np.fromiter((len(t[0]) for t in tracks), dtype=np.int64, count=n)
+        self.firsts = np.zeros(n, dtype=np.int64)
+        if n:
+            np.cumsum(self.counts[:-1], out=self.firsts[1:])
+        total = int(self.counts.sum())
+        # one preallocated table per column, filled in place by ONE concatenation each (no per-track temporaries: arrays that
+        # already have the column's type are copied straight in)
+        base = getattr(arena, "_base", None) if arena is not None and arena._dev is None and arena._pinned is None else None
+        if base is None or base[0].size < total:
+            base = (np.empty(total + total // 8, np.int64), np.empty(total + total // 8, np.int64), np.empty(total + total // 8, np.uint8))
+        self._base = base
+        self.start_us, self.end_us = base[0][:total], base[1][:total]
+        if total:
+            np.concatenate([t[0] for t in tracks], out=self.start_us, casting="unsafe")
+            np.concatenate([t[1] for t in tracks], out=self.end_us, casting="unsafe")
         if all(t[2] is None for t in tracks):
             self.meta = None
         else:  # a track without flags has no metadata lines
-            self.meta = np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else np.asarray(t[2], dtype=np.uint8)
-                                        for t in tracks])
-        self.end_max = np.array([int(np.max(t[1])) if len(t[1]) else 0 for t in tracks], dtype=np.int64)
+            self.meta = base[2][:total]
+            if total:
+                np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else t[2] for t in tracks], out=self.meta, casting="unsafe")
+        # largest end of every track in one vectorised pass (round 5: 512 np.max calls per batch were half of the constructor)
+        self.end_max = np.zeros(n, dtype=np.int64)
+        filled = np.flatnonzero(self.counts > 0)
+        if filled.size:
+            self.end_max[filled] = np.maximum.reduceat(self.end_us, self.firsts[filled])
         self._dev = None  # (start_us, end_us, is_metadata) CUDA tensors once to_device() has uploaded them
         self._pinned = None  # pinned host tensors behind start_us / end_us / meta once pin() has moved them there
 

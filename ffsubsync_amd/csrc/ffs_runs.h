@@ -156,17 +156,21 @@ FFS_DEV float wave_max_f32(float v) {
 // that belongs to its WAVE (ranks from one DPP scan; LDS operations of a wave complete in order, so no barrier), and
 // whenever 64 items are waiting the wave turns them into list entries, one item per lane.
 constexpr int RUNS_XQ = 256;  // items per wave ring (a group of a sweep adds at most 256 per wave)
+// NT threads per workgroup: 256 (eight workgroups per CU: throughput, calls with thousands of vectors) or 1024 (a sweep is
+// 32 KB: a 90 KB vector takes 3 dependent memory round trips instead of 11 -- small calls, where the latency of ONE
+// vector is what the caller waits for).
+template <int NT>
 FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int len, int2* __restrict__ e, int2* __restrict__ hdr,
                                const int cap) {
-    const GWords w = (GWords)w_generic;
-    constexpr int G = 2, SWEEP = 256 * 4 * G;  // words per sweep
+    constexpr int NWV = NT / 64;                // waves
+    constexpr int G = 2, SWEEP = NT * 4 * G;  // words per sweep
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const gptr eb = (gptr)e;
     const int nw = (len + 31) >> 5;     // words that hold samples
     const int n_proc = (len >> 5) + 1;  // word len/32 holds position `len`, where a run that reaches the end closes
     const unsigned tail = (len & 31) ? ((1u << (len & 31)) - 1u) : 0xffffffffu;  // valid bits of word nw - 1
-    __shared__ unsigned s_e[2][4], s_o[2][4];
-    __shared__ __attribute__((aligned(16))) uint4 s_q[4][RUNS_XQ];
+    __shared__ unsigned s_e[2][NWV * 2], s_o[2][NWV * 2];
+    __shared__ __attribute__((aligned(16))) uint4 s_q[NWV][RUNS_XQ];
     uint4* const ring = s_q[wave];
     unsigned q_head = 0, q_tail = 0;   // items [head, tail) of this wave's ring are waiting (wave-uniform)
     unsigned n_bound = 0, n_ones = 0;  // boundaries / ones in front of this sweep
@@ -180,7 +184,7 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
     auto request = [&](int base) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const int w0 = base + (g * 256 + tid) * 4;
+            const int w0 = base + (g * NT + tid) * 4;
             typedef unsigned v4u __attribute__((ext_vector_type(4)));
             // (nontemporal: the samples are read exactly once -- 0.165 -> 0.158 us per pair, profiles/r06_runs_experiments.json)
             const v4u t = __builtin_amdgcn_raw_buffer_load_b128(vrs, w0 * 4, 0, 2);
@@ -213,14 +217,14 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
     request(0);
     int buf = 0;
     for (int base = 0; base < n_proc && n_bound < (unsigned)cap; base += SWEEP, buf ^= 1) {
-        unsigned x[G][4], ee[G][4], pv[G];
+        unsigned x[G][4], pv[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             pv[g] = pn[g];
 #pragma unroll
             for (int k = 0; k < 4; ++k) x[g][k] = xn[g][k];
             // the partial last word: its bits behind the vector's end do not count (one thread of one sweep)
-            const int w0 = base + (g * 256 + tid) * 4;
+            const int w0 = base + (g * NT + tid) * 4;
             if ((unsigned)(nw - 1 - w0) < 4u) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -233,58 +237,85 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
         // the loads' data may be used -- a sweep then pays the write latency on top of the read latency.
         while (q_tail - q_head >= 64u) drain();
         if (base + SWEEP < n_proc) request(base + SWEEP);
-        unsigned pe = 0, po = 0, pc = 0;  // per group, 16 bits each: boundaries, ones, boundary WORDS of this thread
-        unsigned fr[G];                    // bit 31 of the word in front of each group
+        unsigned ne[G], no[G], pc = 0;  // per group: boundaries and ones of this thread; its boundary WORDS (16 bits per group)
+        unsigned fr[G];                  // bit 31 of the word in front of each group
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             unsigned prev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x[g][3], 0x138, 0xf, 0xf, false);  // wave_shr:1
             if (lane == 0) prev = pv[g];
             fr[g] = prev;
-            unsigned ne = 0, no = 0, nc = 0;
+            unsigned nc = 0;
+            ne[g] = no[g] = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ee[g][k] = x[g][k] ^ __builtin_amdgcn_alignbit(x[g][k], prev, 31);  // x ^ (x << 1 | bit 31 of the word in front)
+                const unsigned e_k = x[g][k] ^ __builtin_amdgcn_alignbit(x[g][k], prev, 31);  // x ^ (x << 1 | bit 31 of the word in front)
                 prev = x[g][k];
-                ne += __popc(ee[g][k]);
-                no += __popc(x[g][k]);
-                nc += ee[g][k] != 0u ? 1u : 0u;
+                ne[g] += __popc(e_k);
+                no[g] += __popc(x[g][k]);
+                nc += e_k != 0u ? 1u : 0u;
             }
-            pe |= ne << (16 * g);
-            po |= no << (16 * g);
             pc |= nc << (16 * g);
         }
-        const unsigned ie = wave_incl_scan_u32(pe), io = wave_incl_scan_u32(po), ic = wave_incl_scan_u32(pc);
-        if (lane == 63) s_e[buf][wave] = ie, s_o[buf][wave] = io;
-        __syncthreads();  // (two buffers: the next sweep's totals cannot overwrite these while they are read)
-        unsigned xe = ie - pe, xo = io - po, te = 0, to = 0;  // exclusive in-block prefixes, block totals
+        const unsigned ic = wave_incl_scan_u32(pc);
+        // exclusive in-block prefixes and block totals of (boundaries, ones) per group
+        unsigned qe = 0, qo = 0, se = 0, so = 0;  // NT <= 256: both groups packed 2 x 16 bits (a field sums to at most 256 * 128)
+        unsigned ie[G], io[G];                    // wider workgroups: one scan per group and quantity
+        if (NT <= 256) {
+            static_assert(G == 2, "two groups per packed scan");
+            const unsigned pe = ne[0] | (ne[1] << 16), po = no[0] | (no[1] << 16);
+            const unsigned je = wave_incl_scan_u32(pe), jo = wave_incl_scan_u32(po);
+            if (lane == 63) s_e[buf][wave] = je, s_o[buf][wave] = jo;
+            __syncthreads();  // (two buffers: the next sweep's totals cannot overwrite these while they are read)
+            qe = je - pe, qo = jo - po;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned a = s_e[buf][i], b = s_o[buf][i];
-            if (i < wave) xe += a, xo += b;
-            te += a, to += b;
+            for (int i = 0; i < NWV; ++i) {
+                const unsigned a = s_e[buf][i], b = s_o[buf][i];
+                if (i < wave) qe += a, qo += b;
+                se += a, so += b;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                ie[g] = wave_incl_scan_u32(ne[g]), io[g] = wave_incl_scan_u32(no[g]);
+                if (lane == 63) s_e[buf][wave * G + g] = ie[g], s_o[buf][wave * G + g] = io[g];
+                ie[g] -= ne[g], io[g] -= no[g];
+            }
+            __syncthreads();
         }
         const unsigned wc = (unsigned)__builtin_amdgcn_readlane((int)ic, 63);  // this wave's boundary words, per group
         const unsigned rc = ic - pc;                                           // ranks inside the wave
         unsigned gb = n_bound, go = n_ones;  // boundaries / ones in front of group g of thread 0
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            unsigned k_out = gb + ((xe >> (16 * g)) & 0xffffu);
-            unsigned ones = go + ((xo >> (16 * g)) & 0xffffu);
-            gb += (te >> (16 * g)) & 0xffffu;
-            go += (to >> (16 * g)) & 0xffffu;
+            unsigned xe_g, xo_g, te_g = 0, to_g = 0;
+            if (NT <= 256) {
+                xe_g = (qe >> (16 * g)) & 0xffffu, xo_g = (qo >> (16 * g)) & 0xffffu, te_g = (se >> (16 * g)) & 0xffffu, to_g = (so >> (16 * g)) & 0xffffu;
+            } else {
+                xe_g = ie[g], xo_g = io[g];
+                for (int i = 0; i < NWV; ++i) {
+                    const unsigned a = s_e[buf][i * G + g], b = s_o[buf][i * G + g];
+                    if (i < wave) xe_g += a, xo_g += b;
+                    te_g += a, to_g += b;
+                }
+            }
+            unsigned k_out = gb + xe_g;
+            unsigned ones = go + xo_g;
+            gb += te_g;
+            go += to_g;
             const unsigned add = (wc >> (16 * g)) & 0xffffu;  // (<= 256 = the ring)
             {
             while (q_tail - q_head + add > (unsigned)RUNS_XQ) drain();
             unsigned slot = q_tail + ((rc >> (16 * g)) & 0xffffu);
-            const unsigned w0 = (unsigned)(base + (g * 256 + tid) * 4);
+            const unsigned w0 = (unsigned)(base + (g * NT + tid) * 4);
             unsigned prev = fr[g];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                if (ee[g][k]) {
+                const unsigned e_k = x[g][k] ^ __builtin_amdgcn_alignbit(x[g][k], prev, 31);  // (again: cheaper than keeping eight words alive)
+                if (e_k) {
                     ring[slot & (RUNS_XQ - 1)] = make_uint4((w0 + k) | (prev & 0x80000000u), x[g][k], ones, k_out);
                     ++slot;
                 }
-                k_out += __popc(ee[g][k]);
+                k_out += __popc(e_k);
                 ones += __popc(x[g][k]);
                 prev = x[g][k];
             }
@@ -335,21 +366,50 @@ __global__ __launch_bounds__(256) void k_runs_probe(const RunsRef* __restrict__ 
 __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs) {
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
-    runs_extract_body(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    runs_extract_body<256>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+}
+// The same for calls with few vectors: a vector's latency, not the chip's throughput, is what such a call waits for.  At
+// most 256 vectors: 1024-thread workgroups (one per CU, 3 sweeps per 90 KB vector); at most 768: 512 threads (three per CU,
+// 6 sweeps); more: 256 threads (eight per CU, 11 sweeps -- the wide instantiations need more than 64 registers, so they
+// only pay while every vector of the call is resident at once).  See runs_extract_launch().
+__global__ __launch_bounds__(512, 4) void k_runs_extract_512(const RunsRef* __restrict__ refs, int with_len_cap) {
+    const RunsRef r = refs[blockIdx.x];
+    if (!r.bits) return;
+    if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
+    runs_extract_body<512>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+}
+__global__ __launch_bounds__(1024, 4) void k_runs_extract_1024(const RunsRef* __restrict__ refs, int with_len_cap) {
+    const RunsRef r = refs[blockIdx.x];
+    if (!r.bits) return;
+    if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
+    runs_extract_body<1024>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 
 // vectors into caller-owned list blocks (ffs_runs_from_bits_batch): the block header also gets (len, cap)
 __global__ __launch_bounds__(256, 8) void k_runs_extract_lists(const RunsRef* __restrict__ refs) {
     const RunsRef r = refs[blockIdx.x];
     if (threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
-    runs_extract_body(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    runs_extract_body<256>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 
 // one vector into a caller-owned list (ffs_runs_from_bits)
-__global__ __launch_bounds__(256, 8) void k_runs_extract_one(const unsigned* __restrict__ bits, int len, int2* __restrict__ e,
+__global__ __launch_bounds__(1024, 4) void k_runs_extract_one(const unsigned* __restrict__ bits, int len, int2* __restrict__ e,
                                                              int2* __restrict__ hdr, int cap) {
     if (threadIdx.x == 0) hdr[1] = make_int2(len, cap);
-    runs_extract_body(bits, len, e, hdr, cap);
+    runs_extract_body<1024>(bits, len, e, hdr, cap);
+}
+
+// every vector of `refs` that arrived as bits -> its list, with the workgroup size that suits the number of vectors
+// (`with_len_cap`: caller-owned blocks, whose header also carries (len, cap))
+static inline void runs_extract_launch(const RunsRef* refs, size_t n_vec, bool with_len_cap, hipStream_t st) {
+    if (n_vec <= 256)
+        hipLaunchKernelGGL(k_runs_extract_1024, dim3((unsigned)n_vec), dim3(1024), 0, st, refs, with_len_cap ? 1 : 0);
+    else if (n_vec <= 768)  // (72 registers: three 512-thread workgroups per CU)
+        hipLaunchKernelGGL(k_runs_extract_512, dim3((unsigned)n_vec), dim3(512), 0, st, refs, with_len_cap ? 1 : 0);
+    else if (with_len_cap)
+        hipLaunchKernelGGL(k_runs_extract_lists, dim3((unsigned)n_vec), dim3(256), 0, st, refs);
+    else
+        hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, refs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

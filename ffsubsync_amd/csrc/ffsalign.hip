@@ -1498,7 +1498,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             HIP_TRY(hipGetLastError());
             {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_rr), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_rr, false, st);
             }
             HIP_TRY(hipGetLastError());
         } else if (need_extract) {
@@ -1512,7 +1512,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 hipLaunchKernelGGL(k_runs_probe, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, st, (const RunsRef*)(db + o_rv), (int)n_vec);
             } else {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st);
             }
             HIP_TRY(hipGetLastError());
         }
@@ -1711,7 +1711,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 for (int ch = 0; ch < n_chunks; ++ch) skip_runs = skip_runs && p->runs_flags_host[ch] == 1;
                 if (!skip_runs) {  // not (any more) a dense stream: the usual order from here on
                     ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                    hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)(db + o_rv));
+                    runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st);
                 }
                 HIP_TRY(hipGetLastError());
             }
@@ -2013,7 +2013,7 @@ int ffs_runs_from_bits(const uint32_t* bits_dev, int64_t len, void* list_dev, in
     DeviceGuard guard;
     int rc_dev;
     if ((rc_dev = guard.enter(list_dev))) return rc_dev;
-    hipLaunchKernelGGL(k_runs_extract_one, dim3(1), dim3(256), 0, st, (const unsigned*)bits_dev, (int)len,
+    hipLaunchKernelGGL(k_runs_extract_one, dim3(1), dim3(1024), 0, st, (const unsigned*)bits_dev, (int)len,
                        (int2*)((char*)list_dev + 16), (int2*)list_dev, (int)cap);
     HIP_TRY(hipGetLastError());
     return FFS_OK;
@@ -2443,7 +2443,7 @@ int ffs_runs_from_bits_batch(const uint32_t* const* bits_dev, const int64_t* len
     if (hipMemcpyAsync(d, hr, (size_t)n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st) != hipSuccess) rc = fail(FFS_E_HIP, "copying the vector table failed");
     if (rc == FFS_OK && hipEventRecord(stage->done, st) == hipSuccess) stage->pending = true;
     if (rc == FFS_OK) {
-        hipLaunchKernelGGL(k_runs_extract_lists, dim3((unsigned)n_vec), dim3(256), 0, st, (const RunsRef*)d);
+        runs_extract_launch((const RunsRef*)d, (size_t)n_vec, true, st);
         if (hipGetLastError() != hipSuccess) rc = fail(FFS_E_HIP, "k_runs_extract_lists launch failed");
     }
     (void)hipFreeAsync(d, st);

@@ -385,3 +385,40 @@ def test_device_copy_cache_key_sees_every_in_place_edit():
         assert sr._vector_key(y) != k0
     assert sr._vector_key(x.astype(np.float32)) != k0 and sr._vector_key(x.reshape(2, -1)) != k0
     assert sr._vector_key(np.zeros(0)) is None and sr._vector_key([1.0, 0.0]) is None
+
+
+def test_trackset_tables_and_arena_reuse():
+    """TrackSet lays the per-track interval arrays out in one table per column (one concatenation each, the largest end of
+    every track by one reduceat); with ``arena=`` the tables of an earlier TrackSet are filled again.  Same tables as the
+    straightforward per-track construction: empty tracks, tracks without metadata flags, list inputs."""
+    import numpy as np
+
+    from ffsubsync_amd.batch import TrackSet
+
+    rng = np.random.RandomState(4)
+    tracks = []
+    for k in range(40):
+        n = int(rng.randint(0, 50)) if k % 7 else 0
+        s = np.sort(rng.randint(0, 10 ** 9, n)).astype(np.int64)
+        e = s + rng.randint(1, 10 ** 6, n)
+        m = None if k % 3 == 0 else (rng.rand(n) < 0.1).astype(np.uint8)
+        tracks.append((s.tolist(), e, m) if k == 5 else (s, e, m))
+
+    def check(ts):
+        assert np.array_equal(ts.counts, [len(t[0]) for t in tracks])
+        assert np.array_equal(ts.firsts, np.concatenate([[0], np.cumsum(ts.counts)[:-1]]))
+        assert np.array_equal(ts.start_us, np.concatenate([np.asarray(t[0], dtype=np.int64) for t in tracks]))
+        assert np.array_equal(ts.end_us, np.concatenate([np.asarray(t[1], dtype=np.int64) for t in tracks]))
+        assert np.array_equal(ts.meta, np.concatenate([np.zeros(len(t[0]), np.uint8) if t[2] is None else t[2] for t in tracks]))
+        assert np.array_equal(ts.end_max, [int(np.max(t[1])) if len(t[1]) else 0 for t in tracks])
+        assert ts.start_us.dtype == np.int64 and ts.end_us.dtype == np.int64 and ts.meta.dtype == np.uint8
+
+    first = TrackSet(tracks)
+    check(first)
+    again = TrackSet(tracks, arena=first)
+    check(again)
+    assert again.start_us.base is first._base[0]  # the same memory
+    bigger = TrackSet(tracks + tracks, arena=again)  # does not fit: fresh tables
+    assert bigger.start_us.size == 2 * again.start_us.size and bigger._base is not again._base
+    assert TrackSet([(np.zeros(0, np.int64), np.zeros(0, np.int64), None)]).meta is None
+    assert TrackSet([]).start_us.size == 0
