@@ -2615,33 +2615,66 @@ struct TokView {
     }
 };
 
-__global__ __launch_bounds__(256) void k_vad_tokenize_scan(const float* __restrict__ valid, long long n_frames, long long chunk,
-                                                          int min_len, int max_len, int max_sil, float non_speech,
-                                                          float* __restrict__ out, int lds_frames) {
+// Round 6: 1024 threads per chunk (a 90-minute file has only 54 chunks of 100 s: what counts is a chunk's latency),
+// validity flags read and labels written COALESCED through LDS (round 5: every thread walked its own 40 consecutive frames
+// in global memory), segments of an odd number of frames (LDS bank spread), the segment carries combined by wave scans
+// instead of 256-step loops: 76 -> ~15 us per 90-minute file.
+constexpr int TOK_THREADS = 1024;
+template <class Op>
+FFS_DEV int tok_block_excl_scan(int v, int identity, Op op, int* s_w, bool backward) {
+    // exclusive scan of one int per thread over the block (forward: threads before this one, op(earlier, later); backward:
+    // threads behind this one, op(nearer, farther))
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = backward ? __shfl_down(incl, d, 64) : __shfl_up(incl, d, 64);
+        if (backward ? (lane + d < 64) : (lane >= d)) incl = backward ? op(incl, o) : op(o, incl);  // op(nearer to the start, farther)
+    }
+    int excl = backward ? __shfl_down(incl, 1, 64) : __shfl_up(incl, 1, 64);
+    if (backward ? lane == 63 : lane == 0) excl = identity;
+    __syncthreads();  // (s_w may still be read by the previous scan)
+    if (backward ? lane == 0 : lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int pre = identity;
+    if (backward) {
+        for (int w = TOK_THREADS / 64 - 1; w > wave; --w) pre = op(s_w[w], pre);
+    } else {
+        for (int w = 0; w < wave; ++w) pre = op(pre, s_w[w]);
+    }
+    return backward ? op(excl, pre) : op(pre, excl);
+}
+
+__global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* __restrict__ valid, long long n_frames, long long chunk,
+                                                                  int min_len, int max_len, int max_sil, float non_speech,
+                                                                  float* __restrict__ out, int lds_frames) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     short* s_lastv = reinterpret_cast<short*>(smem);
     short* s_isl = s_lastv + lds_frames;
     short* s_nxt = s_isl + lds_frames;
-    __shared__ int s_carry[256];
-    __shared__ double s_sum[256];
+    signed char* s_code = reinterpret_cast<signed char*>(s_nxt + lds_frames);  // validity flags, later marker codes (+1 / -1 / 0)
+    float* s_lab = reinterpret_cast<float*>(smem);                              // the labels, over lastv + isl once those are dead
+    __shared__ int s_w[TOK_THREADS / 64];
+    __shared__ double s_ws[TOK_THREADS / 64];
     const long long f0 = (long long)blockIdx.x * chunk;
     if (f0 >= n_frames) return;
     const int n = (int)((f0 + chunk) < n_frames ? chunk : (n_frames - f0));
     const float* v = valid + f0;
     float* o = out + f0;
-    const int tid = threadIdx.x;
-    const int seg = (n + 255) / 256, a = tid * seg < n ? tid * seg : n, b = (a + seg) < n ? (a + seg) : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seg = ((n + TOK_THREADS - 1) / TOK_THREADS) | 1;  // odd: consecutive threads start in different banks
+    const int a = tid * seg < n ? tid * seg : n, b = (a + seg) < n ? (a + seg) : n;
     const int ms = max_sil > 0 ? max_sil : 0;
+    for (int i = tid; i < n; i += TOK_THREADS) s_code[i] = v[i] != 0.0f ? 1 : 0;
+    __syncthreads();
+    auto imax = [](int x, int y) { return x > y ? x : y; };
     // scan 1: last valid index
     int cur = -1;
     for (int i = a; i < b; ++i) {
-        if (v[i] != 0.0f) cur = i;
+        if (s_code[i]) cur = i;
         s_lastv[i] = (short)cur;
     }
-    s_carry[tid] = cur;
-    __syncthreads();
-    int pre = -1;
-    for (int t = 0; t < tid; ++t) pre = s_carry[t] > pre ? s_carry[t] : pre;
+    int pre = tok_block_excl_scan(cur, -1, imax, s_w, false);
     for (int i = a; i < b && s_lastv[i] < 0; ++i) s_lastv[i] = (short)pre;
     __syncthreads();
     auto in_island = [&](int i) { const int lv = s_lastv[i]; return lv >= 0 && i - lv <= ms; };
@@ -2652,11 +2685,7 @@ __global__ __launch_bounds__(256) void k_vad_tokenize_scan(const float* __restri
         if (in && s_lastv[i] == i && !(i > 0 && in_island(i - 1))) cur = i;
         s_isl[i] = (short)(in ? cur : -1);
     }
-    __syncthreads();
-    s_carry[tid] = cur;
-    __syncthreads();
-    pre = -2;
-    for (int t = 0; t < tid; ++t) pre = s_carry[t] > pre ? s_carry[t] : pre;  // starts are increasing: the latest one
+    pre = tok_block_excl_scan(cur, -2, imax, s_w, false);  // starts are increasing: the latest one
     for (int i = a; i < b && s_isl[i] == -2; ++i) s_isl[i] = (short)pre;
     // scan 3 (backward): first frame behind i that is outside every island
     cur = -1;  // unknown within this segment
@@ -2664,36 +2693,45 @@ __global__ __launch_bounds__(256) void k_vad_tokenize_scan(const float* __restri
         s_nxt[i] = (short)cur;
         if (!in_island(i)) cur = i;
     }
-    __syncthreads();
-    s_carry[tid] = cur;
-    __syncthreads();
-    pre = n;
-    for (int t = 255; t > tid; --t) pre = (s_carry[t] >= 0) ? s_carry[t] : pre;  // the nearest later segment that has one
+    // the nearest later segment that has one: "first known" over the threads behind this one
+    pre = tok_block_excl_scan(cur, -1, [](int nearer, int farther) { return nearer >= 0 ? nearer : farther; }, s_w, true);
+    if (pre < 0) pre = n;
     for (int i = b - 1; i >= a && s_nxt[i] < 0; --i) s_nxt[i] = (short)pre;
     __syncthreads();
-    // markers (kept in the output buffer) and their fp64 prefix sum
+    // marker codes (over the validity flags, which nothing reads any more) and their fp64 prefix sum
     TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil};
+    const float m_end = non_speech - 1.0f;
     double acc = 0.0;
     for (int i = a; i < b; ++i) {
-        float m = 0.0f;
+        signed char c = 0;
         const int s = s_isl[i];
         if (s >= 0 && (i - s) % max_len == 0 && tv.delivered(i)) {
-            m = 1.0f;
+            c = 1;
         } else if (i >= 1 && s_isl[i - 1] >= 0) {
             const int off = (i - 1 - s_isl[i - 1]) % max_len;
-            if ((off == max_len - 1 || i == s_nxt[i - 1]) && tv.delivered(i - 1 - off)) m = non_speech - 1.0f;
+            if ((off == max_len - 1 || i == s_nxt[i - 1]) && tv.delivered(i - 1 - off)) c = -1;
         }
-        o[i] = m;
-        acc += (double)m;
+        s_code[i] = c;
+        acc += c > 0 ? 1.0 : (c < 0 ? (double)m_end : 0.0);
     }
-    s_sum[tid] = acc;
-    __syncthreads();
-    acc = 0.0;
-    for (int t = 0; t < tid; ++t) acc += s_sum[t];
+    // block-wide exclusive prefix of the segment sums (fp64; every term is a float, the sums are exact in any order)
+    double incl = acc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) s_ws[wave] = incl;
+    __syncthreads();  // (also: every thread is done with lastv / isl / nxt -- the labels go over them)
+    double run = incl - acc;
+    for (int w = 0; w < wave; ++w) run += s_ws[w];
     for (int i = a; i < b; ++i) {
-        acc += (double)o[i];
-        o[i] = (float)fmin(fmax(acc, 0.0), 1.0);
+        const signed char c = s_code[i];
+        run += c > 0 ? 1.0 : (c < 0 ? (double)m_end : 0.0);
+        s_lab[i] = (float)fmin(fmax(run, 0.0), 1.0);
     }
+    __syncthreads();
+    for (int i = tid; i < n; i += TOK_THREADS) o[i] = s_lab[i];
 }
 
 // ---- subtitle rasteriser arithmetic, shared by the host entry points and the batched kernel --------------------
