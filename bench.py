@@ -1377,11 +1377,15 @@ def main():
                     specs = [synth.make_pair_spec(7000 + i, duration_s=args.duration, run_scale=scale) for i in range(P)]
                     db = synth.build_device_batch(specs)
                     n_s = db.required_fft_length(6000)
-                    el_a, kt_a, _ = timed(n_s, 3, 1)
+                    # (dense rows: ~4 ms per step either way -- eight timed steps each, so that a 1 % difference between the
+                    # automatic choice and the forced transforms is not launch-to-launch noise)
+                    n_st = 3 if scale >= 0.25 else 8
+                    el_a, kt_a, _ = timed(n_s, n_st, 2)
                     path_a = info_now["path"]
                     bnd = info_now["boundaries_last_call"] / (P * 8.0)
                     pa_ = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P].copy()
-                    el_f, _, _ = timed(n_s, 3, 1, algorithm="fft")
+                    el_f, _, _ = timed(n_s, n_st, 2, algorithm="fft")
+                    el_a, el_f = el_a * 3 / n_st, el_f * 3 / n_st  # (the figures below are per three steps)
                     pf_ = pair_out.cpu().numpy().view(_native.PAIR_RESULT_DTYPE)[:P]
                     sweep.append({
                         "run_scale": scale, "boundaries_per_vector": bnd, "auto_solves_per_s": P * 3 / el_a, "auto_path": path_a,
