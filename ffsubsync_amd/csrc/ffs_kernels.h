@@ -2589,21 +2589,39 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
 // marker prefix sum (fp64).  oracle/vad_oracle.py::tokenize_chunk_scan is the numpy model of exactly this, tested
 // against the state machine on the CPU.  Chunks of up to TOK_SCAN_MAX frames (16-bit indices in LDS).
 constexpr int TOK_SCAN_MAX = 20480;
+// x / m and x % m for 0 <= x < 2^20 and a divisor that is the same for the whole kernel (max_len): the GPU has no integer
+// divider -- a `%` costs ~35 instructions, and the marker pass needs two per frame.  One multiplication by the float
+// reciprocal is off by at most one; two selects correct it.
+struct TokDiv {
+    int m;
+    float inv;
+    FFS_DEV explicit TokDiv(int m_) : m(m_), inv(1.0f / (float)m_) {}
+    FFS_DEV int div(int x) const {
+        int q = (int)((float)x * inv);
+        const int r = x - q * m;
+        q -= r < 0 ? 1 : 0;
+        q += r >= m ? 1 : 0;
+        return q;
+    }
+    FFS_DEV int mod(int x) const { return x - div(x) * m; }
+};
 struct TokView {
     const short* lastv;  // last valid index <= i, -1 if none
     const short* isl;    // start of the island frame i belongs to, -1 if outside
     const short* nxt;    // first index > i outside every island (n if none)
     int n, min_len, max_len, max_sil;
+    TokDiv dv;
     FFS_DEV bool c_in(int s) const {
         if (max_sil <= 0 || s == 0) return false;
         const int lp = lastv[s - 1];
         if (lp < 0) return false;
         const int lenp = lp + max_sil - isl[lp] + 1;
-        return lenp / max_len >= 1 && lenp % max_len <= max_sil;
+        const int qd = dv.div(lenp);
+        return qd >= 1 && lenp - qd * max_len <= max_sil;
     }
     FFS_DEV bool delivered(int i0) const {  // the piece that starts at frame i0
         const int s = isl[i0], e_isl = nxt[i0] - 1;
-        const int j = (i0 - s) / max_len;
+        const int j = dv.div(i0 - s);
         const int e = (i0 + max_len - 1) < e_isl ? (i0 + max_len - 1) : e_isl;
         const int r = e - i0 + 1;
         if (r == max_len) return true;
@@ -2699,16 +2717,17 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
     for (int i = b - 1; i >= a && s_nxt[i] < 0; --i) s_nxt[i] = (short)pre;
     __syncthreads();
     // marker codes (over the validity flags, which nothing reads any more) and their fp64 prefix sum
-    TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil};
+    const TokDiv dv(max_len);
+    TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil, dv};
     const float m_end = non_speech - 1.0f;
     double acc = 0.0;
     for (int i = a; i < b; ++i) {
         signed char c = 0;
         const int s = s_isl[i];
-        if (s >= 0 && (i - s) % max_len == 0 && tv.delivered(i)) {
+        if (s >= 0 && dv.mod(i - s) == 0 && tv.delivered(i)) {
             c = 1;
         } else if (i >= 1 && s_isl[i - 1] >= 0) {
-            const int off = (i - 1 - s_isl[i - 1]) % max_len;
+            const int off = dv.mod(i - 1 - s_isl[i - 1]);
             if ((off == max_len - 1 || i == s_nxt[i - 1]) && tv.delivered(i - 1 - off)) c = -1;
         }
         s_code[i] = c;
