@@ -39,7 +39,8 @@ constexpr int RUNS_CAP = 32768;                   // boundary-list entries per v
 #define FFS_RUNS_TPW 2
 #endif
 constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate boundaries each) a wave advances together
-constexpr int RUNS_QSENT = 0x3fffffff;            // staged sentinel: beyond every position (vectors are shorter than 2^30)
+constexpr int RUNS_QSENT = 0x1fffffff;            // staged sentinel: beyond every position (a plan's vectors are shorter than 2^24); DOUBLED in
+                                                  // LDS, and sentinel - position must not overflow 32 bits for any position > -2^26
 static_assert(RUNS_LPT <= 32 && RUNS_LPT % 8 == 0 && RUNS_QCAP % 2 == 0, "one 32-bit mask per thread, 16-byte histogram loads");
 
 // One vector of a call as the run-boundary kernels see it.  e[k] = (position of boundary k, ones of the vector in front of
