@@ -195,6 +195,9 @@ int ffs_runs_to_bits(const void* list_dev, int64_t len, uint32_t* bits_out_dev, 
  *     float vector (more levels, no common quantum, noise) and every other element type go through the transforms.
  *   FFS_ALGO_FFT: transforms only (the path of rounds 1-3).
  *   FFS_ALGO_RUNS: like AUTO without the coincidence budget (truncated boundary lists still fall back).
+ *   Boundary lists of vectors that arrive as bits live in the plan, 4 096 entries per vector to start with (FFS_RUNS_STRIDE);
+ *   a call that meets a longer list is solved again with four times the room (at most twice, up to 32 768 entries) and
+ *   the plan keeps the longer stride -- which path solves what does not depend on it.
  * Environment: FFS_ALGORITHM=auto|fft|runs presets new plans, FFS_RUNS_BUDGET=<coincidences> the budget. */
 #define FFS_ALGO_AUTO 0
 #define FFS_ALGO_FFT 1
