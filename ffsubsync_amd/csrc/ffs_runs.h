@@ -364,7 +364,14 @@ __global__ __launch_bounds__(256) void k_runs_probe(const RunsRef* __restrict__ 
 }
 
 // every vector of a call that arrived as bits (list-only vectors are skipped)
-__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs) {
+// (`zero`, `zero_words`: the call's sub-batch flags + statistics, cleared by workgroup 0 -- the kernels that use them run behind
+// this one; a separate hipMemsetAsync is two ~4.5 us fill kernels on the stream, a tenth of a 128-pair step)
+FFS_DEV void runs_extract_zero(int* __restrict__ zero, int zero_words) {
+    if (zero && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;
+}
+__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs, int* __restrict__ zero, int zero_words) {
+    runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
     runs_extract_body<256>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
@@ -373,13 +380,17 @@ __global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restri
 // most 256 vectors: 1024-thread workgroups (one per CU, 3 sweeps per 90 KB vector); at most 768: 512 threads (three per CU,
 // 6 sweeps); more: 256 threads (eight per CU, 11 sweeps -- the wide instantiations need more than 64 registers, so they
 // only pay while every vector of the call is resident at once).  See runs_extract_launch().
-__global__ __launch_bounds__(512, 4) void k_runs_extract_512(const RunsRef* __restrict__ refs, int with_len_cap) {
+__global__ __launch_bounds__(512, 4) void k_runs_extract_512(const RunsRef* __restrict__ refs, int with_len_cap, int* __restrict__ zero,
+                                                             int zero_words) {
+    runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
     if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
     runs_extract_body<512>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
-__global__ __launch_bounds__(1024, 4) void k_runs_extract_1024(const RunsRef* __restrict__ refs, int with_len_cap) {
+__global__ __launch_bounds__(1024, 4) void k_runs_extract_1024(const RunsRef* __restrict__ refs, int with_len_cap, int* __restrict__ zero,
+                                                               int zero_words) {
+    runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
     if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
@@ -402,15 +413,16 @@ __global__ __launch_bounds__(1024, 4) void k_runs_extract_one(const unsigned* __
 
 // every vector of `refs` that arrived as bits -> its list, with the workgroup size that suits the number of vectors
 // (`with_len_cap`: caller-owned blocks, whose header also carries (len, cap))
-static inline void runs_extract_launch(const RunsRef* refs, size_t n_vec, bool with_len_cap, hipStream_t st) {
+static inline void runs_extract_launch(const RunsRef* refs, size_t n_vec, bool with_len_cap, hipStream_t st, int* zero = nullptr,
+                                       int zero_words = 0) {
     if (n_vec <= 256)
-        hipLaunchKernelGGL(k_runs_extract_1024, dim3((unsigned)n_vec), dim3(1024), 0, st, refs, with_len_cap ? 1 : 0);
+        hipLaunchKernelGGL(k_runs_extract_1024, dim3((unsigned)n_vec), dim3(1024), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words);
     else if (n_vec <= 768)  // (72 registers: three 512-thread workgroups per CU)
-        hipLaunchKernelGGL(k_runs_extract_512, dim3((unsigned)n_vec), dim3(512), 0, st, refs, with_len_cap ? 1 : 0);
+        hipLaunchKernelGGL(k_runs_extract_512, dim3((unsigned)n_vec), dim3(512), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words);
     else if (with_len_cap)
         hipLaunchKernelGGL(k_runs_extract_lists, dim3((unsigned)n_vec), dim3(256), 0, st, refs);
     else
-        hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, refs);
+        hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, refs, zero, zero_words);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

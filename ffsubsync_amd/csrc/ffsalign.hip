@@ -100,6 +100,8 @@ constexpr long long kRunsBudgetPerPoint = 12;
 // the transforms (a list that fills its slot counts as over budget), the next call has the room.  A 256 KB stride for 16 KB
 // lists cost 4 % of k_runs_extract (65 536 lists spread over 16 GB of address space).
 constexpr int kRunsStride0 = 4096;
+// calls of at most this many candidates upload their descriptors once and launch the extraction behind them (see late_extract)
+constexpr size_t kSmallCallCands = 4096;
 constexpr int kSegBlocks = 3;    // blocks per candidate in block-segmented mode (n_fft = 3 * block transform length)
 constexpr int kCollectRows = 4;  // grid rows of the exhaustive last pass (each walks the flagged-candidate list)
 
@@ -1429,6 +1431,16 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     RunsRef* hrv = (RunsRef*)(hb + o_rv);
     char* db = (char*)p->dev_desc;
     bool probe_first = false;           // (run-boundary path) a density probe stands in for the extraction so far
+    // sub-batch flags + two 8-byte statistics behind them (boundaries of the call, its longest plan-owned list): cleared by the
+    // extraction kernel's first workgroup when one is launched, by a memset otherwise
+    const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 16;
+    bool flags_cleared = false;
+    // Small calls: ONE upload (vector table + candidate descriptors) and the extraction behind it, instead of the table, the
+    // extraction and then the candidates -- the host takes longer to build ~1000 descriptors than the device to extract
+    // 1000 lists, so the early launch only moved a 20 us hole behind the extraction and cost one more stream operation
+    // (profiles/small_step_timeline.py).  Large calls keep the early launch: the device reads the vectors while the host
+    // builds tens of thousands of descriptors.
+    bool late_extract = false;
     const void* const* xptr = vec_ptr;  // the vectors as the transform path reads them (list-only vectors: their expansion)
     std::vector<const void*> expanded;
     if (runs_ok) {
@@ -1498,9 +1510,12 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             HIP_TRY(hipGetLastError());
             {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                runs_extract_launch((const RunsRef*)(db + o_rv), n_rr, false, st);
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_rr, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+                flags_cleared = true;
             }
             HIP_TRY(hipGetLastError());
+        } else if (need_extract && n_cands <= kSmallCallCands && !(p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in)) {
+            late_extract = true;  // (uploaded and launched behind the candidate descriptors, below)
         } else if (need_extract) {
             HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
             leave.armed = true;
@@ -1512,7 +1527,8 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 hipLaunchKernelGGL(k_runs_probe, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, st, (const RunsRef*)(db + o_rv), (int)n_vec);
             } else {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st);
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+                flags_cleared = true;
             }
             HIP_TRY(hipGetLastError());
         }
@@ -1644,12 +1660,18 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!runs_ok && (rc = build_xforms())) return rc;
     // one upload when the transforms run anyway; with the run-boundary path [header, candidates] (+ the vector table
     // when no extraction was launched ahead of it)
-    if (runs_ok && !need_extract)
+    if (runs_ok && (!need_extract || late_extract))
         HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_rr * sizeof(RunsRef), hipMemcpyHostToDevice, st));
     else
         HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
     leave.armed = true;
     HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
+    if (late_extract) {
+        ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
+        runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+        flags_cleared = true;
+        HIP_TRY(hipGetLastError());
+    }
     const CandDesc* dc = (const CandDesc*)(db + o_cand);
     const XformDesc* dx = (const XformDesc*)(db + o_xf);
     NomList* dn = (NomList*)(db + o_nom);
@@ -1692,7 +1714,6 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                         proven = false;
                 }
             }
-            const size_t flag_bytes = (((size_t)n_chunks * sizeof(int) + 7) & ~(size_t)7) + 16;
             unsigned long long* d_stats = (unsigned long long*)((char*)p->runs_flags + flag_bytes - 16);  // [boundaries, longest list]
             const int* d_flags = proven ? p->runs_zero_flags : p->runs_flags;
             bool skip_runs = false;  // the probe says every sub-batch is dense: transforms only, nothing extracted
@@ -1727,7 +1748,9 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 HIP_TRY(hipEventRecord(p->upload_done, st));
             } else {
             if (!proven) {
-                HIP_TRY(hipMemsetAsync(p->runs_flags, 0, flag_bytes, st));  // (flags + the boundary counter behind them)
+                // (flags + the statistics behind them: cleared by the extraction kernel of this call unless a probe has
+                // written estimates into them since, or no extraction ran)
+                if (!flags_cleared || probe_first) HIP_TRY(hipMemsetAsync(p->runs_flags, 0, flag_bytes, st));
                 if (ml_on)
                     hipLaunchKernelGGL(k_runs_chunk_flags_ml, dim3((unsigned)n_chunks), dim3(256), 0, st, dc, n_pairs, n_cand,
                                        p->pairs_in_flight, (const RunsRef*)(db + o_rv), (const LevelInfo*)(db + o_li), (int)n_vec, budget,
