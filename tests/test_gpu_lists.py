@@ -145,6 +145,62 @@ def test_runs_from_bits_round_trip(torch, n, density, run):
         assert raw[0] >= 8 and (raw[4 + 16:] == -7).all()
 
 
+@pytest.mark.parametrize("n_vec", [24, 300, 900])
+def test_batched_extraction_in_every_workgroup_size(torch, n_vec):
+    """``ffs_runs_from_bits_batch`` picks the extraction kernel by the number of vectors of the call (round 6: 1024-thread
+    workgroups up to 256 vectors, 512 threads up to 768, 256 beyond): random vectors of 1 .. 40 000 samples -- lengths that
+    are multiples of 32, runs that reach the end, empty and full vectors, run lengths from 1 (every word holds boundaries:
+    the per-wave rings drain while they fill) to 3 000 -- against the numpy model, entry by entry; blocks that are too
+    small are truncated at their capacity, nothing is written behind them."""
+    from ffsubsync_amd import _native
+
+    rng = np.random.RandomState(n_vec)
+    vecs, words, offs, total = [], [], [], 0
+    for v in range(n_vec):
+        n = int(rng.choice([rng.randint(1, 200), rng.randint(200, 40000), 32 * rng.randint(1, 600)]))
+        kind = v % 7
+        if kind == 0:
+            x = np.zeros(n, np.uint8)
+        elif kind == 1:
+            x = np.ones(n, np.uint8)
+        else:
+            run = int(rng.choice([1, 2, 7, 60, 400, 3000]))
+            x = np.repeat((rng.rand(n // run + 2) < rng.choice([0.1, 0.5, 0.9])).astype(np.uint8), run)[:n]
+            if kind == 2:
+                x[-1] = 1  # a run that reaches the end
+        vecs.append(x)
+        w = np.packbits(np.concatenate([x, np.zeros(-n % 32, np.uint8)]), bitorder="little").view(np.int32)
+        offs.append(total)
+        words.append(w)
+        total += (w.size + 15) // 16 * 16
+    host = np.zeros(total, np.int32)
+    for w, o in zip(words, offs):
+        host[o:o + w.size] = w
+    dev = torch.from_numpy(host).cuda()
+    models = [_list_of(x) for x in vecs]
+    caps = np.array([(len(m[0]) + 1) if v % 5 else max(1, len(m[0]) // 2) for v, m in enumerate(models)], dtype=np.int64)
+    block_words = 4 + 2 * caps + 8  # header, entries, eight guard words
+    boffs = np.concatenate([[0], np.cumsum(block_words)[:-1]])
+    blocks = torch.full((int(block_words.sum()),), -7, dtype=torch.int32, device="cuda")
+    _native.runs_from_bits_batch(dev.data_ptr() + 4 * np.array(offs, dtype=np.uint64), [x.size for x in vecs],
+                                 blocks.data_ptr() + 4 * boffs.astype(np.uint64), caps)
+    raw = blocks.cpu().numpy()
+    for v, (x, (pos, ones_before, ones)) in enumerate(zip(vecs, models)):
+        b = raw[boffs[v]: boffs[v] + block_words[v]]
+        cap = int(caps[v])
+        assert b[2] == x.size and b[3] == cap, v
+        assert (b[4 + 2 * cap:] == -7).all(), v  # nothing behind the block
+        if len(pos) < cap:
+            assert b[0] == len(pos) and b[1] == ones, (v, b[:4], len(pos))
+            e = b[4: 4 + 2 * len(pos)].reshape(-1, 2)
+            assert np.array_equal(e[:, 0], pos) and np.array_equal(e[:, 1], ones_before), v
+            assert b[4 + 2 * len(pos)] == np.iinfo(np.int32).max and b[5 + 2 * len(pos)] == ones, v
+        else:  # truncated: the header says so, the entries that fit are the list's first ones
+            assert b[0] >= cap, (v, b[:4], cap)
+            e = b[4: 4 + 2 * cap].reshape(-1, 2)
+            assert np.array_equal(e[:, 0], pos[:cap]) and np.array_equal(e[:, 1], ones_before[:cap]), v
+
+
 def _same_records(a, b):
     ca, pa = a
     cb, pb = b
