@@ -504,6 +504,12 @@ FFS_DEV void block_excl_scan3(int& a, int& b, int& c, int* s_tmp) {
 // the error).  stats[0] += boundaries of the sub-batch's vectors.  (One workgroup per sub-batch took 32 us for 512 x 7
 // candidates -- three dependent global loads per candidate -- on the stream between the extraction and k_runs_corr.)
 constexpr int RUNS_FLAG_SPLIT = 8;
+// (round 6: at least RUNS_FLAG_SPLIT, and one workgroup per 448 candidates of a sub-batch -- a call solved as ONE sub-batch of
+// 8192 pairs kept eight workgroups busy for 60 us)
+static inline unsigned runs_flag_split(long long cands_per_chunk) {
+    const long long want = (cands_per_chunk + 447) / 448;
+    return (unsigned)(want < RUNS_FLAG_SPLIT ? RUNS_FLAG_SPLIT : (want > 128 ? 128 : want));
+}
 __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __restrict__ cands, int n_pairs, int n_cand,
                                                           int pairs_per_chunk, const RunsRef* __restrict__ refs, long long budget,
                                                           int* __restrict__ flags, unsigned long long* __restrict__ stats,
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(256) void k_runs_chunk_flags(const CandDesc* __rest
     int over = 0, bad = 0;
     unsigned long long nb = 0;
     int longest = 0;  // longest list among the vectors that arrived as bits (plan-owned lists: the host sizes their stride by it)
-    for (int i = p0 * n_cand + (int)(blockIdx.y * 256 + threadIdx.x); i < p1 * n_cand; i += 256 * RUNS_FLAG_SPLIT) {
+    for (int i = p0 * n_cand + (int)(blockIdx.y * 256 + threadIdx.x); i < p1 * n_cand; i += 256 * (int)gridDim.y) {
         const CandDesc& cd = cands[i];
         const int pair = i / n_cand, j = i - pair * n_cand;
         const int vr = pair * (n_cand + 1), vs = vr + 1 + j;

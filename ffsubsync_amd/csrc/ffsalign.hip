@@ -1721,7 +1721,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 // flags from the ESTIMATED counts against the budget (the estimate's sampling error is a few per cent of a
                 // count whose square enters: a sub-batch within that of the break-even costs the same either way)
                 HIP_TRY(hipMemsetAsync(p->runs_flags, 0, flag_bytes, st));
-                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, RUNS_FLAG_SPLIT), dim3(256), 0, st, dc, n_pairs, n_cand,
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, runs_flag_split((long long)p->pairs_in_flight * n_cand)), dim3(256), 0, st, dc, n_pairs, n_cand,
                                    p->pairs_in_flight, (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 1);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
@@ -1756,7 +1756,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                                        p->pairs_in_flight, (const RunsRef*)(db + o_rv), (const LevelInfo*)(db + o_li), (int)n_vec, budget,
                                        p->runs_flags, d_stats);
                 else
-                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, RUNS_FLAG_SPLIT), dim3(256), 0, st, dc, n_pairs, n_cand,
+                hipLaunchKernelGGL(k_runs_chunk_flags, dim3((unsigned)n_chunks, runs_flag_split((long long)p->pairs_in_flight * n_cand)), dim3(256), 0, st, dc, n_pairs, n_cand,
                                    p->pairs_in_flight, (const RunsRef*)(db + o_rv), budget, p->runs_flags, d_stats, 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(p->runs_flags_host, p->runs_flags, flag_bytes, hipMemcpyDeviceToHost, st));
