@@ -170,3 +170,67 @@ def _fast_counts(s, r, d_lo, d_hi):
         _, lo_ = rm.ones_before(Q, CQ, int(r.sum()), np.clip(a[k] + d, 0, R))
         n11 += hi_ - lo_
     return n11, np.where(ov > 0, b1 - b0, 0), np.where(ov > 0, r1 - r0, 0), ov
+
+
+def test_one_scan_identity_of_the_round6_kernel():
+    """k_runs_corr (round 6) gets g and n11 at every thread's first lag from ONE block scan: with hs = the sum of the
+    thread's LPT second differences, ws = sum_k (LPT - k) h[k] and the thread index t,
+        g_c = g_0 - A,    n11_c = n11_0 + LPT t g_0 - LPT ((t - 1) A - B) - C,
+    A / B / C the exclusive prefixes of hs / t hs / ws -- against the two running sums it replaces, in the kernel's own
+    wrap-around 32-bit arithmetic."""
+    rng = np.random.RandomState(11)
+    for trial in range(20):
+        lpt, threads = 24, int(rng.choice([1, 7, 512]))
+        h = rng.randint(-40, 41, size=lpt * threads).astype(np.int64)
+        if trial % 4 == 0:
+            h = rng.randint(-32768, 32768, size=lpt * threads).astype(np.int64)  # what 16-bit cells can hold
+        g0, n0 = int(rng.randint(-3000, 3000)), int(rng.randint(0, 700000))
+        # reference: n11(d + 1) = n11(d) + g(d) - h(d), g(d + 1) = g(d) - h(d)
+        g = g0 - np.concatenate([[0], np.cumsum(h)[:-1]])
+        n11 = n0 + np.concatenate([[0], np.cumsum(g - h)[:-1]])
+        hb = h.reshape(threads, lpt)
+        hs = hb.sum(axis=1)
+        ws = (hb * (lpt - np.arange(lpt))).sum(axis=1)
+        t = np.arange(threads)
+        excl = lambda v: np.concatenate([[0], np.cumsum(v)[:-1]])
+        A, B, C = excl(hs), excl(t * hs), excl(ws)
+        wrap = lambda v: ((np.asarray(v, dtype=np.int64) + 2 ** 31) % 2 ** 32) - 2 ** 31
+        g_c = wrap(g0 - A)
+        n11_c = wrap(n0 + lpt * t * g0 - lpt * ((t - 1) * A - B) - C)
+        assert np.array_equal(g_c, wrap(g[::lpt])), trial
+        assert np.array_equal(n11_c, wrap(n11[::lpt])), trial
+
+
+def test_run_per_lane_walk_adds_the_boundary_coincidences():
+    """Round 6 walks one candidate RUN per lane: per reference run read, + at (start, start) and (end, end), - at
+    (end of the reference run, start) and (start of the reference run, end).  Same second-difference histogram as the sum
+    over all boundary pairs (p, q) of db[p] drho[q] at lag q - p (the round-5 walk), lag window and all."""
+    rng = np.random.RandomState(3)
+    for trial in range(30):
+        R, S = int(rng.randint(200, 3000)), int(rng.randint(200, 3000))
+
+        def runs(n):
+            cuts = np.unique(rng.randint(0, n + 1, size=2 * int(rng.randint(1, 40))))
+            cuts = cuts[: cuts.size // 2 * 2]
+            return cuts[0::2], cuts[1::2]  # starts, ends (end = one past the last one; may equal n)
+
+        ps, pe = runs(S)
+        qs, qe = runs(R)
+        d_lo, d_hi = int(rng.randint(-S, 0)), int(rng.randint(0, R))
+        width = d_hi - d_lo  # h is needed for the lags d_lo .. d_hi - 1
+        by_boundaries = np.zeros(width, dtype=np.int64)
+        P = np.concatenate([ps, pe]); sp = np.concatenate([np.ones(ps.size), -np.ones(pe.size)])
+        Q = np.concatenate([qs, qe]); sq = np.concatenate([np.ones(qs.size), -np.ones(qe.size)])
+        for p, a in zip(P, sp):
+            for q, b in zip(Q, sq):
+                d = q - p - d_lo
+                if 0 <= d < width:
+                    by_boundaries[d] += int(a * b)
+        by_runs = np.zeros(width, dtype=np.int64)
+        for s_, e_ in zip(ps, pe):           # a lane
+            for a_, b_ in zip(qs, qe):       # the reference runs it reads
+                for lag, sign in ((a_ - s_, 1), (b_ - s_, -1), (a_ - e_, -1), (b_ - e_, 1)):
+                    d = lag - d_lo
+                    if 0 <= d < width:
+                        by_runs[d] += sign
+        assert np.array_equal(by_runs, by_boundaries), trial
