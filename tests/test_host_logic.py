@@ -422,3 +422,35 @@ def test_trackset_tables_and_arena_reuse():
     assert bigger.start_us.size == 2 * again.start_us.size and bigger._base is not again._base
     assert TrackSet([(np.zeros(0, np.int64), np.zeros(0, np.int64), None)]).meta is None
     assert TrackSet([]).start_us.size == 0
+
+
+def test_golden_comparison_rule():
+    """workloads/golden_check.py, the one rule behind `pairs_matching_reference_golden` and the golden GPU tests: winner
+    bit-identical, scores within 1e-5, a candidate's offset bit-identical where the reference's top-2 gap exceeds 0.5 and
+    inside the reference's own plateau of near-maximal lags otherwise."""
+    import numpy as np
+
+    from workloads import golden_check as gc
+
+    g = {"seed": 3, "index": 1, "offset": 40, "score": "1000.0000000001",
+         "per_candidate": [["900.0", -7], ["1000.0000000001", 40]],
+         "per_candidate_top2_gap": [0.0, 12.0], "per_candidate_plateau": [[5, -9, -3], [1, 40, 40]]}
+    pd = np.dtype([("best_cand", "i4"), ("offset", "i8"), ("score", "f8")])
+    cd = np.dtype([("offset", "i8"), ("score", "f8")])
+
+    def recs(winner, cands):
+        return np.array(winner, dtype=pd), np.array(cands, dtype=cd)
+
+    p, c = recs((1, 40, 1000.0), [(-3, 900.0), (40, 1000.0)])  # the tie resolved to another lag of the plateau: fine
+    assert gc.pair_mismatches(g, p, c) == []
+    p, c = recs((1, 40, 1000.0), [(-2, 900.0), (40, 1000.0)])  # outside the plateau
+    assert [m[0] for m in gc.pair_mismatches(g, p, c)] == ["offset outside the reference's plateau"]
+    p, c = recs((1, 41, 1000.0), [(-7, 900.0), (41, 1000.0)])  # a clear maximum at another lag
+    assert sorted(m[0] for m in gc.pair_mismatches(g, p, c)) == ["offset", "winner"]
+    p, c = recs((1, 40, 1000.02), [(-7, 900.0), (40, 1000.02)])  # 2e-5 relative
+    assert sorted(m[0] for m in gc.pair_mismatches(g, p, c)) == ["score", "winner"]
+    assert gc.count_ties(g) == 1
+    ok, total, first = gc.matching({3: g}, [2, 3], [None, p], [None, c])
+    assert (ok, total) == (0, 1) and len(first) == 1
+    wl = gc.load("windowless_golden")
+    assert len(wl) >= 64 and all("per_candidate_plateau" in v for v in wl.values())
