@@ -16,7 +16,7 @@
 // k of np.argmax, aligners.py:45-48).  Work ~ |P| * |Q| * W / R boundary coincidences per candidate (W lags): 5e4 for
 // subtitle-like vectors under the production window of +-60 s, against ~2e8 flops of the transform path.
 //
-// Round 5: a vector reaches the kernels as a BOUNDARY LIST (RunsRef): either extracted here from its bit-packed samples
+// A vector reaches the kernels as a BOUNDARY LIST (RunsRef, round 5): either extracted here from its bit-packed samples
 // (k_runs_extract) or handed over by its producer -- the subtitle rasteriser knows its intervals (k_rasterize_runs: no
 // bitmap is ever written or read), a bit-packed label vector is converted once (ffs_runs_from_bits) and reused by
 // every later solve.  Dense vectors (a list of RUNS_CAP or more entries, or a coincidence count above the budget) go
@@ -38,7 +38,7 @@ constexpr int RUNS_CAP = 32768;                   // boundary-list entries per v
 #ifndef FFS_RUNS_TPW
 #define FFS_RUNS_TPW 2
 #endif
-constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate boundaries each) a wave advances together
+constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate RUNS each, one per lane) a wave advances together
 constexpr int RUNS_QSENT = 0x1fffffff;            // staged sentinel: beyond every position (a plan's vectors are shorter than 2^24); DOUBLED in
                                                   // LDS, and sentinel - position must not overflow 32 bits for any position > -2^26
 static_assert(RUNS_LPT <= 32 && RUNS_LPT % 8 == 0 && RUNS_QCAP % 2 == 0, "one 32-bit mask per thread, 16-byte histogram loads");
@@ -114,14 +114,14 @@ FFS_HD bool runs_over_budget(long long n_p, long long n_q, long long cap_p, long
 
 // ---------------------------------------------------------------------------------------------------------------
 // Boundary lists from bit-packed samples.  One workgroup per vector; per sweep every thread takes two 16-byte groups,
-// group g of thread t = words base + (256 g + t) * 4 .. + 3 -- a wave's load instruction reads 1 KB of consecutive bytes
-// -- and the loads of the NEXT sweep are issued before the current one is scanned (a sweep is load latency + scan +
-// writes; eight resident blocks per CU in different phases keep the HBM reads going).  Boundary bits e = x ^ (x << 1 |
+// group g of thread t = words base + (NT g + t) * 4 .. + 3 -- a wave's load instruction reads 1 KB of consecutive bytes
+// -- and the loads of the NEXT sweep are issued before the current one is scanned.  Boundary bits e = x ^ (x << 1 |
 // previous bit) (the previous word comes from the neighbouring lane), one block scan per sweep of the per-group
-// (boundaries, ones) counts packed 2 x 16 bits (a field sums to at most 256 * 128; DPP row shifts + row broadcasts inside
-// a wave, the four wave totals through LDS), then every thread writes its own boundaries, ONE 8-byte store each:
-// e[k] = (position, ones of the vector in front of it).  The sweep loop stops as soon as the list is full (a vector that
-// dense goes through the transforms anyway -- its remaining words are never read).
+// (boundaries, ones) counts (256 threads: packed 2 x 16 bits, a field sums to at most 256 * 128; DPP row shifts + row
+// broadcasts inside a wave, the wave totals through LDS); what happens to the boundary words then is described at
+// runs_extract_body (round 6: compacted into per-wave rings, one list entry per lane).  e[k] = (position, ones of the
+// vector in front of it).  The sweep loop stops as soon as the list is full (a vector that dense goes through the
+// transforms anyway -- its remaining words are never read).
 FFS_DEV unsigned wave_incl_scan_u32(unsigned v) {  // inclusive prefix sum over the 64 lanes
 #define FFS_DPP_ADD(ctrl, rows) v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, false)
     FFS_DPP_ADD(0x111, 0xf);  // row_shr:1
