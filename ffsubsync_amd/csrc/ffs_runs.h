@@ -910,7 +910,14 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     __shared__ int s_d[RUNS_WAVES];
     __shared__ float s_m[RUNS_WAVES];
     const int tile = blockIdx.y, tid0 = threadIdx.x;
-    const int pair = (int)blockIdx.x / split, j_first = (int)blockIdx.x - pair * split;
+    // workgroup b runs on XCD b % 8 (one L2 each): every XCD takes a contiguous stretch of the (pair, candidate) indices, so
+    // the workgroups of one pair -- which all stage the same reference list -- follow each other on ONE XCD
+    int bx;
+    {
+        const int nb = (int)gridDim.x, x = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3, base = nb >> 3, rem = nb & 7;
+        bx = x * base + (x < rem ? x : rem) + i;  // (-1.3 % at 8192 pairs: the six other stagings of a list hit the L2)
+    }
+    const int pair = bx / split, j_first = bx - pair * split;
     if (chunk_flags[pair / pairs_per_chunk]) return;  // this sub-batch goes through the transforms (k_runs_chunk_flags)
     const int vr = pair * (n_cand + 1);
     const int vr0 = ML ? n_vec_all + 3 * pair : vr;  // (first) list of the reference
