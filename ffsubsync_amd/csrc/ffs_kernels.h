@@ -2637,6 +2637,7 @@ struct TokView {
 // validity flags read and labels written COALESCED through LDS (round 5: every thread walked its own 40 consecutive frames
 // in global memory), segments of an odd number of frames (LDS bank spread), the segment carries combined by wave scans
 // instead of 256-step loops: 76 -> ~15 us per 90-minute file.
+// (FFS_TOK_STOP=k, never defined in the product build: section stop points for profiles/tok_sections.sh -- WRONG results.)
 constexpr int TOK_THREADS = 1024;
 template <class Op>
 FFS_DEV int tok_block_excl_scan(int v, int identity, Op op, int* s_w, bool backward) {
@@ -2685,6 +2686,9 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
     const int ms = max_sil > 0 ? max_sil : 0;
     for (int i = tid; i < n; i += TOK_THREADS) s_code[i] = v[i] != 0.0f ? 1 : 0;
     __syncthreads();
+#if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 1
+    if (n >= 0) return;
+#endif
     auto imax = [](int x, int y) { return x > y ? x : y; };
     // scan 1: last valid index
     int cur = -1;
@@ -2695,6 +2699,9 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
     int pre = tok_block_excl_scan(cur, -1, imax, s_w, false);
     for (int i = a; i < b && s_lastv[i] < 0; ++i) s_lastv[i] = (short)pre;
     __syncthreads();
+#if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 2
+    if (n >= 0) return;
+#endif
     auto in_island = [&](int i) { const int lv = s_lastv[i]; return lv >= 0 && i - lv <= ms; };
     // scan 2: island start (-2 = inside an island that started in an earlier segment)
     cur = -2;
@@ -2705,6 +2712,9 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
     }
     pre = tok_block_excl_scan(cur, -2, imax, s_w, false);  // starts are increasing: the latest one
     for (int i = a; i < b && s_isl[i] == -2; ++i) s_isl[i] = (short)pre;
+#if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 3
+    if (n >= 0) return;
+#endif
     // scan 3 (backward): first frame behind i that is outside every island
     cur = -1;  // unknown within this segment
     for (int i = b - 1; i >= a; --i) {
@@ -2716,6 +2726,9 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
     if (pre < 0) pre = n;
     for (int i = b - 1; i >= a && s_nxt[i] < 0; --i) s_nxt[i] = (short)pre;
     __syncthreads();
+#if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 4
+    if (n >= 0) return;
+#endif
     // marker codes (over the validity flags, which nothing reads any more) and their fp64 prefix sum
     const TokDiv dv(max_len);
     TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil, dv};
@@ -2733,6 +2746,9 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
         s_code[i] = c;
         acc += c > 0 ? 1.0 : (c < 0 ? (double)m_end : 0.0);
     }
+#if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 5
+    if (n >= 0) return;
+#endif
     // block-wide exclusive prefix of the segment sums (fp64; every term is a float, the sums are exact in any order)
     double incl = acc;
 #pragma unroll
