@@ -2574,9 +2574,9 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
     }
 }
 
-// The same smoothing as a parallel kernel: one workgroup per chunk, every step a scan.  What makes that possible: the
-// state of the tokenizer (SILENCE / NOISE / POSSIBLE_SILENCE and its silence counter) depends on the validity runs
-// alone, never on token lengths -- truncation at max_len only cuts the frames of an "island" into pieces:
+// The same smoothing as a parallel kernel: one workgroup per chunk.  What makes that possible: the state of the
+// tokenizer (SILENCE / NOISE / POSSIBLE_SILENCE and its silence counter) depends on the validity runs alone, never on
+// token lengths -- truncation at max_len only cuts the frames of an "island" into pieces:
 //   * an island starts at a valid frame that follows more than max_sil invalid ones (or none valid at all) and runs
 //     until max_sil frames past its last valid frame (to the end of the chunk if no longer gap follows);
 //   * inside an island a token is cut every max_len frames; full pieces are always delivered (max_len >= min_len, the
@@ -2585,188 +2585,279 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
 //     island ended with a cut followed by at most max_sil frames, which leaves the tokenizer's flag set);
 //   * markers: +1 at the first frame of a delivered piece, non_speech - 1 behind its last (the +1 wins where both
 //     fall on one frame, as the reference's in-order assignments do), then clip(cumsum, 0, 1).
-// Scans: last valid index (forward max), island start (forward), first frame outside any island (backward min),
-// marker prefix sum (fp64).  oracle/vad_oracle.py::tokenize_chunk_scan is the numpy model of exactly this, tested
-// against the state machine on the CPU.  Chunks of up to TOK_SCAN_MAX frames (16-bit indices in LDS).
-constexpr int TOK_SCAN_MAX = 20480;
-// x / m and x % m for 0 <= x < 2^20 and a divisor that is the same for the whole kernel (max_len): the GPU has no integer
-// divider -- a `%` costs ~35 instructions, and the marker pass needs two per frame.  One multiplication by the float
-// reciprocal is off by at most one; two selects correct it.
-struct TokDiv {
-    int m;
-    float inv;
-    FFS_DEV explicit TokDiv(int m_) : m(m_), inv(1.0f / (float)m_) {}
-    FFS_DEV int div(int x) const {
-        int q = (int)((float)x * inv);
-        const int r = x - q * m;
-        q -= r < 0 ? 1 : 0;
-        q += r >= m ? 1 : 0;
-        return q;
+// Round 6 (second form): no per-frame index arrays.  Rounds 4-6 kept three of them (last valid frame, island start,
+// island end) and filled them with per-thread serial passes over ~11 frames each plus block scans: 54 workgroups on
+// 256 CUs, four waves per SIMD, every pass a chain of dependent LDS round trips -- 22.7 us per 90-minute file, bound by
+// the latency of ONE wave's instruction stream (profiles/r06_runs_experiments.json).  Now:
+//   P0  validity as 64-bit words V (one ballot per 64 coalesced frames);
+//   P1  PL[w] = last valid frame in the words in front of w (one value per WORD: a DPP wave scan + seven wave totals),
+//       which makes "last valid frame <= i" one or two LDS reads: the word's own bits, else PL;
+//   P2  island starts as a second bit array S: frame i starts an island iff it is valid and its predecessor is outside
+//       every island -- the word's bits below the lane, else PL: registers only, one ballot per word;
+//   P3  SL[w] / NS[w] = last start in front of / first start behind word w (two scans, one pair of barriers);
+//   P4  one thread per HALF WORD of S walks its island starts (typically none or one) and sets the marker BITS of the
+//       island's pieces in two more bit arrays (P: +1, M: non_speech - 1; a frame in both carries the +1); the island's
+//       end is min(n, last valid frame in front of the next start + max_sil + 1);
+//   P5  clip(cumsum) per frame without a sum over frames: label(i) = clamp(#P(<= i) + #M(<= i) (non_speech - 1), 0, 1),
+//       the counts from a packed prefix count per word + a popcount (fp64; equal to the sequential sum whenever that one
+//       is exact -- every term is a float -- which is what rounds 4-6's blocked prefix sum relied on as well).
+// Frames map to lanes the same way in P0, P2 and P5: wave v owns the words v, v + 16, ...; lane k of the wave holds the
+// wave's k-th word of every bit array in a register (v_readlane hands it to the whole wave: no LDS round trip per word),
+// lane l of the wave is frame 64 w + l of the word being processed -- loads and stores are coalesced.
+// oracle/vad_oracle.py::tokenize_chunk_words is the model of exactly this, tested against the state machine on the
+// CPU.  LDS: 48 bytes per 64-frame word, nothing per frame.
+// (FFS_TOK_STOP=k, never defined in the product build: section stop points for profiles/tok_sections.sh -- WRONG results.)
+constexpr int TOK_SCAN_MAX = 28672;
+constexpr int TOK_THREADS = 1024;
+constexpr int TOK_WORDS = TOK_SCAN_MAX / 64;
+constexpr int TOK_WPW = TOK_WORDS / (TOK_THREADS / 64);  // words per wave
+constexpr int TOK_WORD_WAVES = TOK_SCAN_MAX / 64 / 64;  // waves whose threads own a word in the word scans
+static_assert(TOK_SCAN_MAX % 1024 == 0 && TOK_SCAN_MAX / 32 <= TOK_THREADS && TOK_WPW <= 64 && TOK_SCAN_MAX < 65536, "one thread per half word, one lane per word of a wave, 16-bit counts");
+
+// inclusive scan over the 64 lanes, DPP only; op(earlier, later), identity = left identity of op
+template <class Op>
+FFS_DEV int tok_wave_incl_scan(int v, int identity, Op op) {
+#define FFS_TOK_STEP(ctrl, rows) v = op(__builtin_amdgcn_update_dpp(identity, v, ctrl, rows, 0xf, false), v)
+    FFS_TOK_STEP(0x111, 0xf);  // row_shr:1 (a lane without a source receives the identity)
+    FFS_TOK_STEP(0x112, 0xf);
+    FFS_TOK_STEP(0x114, 0xf);
+    FFS_TOK_STEP(0x118, 0xf);
+    FFS_TOK_STEP(0x142, 0xa);  // row_bcast:15
+    FFS_TOK_STEP(0x143, 0xc);  // row_bcast:31
+#undef FFS_TOK_STEP
+    return v;
+}
+// block-wide INCLUSIVE scan of one value per thread of the first TOK_WORD_WAVES waves (the word owners); s_w: one int per
+// wave; the caller has a barrier between two uses of the same s_w
+template <class Op>
+FFS_DEV int tok_words_incl_scan(int v, int identity, Op op, int* s_w, int lane, int wave) {
+    const int incl = tok_wave_incl_scan(v, identity, op);
+    if (lane == 63 && wave < TOK_WORD_WAVES) s_w[wave] = incl;
+    __syncthreads();
+    int sw[TOK_WORD_WAVES];
+#pragma unroll
+    for (int w = 0; w < TOK_WORD_WAVES; ++w) sw[w] = s_w[w];
+    int pre = identity;
+#pragma unroll
+    for (int w = 0; w < TOK_WORD_WAVES; ++w) pre = w < wave ? op(pre, sw[w]) : pre;
+    return op(pre, incl);
+}
+
+struct TokWords {
+    const unsigned long long* V;  // validity, bit i & 63 of word i >> 6
+    const unsigned long long* S;  // island starts
+    const int* PL;                // last valid frame in the words in front of w (-1: none)
+    const int* SL;                // last island start in the words in front of w
+    const int* NS;                // first island start in the words behind w (-1: none)
+    int n, min_len, max_len, max_sil, ms;
+    FFS_DEV static int last_le(const unsigned long long* B, const int* front, int i) {
+        if (i < 0) return -1;
+        const int w = i >> 6;
+        const unsigned long long m = B[w] & (~0ull >> (63 - (i & 63)));
+        return m ? (w << 6) + 63 - __clzll((long long)m) : front[w];
     }
-    FFS_DEV int mod(int x) const { return x - div(x) * m; }
-};
-struct TokView {
-    const short* lastv;  // last valid index <= i, -1 if none
-    const short* isl;    // start of the island frame i belongs to, -1 if outside
-    const short* nxt;    // first index > i outside every island (n if none)
-    int n, min_len, max_len, max_sil;
-    TokDiv dv;
+    FFS_DEV int lastv(int i) const { return last_le(V, PL, i); }
+    FFS_DEV int island_end(int i) const {  // i inside an island: its last frame
+        const int w = i >> 6, b = i & 63;
+        const unsigned long long m = b == 63 ? 0ull : S[w] & (~0ull << (b + 1));
+        const int ns = m ? (w << 6) + __ffsll((long long)m) - 1 : NS[w];
+        const int lv = lastv((ns >= 0 ? ns : n) - 1);
+        return (lv + ms + 1 < n ? lv + ms + 1 : n) - 1;
+    }
     FFS_DEV bool c_in(int s) const {
         if (max_sil <= 0 || s == 0) return false;
-        const int lp = lastv[s - 1];
+        const int lp = lastv(s - 1);
         if (lp < 0) return false;
-        const int lenp = lp + max_sil - isl[lp] + 1;
-        const int qd = dv.div(lenp);
+        const int lenp = lp + max_sil - last_le(S, SL, lp) + 1;
+        const int qd = lenp / max_len;
         return qd >= 1 && lenp - qd * max_len <= max_sil;
     }
-    FFS_DEV bool delivered(int i0) const {  // the piece that starts at frame i0
-        const int s = isl[i0], e_isl = nxt[i0] - 1;
-        const int j = dv.div(i0 - s);
-        const int e = (i0 + max_len - 1) < e_isl ? (i0 + max_len - 1) : e_isl;
-        const int r = e - i0 + 1;
-        if (r == max_len) return true;
-        const bool c = j >= 1 ? true : c_in(s);
-        const bool ok_len = r >= min_len || (r > 0 && c);
-        if (e_isl + 1 < n) return max_sil <= 0 ? ok_len : (max_sil < r && ok_len);  // ended by a long gap
-        const int t = e_isl - lastv[e_isl];  // trailing silence at the end of the chunk
-        return r > 0 && r > t && ok_len;
+    // the markers of the island that starts at frame s
+    FFS_DEV void island(int s, unsigned long long* P, unsigned long long* M) const {
+        const int e_isl = island_end(s);
+        const int t_end = e_isl + 1 < n ? 0 : e_isl - lastv(e_isl);  // trailing silence of an island cut by the chunk's end
+        int cin = -1;                                                // c_in(s), when a first piece needs it
+        int j = 0;
+        for (int i0 = s; i0 <= e_isl; i0 += max_len, ++j) {
+            const int e = (i0 + max_len - 1) < e_isl ? (i0 + max_len - 1) : e_isl;
+            const int r = e - i0 + 1;
+            bool d = true;
+            if (r != max_len) {
+                bool ok_len = r >= min_len;
+                if (!ok_len && r > 0) {
+                    if (j >= 1) {
+                        ok_len = true;
+                    } else {
+                        if (cin < 0) cin = c_in(s) ? 1 : 0;
+                        ok_len = cin != 0;
+                    }
+                }
+                if (e_isl + 1 < n)
+                    d = max_sil <= 0 ? ok_len : (max_sil < r && ok_len);  // ended by a long gap
+                else
+                    d = r > 0 && r > t_end && ok_len;
+            }
+            if (d) {
+                if (e + 1 < n) atomicOr(&M[(e + 1) >> 6], 1ull << ((e + 1) & 63));
+                atomicOr(&P[i0 >> 6], 1ull << (i0 & 63));  // (a frame in both arrays carries the +1)
+            }
+        }
     }
 };
-
-// Round 6: 1024 threads per chunk (a 90-minute file has only 54 chunks of 100 s: what counts is a chunk's latency),
-// validity flags read and labels written COALESCED through LDS (round 5: every thread walked its own 40 consecutive frames
-// in global memory), segments of an odd number of frames (LDS bank spread), the segment carries combined by wave scans
-// instead of 256-step loops: 76 -> ~15 us per 90-minute file.
-// (FFS_TOK_STOP=k, never defined in the product build: section stop points for profiles/tok_sections.sh -- WRONG results.)
-constexpr int TOK_THREADS = 1024;
-template <class Op>
-FFS_DEV int tok_block_excl_scan(int v, int identity, Op op, int* s_w, bool backward) {
-    // exclusive scan of one int per thread over the block (forward: threads before this one, op(earlier, later); backward:
-    // threads behind this one, op(nearer, farther))
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = backward ? __shfl_down(incl, d, 64) : __shfl_up(incl, d, 64);
-        if (backward ? (lane + d < 64) : (lane >= d)) incl = backward ? op(incl, o) : op(o, incl);  // op(nearer to the start, farther)
-    }
-    int excl = backward ? __shfl_down(incl, 1, 64) : __shfl_up(incl, 1, 64);
-    if (backward ? lane == 63 : lane == 0) excl = identity;
-    __syncthreads();  // (s_w may still be read by the previous scan)
-    if (backward ? lane == 0 : lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    int pre = identity;
-    if (backward) {
-        for (int w = TOK_THREADS / 64 - 1; w > wave; --w) pre = op(s_w[w], pre);
-    } else {
-        for (int w = 0; w < wave; ++w) pre = op(pre, s_w[w]);
-    }
-    return backward ? op(excl, pre) : op(pre, excl);
-}
 
 __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* __restrict__ valid, long long n_frames, long long chunk,
                                                                   int min_len, int max_len, int max_sil, float non_speech,
-                                                                  float* __restrict__ out, int lds_frames) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    short* s_lastv = reinterpret_cast<short*>(smem);
-    short* s_isl = s_lastv + lds_frames;
-    short* s_nxt = s_isl + lds_frames;
-    signed char* s_code = reinterpret_cast<signed char*>(s_nxt + lds_frames);  // validity flags, later marker codes (+1 / -1 / 0)
-    float* s_lab = reinterpret_cast<float*>(smem);                              // the labels, over lastv + isl once those are dead
-    __shared__ int s_w[TOK_THREADS / 64];
-    __shared__ double s_ws[TOK_THREADS / 64];
+                                                                  float* __restrict__ out) {
+    __shared__ unsigned long long s_V[TOK_WORDS], s_S[TOK_WORDS], s_P[TOK_WORDS], s_M[TOK_WORDS];
+    __shared__ int s_PL[TOK_WORDS], s_SL[TOK_WORDS], s_NS[TOK_WORDS], s_PP[TOK_WORDS];
+    __shared__ int s_w[3][TOK_WORD_WAVES];
     const long long f0 = (long long)blockIdx.x * chunk;
     if (f0 >= n_frames) return;
     const int n = (int)((f0 + chunk) < n_frames ? chunk : (n_frames - f0));
     const float* v = valid + f0;
     float* o = out + f0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seg = ((n + TOK_THREADS - 1) / TOK_THREADS) | 1;  // odd: consecutive threads start in different banks
-    const int a = tid * seg < n ? tid * seg : n, b = (a + seg) < n ? (a + seg) : n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int W = (n + 63) >> 6;
     const int ms = max_sil > 0 ? max_sil : 0;
-    for (int i = tid; i < n; i += TOK_THREADS) s_code[i] = v[i] != 0.0f ? 1 : 0;
+    constexpr int NWV = TOK_THREADS / 64;
+    const int my_w = wave + NWV * lane;  // the word this lane keeps in registers (lanes < TOK_WPW)
+    const bool own = lane < TOK_WPW && my_w < W;
+    auto lane64 = [](unsigned long long x, int k) -> unsigned long long {  // (k uniform)
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, k), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), k);
+        return ((unsigned long long)hi << 32) | lo;
+    };
+    // P0: validity words -- every load of the wave requested before the first ballot waits for one
+    unsigned long long v_reg = 0ull;
+    {
+        float x[TOK_WPW];
+#pragma unroll
+        for (int k = 0; k < TOK_WPW; ++k) {
+            x[k] = 0.0f;
+            if (wave + NWV * k < W) {
+                const int i = ((wave + NWV * k) << 6) + lane;
+                if (i < n) x[k] = v[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TOK_WPW; ++k) {
+            if (wave + NWV * k < W) {
+                const unsigned long long m = __ballot(x[k] != 0.0f);
+                if (lane == k) v_reg = m;
+            }
+        }
+    }
+    if (own) s_V[my_w] = v_reg;
+    if (tid < W) s_P[tid] = 0ull, s_M[tid] = 0ull;
     __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 1
     if (n >= 0) return;
 #endif
     auto imax = [](int x, int y) { return x > y ? x : y; };
-    // scan 1: last valid index
-    int cur = -1;
-    for (int i = a; i < b; ++i) {
-        if (s_code[i]) cur = i;
-        s_lastv[i] = (short)cur;
+    auto later_known = [](int earlier, int later) { return later >= 0 ? later : earlier; };
+    // P1: last valid frame in front of every word
+    {
+        int a = -1;
+        if (tid < W) {
+            const unsigned long long m = s_V[tid];
+            a = m ? (tid << 6) + 63 - __clzll((long long)m) : -1;
+        }
+        const int incl = tok_words_incl_scan(a, -1, imax, s_w[0], lane, wave);
+        if (tid == 0) s_PL[0] = -1;
+        if (tid + 1 < W) s_PL[tid + 1] = incl;
     }
-    int pre = tok_block_excl_scan(cur, -1, imax, s_w, false);
-    for (int i = a; i < b && s_lastv[i] < 0; ++i) s_lastv[i] = (short)pre;
     __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 2
     if (n >= 0) return;
 #endif
-    auto in_island = [&](int i) { const int lv = s_lastv[i]; return lv >= 0 && i - lv <= ms; };
-    // scan 2: island start (-2 = inside an island that started in an earlier segment)
-    cur = -2;
-    for (int i = a; i < b; ++i) {
-        const bool in = in_island(i);
-        if (in && s_lastv[i] == i && !(i > 0 && in_island(i - 1))) cur = i;
-        s_isl[i] = (short)(in ? cur : -1);
+    // P2: island starts
+    {
+        const int pl_reg = own ? s_PL[my_w] : -1;
+        unsigned long long s_reg = 0ull;
+        for (int k = 0; wave + NWV * k < W; ++k) {
+            const int base = (wave + NWV * k) << 6, i = base + lane;
+            const unsigned long long vw = lane64(v_reg, k);
+            const int pl = __builtin_amdgcn_readlane(pl_reg, k);
+            const unsigned long long below = vw & ((1ull << lane) - 1ull);  // valid frames of this word in front of frame i
+            const int lv = below ? base + 63 - __clzll((long long)below) : pl;
+            const bool start = ((vw >> lane) & 1ull) && (lv < 0 || i - 1 - lv > ms);
+            const unsigned long long m = __ballot(start);
+            if (lane == k) s_reg = m;
+        }
+        if (own) s_S[my_w] = s_reg;
     }
-    pre = tok_block_excl_scan(cur, -2, imax, s_w, false);  // starts are increasing: the latest one
-    for (int i = a; i < b && s_isl[i] == -2; ++i) s_isl[i] = (short)pre;
+    __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 3
     if (n >= 0) return;
 #endif
-    // scan 3 (backward): first frame behind i that is outside every island
-    cur = -1;  // unknown within this segment
-    for (int i = b - 1; i >= a; --i) {
-        s_nxt[i] = (short)cur;
-        if (!in_island(i)) cur = i;
+    // P3: last start in front of / first start behind every word (the second scan runs over the words in reverse order)
+    {
+        int a = -1, b = -1;
+        if (tid < W) {
+            const unsigned long long m = s_S[tid], mr = s_S[W - 1 - tid];
+            a = m ? (tid << 6) + 63 - __clzll((long long)m) : -1;
+            b = mr ? ((W - 1 - tid) << 6) + __ffsll((long long)mr) - 1 : -1;
+        }
+        const int ia = tok_wave_incl_scan(a, -1, imax), ib = tok_wave_incl_scan(b, -1, later_known);
+        if (lane == 63 && wave < TOK_WORD_WAVES) s_w[1][wave] = ia, s_w[2][wave] = ib;
+        __syncthreads();
+        int pa = -1, pb = -1;
+#pragma unroll
+        for (int w = 0; w < TOK_WORD_WAVES; ++w) {
+            const int ta = s_w[1][w], tb = s_w[2][w];
+            pa = w < wave ? imax(pa, ta) : pa;
+            pb = w < wave ? later_known(pb, tb) : pb;
+        }
+        if (tid == 0) s_SL[0] = -1, s_NS[W - 1] = -1;
+        if (tid + 1 < W) {
+            s_SL[tid + 1] = imax(pa, ia);
+            s_NS[W - 2 - tid] = later_known(pb, ib);  // words behind W - 2 - tid = the words W - 1 - tid .. W - 1
+        }
     }
-    // the nearest later segment that has one: "first known" over the threads behind this one
-    pre = tok_block_excl_scan(cur, -1, [](int nearer, int farther) { return nearer >= 0 ? nearer : farther; }, s_w, true);
-    if (pre < 0) pre = n;
-    for (int i = b - 1; i >= a && s_nxt[i] < 0; --i) s_nxt[i] = (short)pre;
     __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 4
     if (n >= 0) return;
 #endif
-    // marker codes (over the validity flags, which nothing reads any more) and their fp64 prefix sum
-    const TokDiv dv(max_len);
-    TokView tv{s_lastv, s_isl, s_nxt, n, min_len, max_len, max_sil, dv};
-    const float m_end = non_speech - 1.0f;
-    double acc = 0.0;
-    for (int i = a; i < b; ++i) {
-        signed char c = 0;
-        const int s = s_isl[i];
-        if (s >= 0 && dv.mod(i - s) == 0 && tv.delivered(i)) {
-            c = 1;
-        } else if (i >= 1 && s_isl[i - 1] >= 0) {
-            const int off = dv.mod(i - 1 - s_isl[i - 1]);
-            if ((off == max_len - 1 || i == s_nxt[i - 1]) && tv.delivered(i - 1 - off)) c = -1;
+    // P4: marker bits, island by island
+    if (tid < 2 * W) {
+        const TokWords tw{s_V, s_S, s_PL, s_SL, s_NS, n, min_len, max_len, max_sil, ms};
+        const int w = tid >> 1, h = tid & 1;
+        unsigned m = (unsigned)(s_S[w] >> (32 * h));
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            tw.island((w << 6) + 32 * h + b, s_P, s_M);
         }
-        s_code[i] = c;
-        acc += c > 0 ? 1.0 : (c < 0 ? (double)m_end : 0.0);
     }
+    __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 5
     if (n >= 0) return;
 #endif
-    // block-wide exclusive prefix of the segment sums (fp64; every term is a float, the sums are exact in any order)
-    double incl = acc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += t;
-    }
-    if (lane == 63) s_ws[wave] = incl;
-    __syncthreads();  // (also: every thread is done with lastv / isl / nxt -- the labels go over them)
-    double run = incl - acc;
-    for (int w = 0; w < wave; ++w) run += s_ws[w];
-    for (int i = a; i < b; ++i) {
-        const signed char c = s_code[i];
-        run += c > 0 ? 1.0 : (c < 0 ? (double)m_end : 0.0);
-        s_lab[i] = (float)fmin(fmax(run, 0.0), 1.0);
+    // P5: markers in front of every word (packed: +1 markers in the low half, end markers in the high half), labels
+    {
+        int c = 0;
+        if (tid < W) {
+            const unsigned long long pw = s_P[tid], mw = s_M[tid] & ~pw;
+            c = __popcll(pw) | (__popcll(mw) << 16);
+        }
+        const int incl = tok_words_incl_scan(c, 0, [](int x, int y) { return x + y; }, s_w[0], lane, wave);
+        if (tid < W) s_PP[tid] = incl - c;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += TOK_THREADS) o[i] = s_lab[i];
+    {
+        unsigned long long p_reg = 0ull, m_reg = 0ull;
+        int pp_reg = 0;
+        if (own) p_reg = s_P[my_w], m_reg = s_M[my_w] & ~p_reg, pp_reg = s_PP[my_w];
+        const double m_end = (double)(non_speech - 1.0f);
+        const unsigned long long le = ~0ull >> (63 - lane);  // this frame and the frames of its word in front of it
+        for (int k = 0; wave + NWV * k < W; ++k) {
+            const int i = ((wave + NWV * k) << 6) + lane;
+            const unsigned long long pw = lane64(p_reg, k), mw = lane64(m_reg, k);
+            const int pp = __builtin_amdgcn_readlane(pp_reg, k);
+            const int cp = (pp & 0xffff) + __popcll(pw & le), cm = (pp >> 16) + __popcll(mw & le);
+            const double run = (double)cp + (double)cm * m_end;
+            if (i < n) o[i] = (float)fmin(fmax(run, 0.0), 1.0);
+        }
+    }
 }
 
 // ---- subtitle rasteriser arithmetic, shared by the host entry points and the batched kernel --------------------

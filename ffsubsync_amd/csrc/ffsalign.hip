@@ -2793,20 +2793,10 @@ int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_fra
     const long long chunks = (n_frames + chunk_frames - 1) / chunk_frames;
     const long long longest = chunk_frames < n_frames ? chunk_frames : n_frames;
     if (longest <= TOK_SCAN_MAX && max_length >= min_length && min_length >= 0) {
-        // one workgroup per chunk, every step a scan (three 16-bit index arrays of the chunk in LDS)
-        const int lds_frames = (int)((longest + 7) / 8 * 8);
-        const size_t lds = (size_t)lds_frames * (3 * sizeof(short) + 1);  // three 16-bit index arrays + one byte per frame
-        static thread_local size_t lds_set[64] = {};
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && lds_set[dev] < lds) {
-            HIP_TRY(hipFuncSetAttribute((const void*)k_vad_tokenize_scan, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(TOK_SCAN_MAX * (3 * sizeof(short) + 1))));
-            lds_set[dev] = (size_t)TOK_SCAN_MAX * (3 * sizeof(short) + 1);
-        }
-        hipLaunchKernelGGL(k_vad_tokenize_scan, dim3((unsigned)chunks), dim3(TOK_THREADS), lds, (hipStream_t)hip_stream, valid_dev,
+        // one workgroup per chunk (validity, island starts and markers as bit words in LDS: ffs_kernels.h)
+        hipLaunchKernelGGL(k_vad_tokenize_scan, dim3((unsigned)chunks), dim3(TOK_THREADS), 0, (hipStream_t)hip_stream, valid_dev,
                            (long long)n_frames, (long long)chunk_frames, min_length, max_length, max_continuous_silence,
-                           non_speech_label, labels_dev, lds_frames);
+                           non_speech_label, labels_dev);
     } else {
         hipLaunchKernelGGL(k_vad_tokenize, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, (hipStream_t)hip_stream,
                            valid_dev, (long long)n_frames, (long long)chunk_frames, min_length, max_length,

@@ -248,9 +248,10 @@ int ffs_vad_energy_bits(const int16_t* pcm_dev, int64_t n_samples, int frame_len
  * token order), out = clip(cumsum(marker)[:-1], 0, 1).
  * valid_dev[f] != 0  <=>  frame f passed the energy test.  PARITY UNPINNED: auditok is not available
  * to check against; restated from its published source (oracle/vad_oracle.py, tokenize()).
- * Chunks of up to 20480 frames with max_length >= min_length run as one workgroup per chunk in which every
- * step is a scan (k_vad_tokenize_scan; model: oracle/vad_oracle.py::tokenize_chunk_scan); anything else as one
- * thread per chunk walking the state machine.  Identical outputs. */
+ * Chunks of up to 28672 frames with max_length >= min_length >= 0 run as one workgroup per chunk (k_vad_tokenize_scan:
+ * validity and island starts as bit words, markers written island by island; model:
+ * oracle/vad_oracle.py::tokenize_chunk_words); anything else as one thread per chunk walking the state machine.
+ * Identical outputs. */
 int ffs_vad_tokenize(const float* valid_dev, int64_t n_frames, int64_t chunk_frames, int min_length,
                      int max_length, int max_continuous_silence, float non_speech_label,
                      float* labels_dev, void* hip_stream);

@@ -228,6 +228,108 @@ def tokenize_chunk_scan(valid, non_speech_label=0.0, min_length=20, max_length=5
     return np.clip(np.cumsum(m), 0.0, 1.0)                                    # scan 4
 
 
+def tokenize_chunk_words(valid, non_speech_label=0.0, min_length=20, max_length=500, max_continuous_silence=25):
+    """Model of k_vad_tokenize_scan as of round 6 (test infrastructure): the island formulation of
+    tokenize_chunk_scan() above WITHOUT per-frame index arrays.  The validity flags are 64-bit words V; the island
+    starts are a second bit array S (a valid frame whose predecessor is outside every island); three arrays with one
+    entry per WORD (last valid frame / last start in front of the word, first start behind it) turn "last valid frame
+    <= i", "start of the island of i" and "first frame behind the island of i" into one or two word reads.  The
+    markers are then written island by island (one thread per half word of S on the device), piece by piece."""
+    v = np.asarray(valid, bool)
+    n = v.size
+    if n == 0:
+        return np.zeros(0)
+    mn, mx, msil = int(min_length), int(max_length), int(max_continuous_silence)
+    assert mx >= mn
+    ms = max(msil, 0)
+    W = (n + 63) // 64
+    full = (1 << 64) - 1
+
+    def words(bits):
+        out = [0] * W
+        for i in np.nonzero(bits)[0]:
+            out[int(i) >> 6] |= 1 << (int(i) & 63)
+        return out
+
+    def last_in_front(words_):  # entry w: highest set bit in the words < w, -1 if none
+        out, cur = [], -1
+        for w in range(W):
+            out.append(cur)
+            if words_[w]:
+                cur = 64 * w + words_[w].bit_length() - 1
+        return out
+
+    def first_behind(words_):   # entry w: lowest set bit in the words > w, -1 if none
+        out, cur = [0] * W, -1
+        for w in range(W - 1, -1, -1):
+            out[w] = cur
+            if words_[w]:
+                cur = 64 * w + (words_[w] & -words_[w]).bit_length() - 1
+        return out
+
+    V = words(v)
+    PL = last_in_front(V)
+
+    def last_le(words_, front, i):
+        if i < 0:
+            return -1
+        w = i >> 6
+        m = words_[w] & (full >> (63 - (i & 63)))
+        return 64 * w + m.bit_length() - 1 if m else front[w]
+
+    def lastv(i):
+        return last_le(V, PL, i)
+
+    start = np.zeros(n, bool)
+    for i in range(n):
+        if v[i]:
+            lv = lastv(i - 1)
+            start[i] = lv < 0 or (i - 1 - lv) > ms
+    S = words(start)
+    SL, NS = last_in_front(S), first_behind(S)
+
+    def nxt_of(i):  # i inside an island: first frame behind it
+        w, b = i >> 6, i & 63
+        m = S[w] & ((full << (b + 1)) & full)
+        ns = 64 * w + (m & -m).bit_length() - 1 if m else NS[w]
+        lv = lastv((ns if ns >= 0 else n) - 1)
+        return min(n, lv + ms + 1)
+
+    def c_in(s):
+        if msil <= 0 or s == 0:
+            return False
+        lp = lastv(s - 1)
+        if lp < 0:
+            return False
+        lenp = lp + msil - last_le(S, SL, lp) + 1
+        return lenp // mx >= 1 and lenp % mx <= msil
+
+    code = np.zeros(n, np.int8)
+    for s in np.nonzero(start)[0]:
+        s = int(s)
+        e_isl = nxt_of(s) - 1
+        i0, j = s, 0
+        while i0 <= e_isl:
+            e = min(i0 + mx - 1, e_isl)
+            r = e - i0 + 1
+            if r == mx:
+                d = True
+            else:
+                ok_len = r >= mn or (r > 0 and (j >= 1 or c_in(s)))
+                if e_isl + 1 < n:
+                    d = ok_len if msil <= 0 else (msil < r and ok_len)
+                else:
+                    d = r > 0 and r > e_isl - lastv(e_isl) and ok_len
+            if d:
+                if e + 1 < n:
+                    code[e + 1] = -1
+                code[i0] = 1   # (a start wins over the end marker of the piece in front: assigned later)
+            i0 += mx
+            j += 1
+    m = np.where(code > 0, 1.0, np.where(code < 0, non_speech_label - 1.0, 0.0))
+    return np.clip(np.cumsum(m), 0.0, 1.0)
+
+
 def tokenize(valid, non_speech_label=0.0, chunk_frames=10000, sample_rate=100):
     """Chunk loop: the reference builds the tokenizer once but every detector call starts a fresh
     tokenize() pass over its own 100 s buffer."""

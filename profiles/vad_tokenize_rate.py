@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Token smoothing of one 90-minute file (540 000 frames): the scan kernel (100 s chunks, the reference's buffer) against
-the one-thread-per-chunk state machine, which chunks above 20 480 frames still take (here: 27 000-frame chunks -- the
-round-2 environment switch that forced it is gone).
+"""Token smoothing of one 90-minute file (540 000 frames): the workgroup-per-chunk kernel (100 s chunks, the reference's
+buffer) against the one-thread-per-chunk state machine, which chunks above 28 672 frames still take (here: 30 000-frame
+chunks -- the round-2 environment switch that forced it is gone).
 
     python profiles/vad_tokenize_rate.py
 """
@@ -24,7 +24,7 @@ valid = np.repeat(rng.rand(runs.size) < 0.5, runs)[:n].astype(np.float32)
 dev = torch.from_numpy(valid).cuda()
 out = {}
 ref = None
-for label, chunk in (("scan_100s_chunks", 10000), ("serial_270s_chunks", 27000)):
+for label, chunk in (("scan_100s_chunks", 10000), ("serial_300s_chunks", 30000)):
     res = {}
     for what, frames in (("one_chunk", chunk), ("whole_file", n)):
         x = dev[:frames]

@@ -463,23 +463,25 @@ def test_pass_a_prefetch_blocks_change_nothing_but_time(torch, monkeypatch):
 
 
 def test_scan_tokenizer_equals_serial_kernel_and_restatement(torch, monkeypatch):
-    """ffs_vad_tokenize runs one workgroup per chunk with every step a scan (k_vad_tokenize_scan) for chunks of up to
-    20480 frames and max_length >= min_length, the one-thread-per-chunk state machine (k_vad_tokenize) otherwise (the
-    25000-frame chunks below, and the max_length < min_length case).  Both against the Python restatement: reference parameters and degenerate
-    ones, several labels, chunk lengths around the segment size of the scans, chunks too long for the scan kernel."""
+    """ffs_vad_tokenize runs one workgroup per chunk (k_vad_tokenize_scan: bit words and islands) for chunks of up to
+    28672 frames and max_length >= min_length, the one-thread-per-chunk state machine (k_vad_tokenize) otherwise (the
+    30011-frame chunks below, and the max_length < min_length case).  Both against the Python restatement: reference
+    parameters and degenerate ones (no tolerated silence, one-frame tokens, silence longer than a token), several
+    labels, chunk lengths around the 64-frame word and the segment size of the prefix sum, chunks too long for the
+    workgroup kernel."""
     from ffsubsync_amd import _native
 
     rng = np.random.RandomState(21)
-    cases = [(20, 500, 25), (3, 10, 2), (5, 5, 1), (1, 7, 0), (4, 40, 30), (2, 9, 9)]
-    for trial in range(10):
-        n = int(rng.choice([1, 255, 256, 257, 3000, 10000, 20480, 30011]))
+    cases = [(20, 500, 25), (3, 10, 2), (5, 5, 1), (1, 7, 0), (4, 40, 30), (2, 9, 9), (1, 1, 0), (0, 3, -1), (2, 70, 100), (9, 4, 2)]
+    for trial in range(int(os.environ.get("FFS_TOK_TRIALS", "20"))):
+        n = int(rng.choice([1, 63, 64, 65, 255, 256, 257, 3000, 10000, 20480, 28672, 30011]))
         p_on = rng.choice([0.02, 0.2, 0.6, 0.95])
         runs = rng.geometric(1.0 / rng.choice([1, 3, 15, 80, 700]), size=n + 4)
         valid = np.repeat(rng.rand(runs.size) < p_on, runs)[:n]
         dev = torch.from_numpy(valid.astype(np.float32)).cuda()
         mn, mx, msil = cases[trial % len(cases)]
         for label in (0.0, 0.25, -1.0):
-            for chunk in (10000, 997, 20480, 25000):
+            for chunk in (10000, 997, 20480, 25000, 28672, 30011):
                 tok = lambda c: vo._Tokenizer(mn, mx, msil).tokenize(c)
                 want = []
                 for o in range(0, n, chunk):

@@ -72,3 +72,26 @@ def test_scan_formulation_of_the_tokenizer_equals_the_state_machine():
         want = np.clip(np.cumsum(marks)[:-1], 0.0, 1.0)
         got = vo.tokenize_chunk_scan(valid, label, mn, mx, msil)
         assert np.array_equal(got, want), (trial, n, (mn, mx, msil), label)
+
+
+def test_word_formulation_of_the_tokenizer_equals_the_state_machine():
+    """oracle/vad_oracle.py::tokenize_chunk_words (the model of the round-6 kernel: validity and island starts as bit
+    words, markers written island by island) against the restated state machine, same cases as above plus lengths
+    around the 64-frame word."""
+    rng = np.random.RandomState(12)
+    for trial in range(240):
+        n = int(rng.choice([1, 2, 7, 63, 64, 65, 128, 500, 1500]))
+        p_on = rng.choice([0.02, 0.2, 0.5, 0.8, 0.95])
+        runs = rng.geometric(1.0 / rng.choice([1, 3, 15, 80, 700]), size=n + 4)
+        valid = np.repeat(rng.rand(runs.size) < p_on, runs)[:n]
+        mn, mx, msil = [(20, 500, 25), (20, 500, 25), (3, 10, 2), (5, 5, 1), (1, 7, 0), (4, 40, 30), (2, 9, 9), (3, 12, 11),
+                        (1, 1, 0), (0, 3, -1), (2, 70, 100)][rng.randint(11)]
+        label = float(rng.choice([0.0, 0.25, -1.0]))
+        tok = vo._Tokenizer(mn, mx, msil)
+        marks = np.zeros(n + 1)
+        for s, e in tok.tokenize(valid):
+            marks[s] = 1.0
+            marks[e + 1] = label - 1.0
+        want = np.clip(np.cumsum(marks)[:-1], 0.0, 1.0)
+        got = vo.tokenize_chunk_words(valid, label, mn, mx, msil)
+        assert np.array_equal(got, want), (trial, n, (mn, mx, msil), label)
