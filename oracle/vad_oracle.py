@@ -174,9 +174,10 @@ def tokenize_chunk(valid, non_speech_label=0.0, sample_rate=100):
 
 
 def tokenize_chunk_scan(valid, non_speech_label=0.0, min_length=20, max_length=500, max_continuous_silence=25):
-    """numpy model of the device's PARALLEL formulation of the same smoothing (k_vad_tokenize_scan: one workgroup per
-    chunk, every step a scan) -- test infrastructure like fft_model.py; tests/test_oracle_vad.py checks it against the
-    state machine above.  Requires max_length >= min_length.
+    """numpy model of the PARALLEL formulation of the same smoothing (the island rule; the form k_vad_tokenize_scan had
+    in rounds 4-6: per-frame index arrays, every step a scan -- tokenize_chunk_words() below models the kernel as it is
+    now) -- test infrastructure like fft_model.py; tests/test_oracle_vad.py checks it against the state machine above.
+    Requires max_length >= min_length.
 
     The tokenizer's state (and its silence counter) depends on the validity runs alone, so the frames fall into
     islands: an island starts at a valid frame that follows more than max_continuous_silence invalid ones (or no
