@@ -207,6 +207,17 @@ struct ffs_plan {
     void* host_desc = nullptr;                // pinned
     size_t host_desc_bytes = 0;
     hipEvent_t upload_done = nullptr;
+    // Large run-boundary calls (more than kSmallCallCands candidates) upload their descriptors on a COPY STREAM of the plan
+    // into one of TWO device blocks (dev_desc / dev_desc2, alternating): the vector table of call k + 1 goes up while
+    // call k's correlation runs, the candidate descriptors while the extraction of their own call runs -- on one stream
+    // the two uploads sat between the kernels with the device idle (126 + 70 us of a 3.3 ms step of 8192 pairs,
+    // profiles/large_step_timeline.py).  Created on the first such call (a stream per plan makes plan creation slow).
+    void* dev_desc2 = nullptr;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_ev = nullptr;                 // the vector table of the current call has arrived
+    hipEvent_t half_done[2] = {nullptr, nullptr};  // the last call that used block h has finished
+    bool half_used[2] = {false, false};
+    int cur_half = 0;                             // the block the current (or most recent) call uses
     // The workspace, descriptor and nominee buffers are reused by every call: a call on another stream
     // than the previous one first waits for that one's last kernel (same-stream calls are ordered anyway).
     hipEvent_t last_done = nullptr;
@@ -267,6 +278,9 @@ int ensure_desc(ffs_plan* p, size_t bytes) {
     if (bytes <= p->dev_desc_bytes) return FFS_OK;
     if (p->upload_done) HIP_TRY(hipEventSynchronize(p->upload_done));
     if (p->dev_desc) HIP_TRY(hipFree(p->dev_desc));
+    if (p->dev_desc2) HIP_TRY(hipFree(p->dev_desc2));  // (allocated again by ensure_copy, at the new size)
+    p->dev_desc2 = nullptr;
+    p->half_used[1] = false;
     if (p->host_desc) HIP_TRY(hipHostFree(p->host_desc));
     p->dev_desc = nullptr;
     p->host_desc = nullptr;
@@ -275,6 +289,17 @@ int ensure_desc(ffs_plan* p, size_t bytes) {
     HIP_TRY(hipMalloc(&p->dev_desc, cap));
     HIP_TRY(hipHostMalloc(&p->host_desc, cap, hipHostMallocDefault));
     p->dev_desc_bytes = p->host_desc_bytes = cap;
+    return FFS_OK;
+}
+
+// Copy stream, its events and the second descriptor block (see ffs_plan::dev_desc2).
+int ensure_copy(ffs_plan* p) {
+    if (!p->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
+        for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&p->half_done[h], hipEventDisableTiming));
+    }
+    if (!p->dev_desc2) HIP_TRY(hipMalloc(&p->dev_desc2, p->dev_desc_bytes));
     return FFS_OK;
 }
 
@@ -385,6 +410,10 @@ int enter_stream(ffs_plan* p, hipStream_t st) {
     return FFS_OK;
 }
 int leave_stream(ffs_plan* p, hipStream_t st) {
+    if (p->copy_stream) {
+        HIP_TRY(hipEventRecord(p->half_done[p->cur_half], st));
+        p->half_used[p->cur_half] = true;
+    }
     HIP_TRY(hipEventRecord(p->last_done, st));
     p->last_stream = st;
     p->has_last = true;
@@ -1173,7 +1202,14 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->lvl_buf);
     if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
     if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
+    if (p->copy_stream) {
+        (void)hipStreamSynchronize(p->copy_stream);
+        (void)hipStreamDestroy(p->copy_stream);
+        (void)hipEventDestroy(p->copy_ev);
+        for (int h = 0; h < 2; ++h) (void)hipEventDestroy(p->half_done[h]);
+    }
     (void)hipFree(p->dev_desc);
+    (void)hipFree(p->dev_desc2);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
     if (p->upload_done) (void)hipEventDestroy(p->upload_done);
     if (p->last_done) (void)hipEventDestroy(p->last_done);
@@ -1265,6 +1301,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         if ((rc0 = grow_pack_buf(p, off[n_vec]))) return rc0;
         if ((rc0 = ensure_desc(p, n_vec * sizeof(PackVec) + 4096))) return rc0;
         HIP_TRY(hipEventSynchronize(p->upload_done));
+        p->cur_half = 0;
         PackVec* hp = (PackVec*)p->host_desc;
         std::vector<const void*> packed(n_vec);
         for (size_t i = 0; i < n_vec; ++i) {
@@ -1429,7 +1466,11 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     CandDesc* hc = (CandDesc*)(hb + o_cand);
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     RunsRef* hrv = (RunsRef*)(hb + o_rv);
-    char* db = (char*)p->dev_desc;
+    const bool ml_early = runs_ok && ml;
+    const bool use_copy = runs_ok && need_extract && !ml_early && n_cands > kSmallCallCands && !(p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in);
+    if (use_copy && (rc = ensure_copy(p))) return rc;
+    p->cur_half = use_copy ? 1 - p->cur_half : 0;
+    char* db = (char*)(p->cur_half ? p->dev_desc2 : p->dev_desc);
     bool probe_first = false;           // (run-boundary path) a density probe stands in for the extraction so far
     // sub-batch flags + two 8-byte statistics behind them (boundaries of the call, its longest plan-owned list): cleared by the
     // extraction kernel's first workgroup when one is launched, by a memset otherwise
@@ -1517,7 +1558,14 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         } else if (need_extract && n_cands <= kSmallCallCands && !(p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in)) {
             late_extract = true;  // (uploaded and launched behind the candidate descriptors, below)
         } else if (need_extract) {
-            HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
+            if (use_copy) {
+                if (p->half_used[p->cur_half]) HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->half_done[p->cur_half], 0));
+                HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, p->copy_stream));
+                HIP_TRY(hipEventRecord(p->copy_ev, p->copy_stream));
+                HIP_TRY(hipStreamWaitEvent(st, p->copy_ev, 0));
+            } else {
+                HIP_TRY(hipMemcpyAsync(db + o_rv, hb + o_rv, n_vec * sizeof(RunsRef), hipMemcpyHostToDevice, st));
+            }
             leave.armed = true;
             // A stream of dense calls (the previous one needed the transforms): sample the vectors first -- when the
             // estimate puts every sub-batch far over budget the lists are never extracted (decided below, once the
@@ -1660,12 +1708,18 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!runs_ok && (rc = build_xforms())) return rc;
     // one upload when the transforms run anyway; with the run-boundary path [header, candidates] (+ the vector table
     // when no extraction was launched ahead of it)
-    if (runs_ok && (!need_extract || late_extract))
+    if (runs_ok && (!need_extract || late_extract)) {
         HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_rr * sizeof(RunsRef), hipMemcpyHostToDevice, st));
-    else
+    } else if (runs_ok && use_copy) {  // (beside the extraction of this call)
+        HIP_TRY(hipMemcpyAsync(db, hb, o_rv, hipMemcpyHostToDevice, p->copy_stream));
+        HIP_TRY(hipEventRecord(p->upload_done, p->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(st, p->upload_done, 0));
+    } else {
         HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
+    }
     leave.armed = true;
-    HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
+    if (!(runs_ok && use_copy && need_extract && !late_extract))
+        HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
     if (late_extract) {
         ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
         runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
@@ -2086,6 +2140,7 @@ int ffs_correlate_full(ffs_plan* p, int dtype, const void* ref_dev, int64_t ref_
     if ((rc = ensure_workspace(p))) return rc;
     if ((rc = ensure_desc(p, 4096))) return rc;
     HIP_TRY(hipEventSynchronize(p->upload_done));
+    p->cur_half = 0;
     XformDesc* hx = (XformDesc*)p->host_desc;
     VecView r{ref_dev, ref_len, ref_lo, ref_hi}, a{a_dev, a_len, a_lo, a_hi}, b{b_dev, b_len, b_lo, b_hi};
     fill_xform(&hx[0], &r, nullptr);
