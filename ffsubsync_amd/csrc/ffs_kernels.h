@@ -2592,8 +2592,9 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
 //   P0  validity as 64-bit words V (one ballot per 64 coalesced frames);
 //   P1  PL[w] = last valid frame in the words in front of w (one value per WORD: a DPP wave scan + seven wave totals),
 //       which makes "last valid frame <= i" one or two LDS reads: the word's own bits, else PL;
-//   P2  island starts as a second bit array S: frame i starts an island iff it is valid and its predecessor is outside
-//       every island -- the word's bits below the lane, else PL: registers only, one ballot per word;
+//   P2  island starts as a second bit array S, one thread per word: frame i starts an island iff it is valid and no valid
+//       frame lies in the max_sil + 1 frames in front of it -- the word's own bits smeared upwards (shift-or doubling)
+//       and the low frames that PL still covers;
 //   P3  SL[w] / NS[w] = last start in front of / first start behind word w (two scans, one pair of barriers);
 //   P4  one thread per HALF WORD of S walks its island starts (typically none or one) and sets the marker BITS of the
 //       island's pieces in two more bit arrays (P: +1, M: non_speech - 1; a frame in both carries the +1); the island's
@@ -2601,7 +2602,7 @@ __global__ void k_vad_tokenize(const float* __restrict__ valid, long long n_fram
 //   P5  clip(cumsum) per frame without a sum over frames: label(i) = clamp(#P(<= i) + #M(<= i) (non_speech - 1), 0, 1),
 //       the counts from a packed prefix count per word + a popcount (fp64; equal to the sequential sum whenever that one
 //       is exact -- every term is a float -- which is what rounds 4-6's blocked prefix sum relied on as well).
-// Frames map to lanes the same way in P0, P2 and P5: wave v owns the words v, v + 16, ...; lane k of the wave holds the
+// Frames map to lanes the same way in P0 and P5: wave v owns the words v, v + 16, ...; lane k of the wave holds the
 // wave's k-th word of every bit array in a register (v_readlane hands it to the whole wave: no LDS round trip per word),
 // lane l of the wave is frame 64 w + l of the word being processed -- loads and stores are coalesced.
 // oracle/vad_oracle.py::tokenize_chunk_words is the model of exactly this, tested against the state machine on the
@@ -2769,21 +2770,29 @@ __global__ __launch_bounds__(TOK_THREADS) void k_vad_tokenize_scan(const float* 
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 2
     if (n >= 0) return;
 #endif
-    // P2: island starts
-    {
-        const int pl_reg = own ? s_PL[my_w] : -1;
-        unsigned long long s_reg = 0ull;
-        for (int k = 0; wave + NWV * k < W; ++k) {
-            const int base = (wave + NWV * k) << 6, i = base + lane;
-            const unsigned long long vw = lane64(v_reg, k);
-            const int pl = __builtin_amdgcn_readlane(pl_reg, k);
-            const unsigned long long below = vw & ((1ull << lane) - 1ull);  // valid frames of this word in front of frame i
-            const int lv = below ? base + 63 - __clzll((long long)below) : pl;
-            const bool start = ((vw >> lane) & 1ull) && (lv < 0 || i - 1 - lv > ms);
-            const unsigned long long m = __ballot(start);
-            if (lane == k) s_reg = m;
+    // P2: island starts, one thread per word: a valid frame starts an island iff no valid frame lies in the K = max_sil + 1
+    // frames in front of it -- the word's own bits smeared upwards by 1 .. K (doubling: log2 K shift-ors), and the low
+    // frames the last valid frame of the words in front still covers
+    if (tid < W) {
+        const unsigned long long x = s_V[tid];
+        const int K = ms + 1;
+        unsigned long long g;
+        if (K >= 64) {
+            const unsigned long long low = x & (0ull - x);
+            g = x ? ~(low | (low - 1ull)) : 0ull;  // every frame of the word behind its first valid one
+        } else {
+            g = x << 1;
+            for (int c = 1; c < K;) {
+                const int sh = c < K - c ? c : K - c;
+                g |= g << sh;
+                c += sh;
+            }
         }
-        if (own) s_S[my_w] = s_reg;
+        const int pl = s_PL[tid];
+        int cnt = pl >= 0 ? pl + K - (tid << 6) + 1 : 0;  // frames 64 tid .. pl + K are within K of frame pl
+        cnt = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
+        const unsigned long long inc = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        s_S[tid] = x & ~(g | inc);
     }
     __syncthreads();
 #if defined(FFS_TOK_STOP) && FFS_TOK_STOP == 3

@@ -317,15 +317,13 @@ def test_host_batch_entry_equals_one_call_per_problem(torch):
     assert np.allclose(p3["score"][1:], pres["score"][1:], rtol=1e-12)
 
 
-def test_calls_beyond_65536_vectors_are_split(torch):
-    """8200 seven-candidate problems = 65 600 vectors in one ffs_align_batch call: the run-boundary path solves them as two
-    consecutive sub-calls (boundary-list workspace bounded at 65 536 vectors); records equal the transform path's."""
+def _block_batch(torch, seed, n_pairs, n_cand=7, R=4608):
+    """n_pairs short problems (runs of 64 samples, candidates = shifted copies) as one bit-packed DeviceBatch."""
     from ffsubsync_amd import _native
     from ffsubsync_amd.batch import DeviceBatch
 
-    rng = np.random.RandomState(11)
-    n_pairs, n_cand, R = 8200, 7, 4608
-    base = np.repeat(rng.rand(n_pairs, R // 64) < 0.4, 64, axis=1)                      # runs of 64 samples
+    rng = np.random.RandomState(seed)
+    base = np.repeat(rng.rand(n_pairs, R // 64) < 0.4, 64, axis=1)
     shifts = rng.randint(-300, 300, size=(n_pairs, n_cand))
     words_per = R // 32
     stride_b = (words_per * 4 + 63) // 64 * 64
@@ -339,12 +337,56 @@ def test_calls_beyond_65536_vectors_are_split(torch):
     data = torch.from_numpy(host.reshape(-1)).cuda()
     offs = (np.arange(n_pairs * (1 + n_cand), dtype=np.int64) * stride_b).reshape(n_pairs, 1 + n_cand)
     lens = np.full((n_pairs, 1 + n_cand), R, np.int64)
-    db = DeviceBatch(data, offs, lens, np.zeros(offs.shape), np.ones(offs.shape), _native.FFS_DTYPE_U1)
+    return DeviceBatch(data, offs, lens, np.zeros(offs.shape), np.ones(offs.shape), _native.FFS_DTYPE_U1)
+
+
+def test_calls_beyond_65536_vectors_are_split(torch):
+    """8200 seven-candidate problems = 65 600 vectors in one ffs_align_batch call: the run-boundary path solves them as two
+    consecutive sub-calls (boundary-list workspace bounded at 65 536 vectors); records equal the transform path's."""
+    db = _block_batch(torch, 11, 8200)
     n_fft = db.required_fft_length(600)
     a, st = _solve(db, n_fft, 600, "auto", pairs_in_flight=512)
     b, _ = _solve(db, n_fft, 600, "fft", pairs_in_flight=512)
     assert st[0] == 2 and st[2] == 0  # two sub-calls, nothing through the transforms
     _same_records(a, b)
+
+
+def test_large_calls_alternate_descriptor_blocks_and_mix_with_small_ones(torch):
+    """Calls of more than 4096 candidates upload their descriptors on the plan's copy stream into alternating device blocks
+    (the next call's vector table goes up while this call's correlation runs); small calls keep the single upload on the
+    call's stream.  Six calls queued back to back on ONE plan without a synchronisation in between -- three different
+    large batches, a small one in the middle, one call on a side stream, a growing call last (the descriptor blocks are
+    reallocated) -- every call's records equal the transform path's: a descriptor that arrived late, or in the block a
+    running kernel still reads, would show as another call's answers."""
+    from ffsubsync_amd import _native, batch
+
+    sets = {"A": _block_batch(torch, 21, 700), "B": _block_batch(torch, 22, 700), "C": _block_batch(torch, 23, 640),
+            "S": _block_batch(torch, 24, 40), "G": _block_batch(torch, 25, 1500)}
+    n_fft = sets["A"].required_fft_length(600)
+    want = {k: _solve(db, n_fft, 600, "fft", pairs_in_flight=128)[0] for k, db in sets.items()}
+    al = batch.BatchAligner(n_fft, 7, 600, pairs_in_flight=128, algorithm="auto")
+    side = torch.cuda.Stream()
+    order = ["A", "B", "S", "C", "A", "B", "G", "A"]
+    outs = []
+    for i, k in enumerate(order):
+        n = sets[k].offs.shape[0]
+        co = torch.empty(n * 7 * 24, dtype=torch.uint8, device="cuda")
+        po = torch.empty(n * 24, dtype=torch.uint8, device="cuda")
+        if i == 4:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                al.solve_async(sets[k], 0, n, co, po)
+            torch.cuda.current_stream().wait_stream(side)
+        else:
+            al.solve_async(sets[k], 0, n, co, po)
+        outs.append((k, n, co, po))
+    torch.cuda.synchronize()
+    calls, _, fft_chunks = al.plan.runs_stats()
+    assert calls == len(order) and fft_chunks == 0
+    for k, n, co, po in outs:
+        got = (co.cpu().numpy().view(_native.CAND_RESULT_DTYPE).reshape(n, 7), po.cpu().numpy().view(_native.PAIR_RESULT_DTYPE))
+        _same_records(got, want[k])
+    al.close()
 
 
 def test_byte_inputs_are_packed_on_the_device_and_take_the_same_path(headline):
