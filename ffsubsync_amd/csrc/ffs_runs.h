@@ -29,11 +29,17 @@
 
 namespace ffsa {
 
-constexpr int RUNS_THREADS = 512;                 // k_runs_corr workgroup
+#ifndef FFS_RUNS_THREADS  // (A/B builds only: profiles/r06_runs_experiments.json, "seven-wave workgroups")
+#define FFS_RUNS_THREADS 512
+#define FFS_RUNS_T 12288
+#define FFS_RUNS_QCAP 3070
+#endif
+constexpr int RUNS_THREADS = FFS_RUNS_THREADS;    // k_runs_corr workgroup
 constexpr int RUNS_WAVES = RUNS_THREADS / 64;
-constexpr int RUNS_T = 12288;                     // lags per tile = per workgroup (the +-6000-lag production window is one tile)
+constexpr int RUNS_T = FFS_RUNS_T;                // lags per tile = per workgroup (the +-6000-lag production window is one tile)
 constexpr int RUNS_LPT = RUNS_T / RUNS_THREADS;   // consecutive lags per thread in the scan phase
-constexpr int RUNS_QCAP = 3070;                   // reference boundaries staged in LDS at a time (longer lists: slice by slice)
+constexpr int RUNS_QCAP = FFS_RUNS_QCAP;          // reference boundaries staged in LDS at a time (longer lists: slice by slice)
+static_assert(RUNS_T % RUNS_THREADS == 0 && RUNS_LPT % 4 == 0 && RUNS_LPT <= 32, "whole groups of four lags per thread, 32-bit edge windows");
 constexpr int RUNS_CAP = 32768;                   // boundary-list entries per vector incl. the sentinel (plan-owned lists)
 #ifndef FFS_RUNS_TPW
 #define FFS_RUNS_TPW 2
@@ -41,7 +47,7 @@ constexpr int RUNS_CAP = 32768;                   // boundary-list entries per v
 constexpr int RUNS_TPW = FFS_RUNS_TPW;             // wave tasks (64 candidate RUNS each, one per lane) a wave advances together
 constexpr int RUNS_QSENT = 0x1fffffff;            // staged sentinel: beyond every position (a plan's vectors are shorter than 2^24); DOUBLED in
                                                   // LDS, and sentinel - position must not overflow 32 bits for any position > -2^26
-static_assert(RUNS_LPT <= 32 && RUNS_LPT % 8 == 0 && RUNS_QCAP % 2 == 0, "one 32-bit mask per thread, 16-byte histogram loads");
+static_assert(RUNS_LPT <= 32 && RUNS_LPT % 4 == 0 && RUNS_QCAP % 2 == 0, "one 32-bit mask per thread, 8-byte histogram loads");
 
 // One vector of a call as the run-boundary kernels see it.  e[k] = (position of boundary k, ones of the vector in front of
 // it), k < n, sorted; e[n] = (INT32_MAX, all ones); n is even (a run that reaches the end closes at position len).
