@@ -297,7 +297,6 @@ int ensure_copy(ffs_plan* p) {
     if (!p->copy_stream) {
         HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
-        for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&p->half_done[h], hipEventDisableTiming));
     }
     if (!p->dev_desc2) HIP_TRY(hipMalloc(&p->dev_desc2, p->dev_desc_bytes));
     return FFS_OK;
@@ -410,10 +409,9 @@ int enter_stream(ffs_plan* p, hipStream_t st) {
     return FFS_OK;
 }
 int leave_stream(ffs_plan* p, hipStream_t st) {
-    if (p->copy_stream) {
-        HIP_TRY(hipEventRecord(p->half_done[p->cur_half], st));
-        p->half_used[p->cur_half] = true;
-    }
+    // (every call, whichever stream uploaded its descriptors: a later call's copy-stream upload into this block waits for it)
+    HIP_TRY(hipEventRecord(p->half_done[p->cur_half], st));
+    p->half_used[p->cur_half] = true;
     HIP_TRY(hipEventRecord(p->last_done, st));
     p->last_stream = st;
     p->has_last = true;
@@ -1040,6 +1038,7 @@ int ffs_plan_create(int device, int64_t n_fft, int pairs_in_flight, int max_cand
     p->max_slots = 1 + (max_cand + 1) / 2;
     HIP_TRY(hipEventCreateWithFlags(&p->upload_done, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&p->last_done, hipEventDisableTiming));
+    for (int h = 0; h < 2; ++h) HIP_TRY(hipEventCreateWithFlags(&p->half_done[h], hipEventDisableTiming));
     {
         // Run-time knobs: five, all listed in INTEGRATION.md section 6, each selecting between code paths that
         // return identical records (every pairing has an "identical records" GPU test).
@@ -1206,8 +1205,9 @@ int ffs_plan_destroy(ffs_plan* p) {
         (void)hipStreamSynchronize(p->copy_stream);
         (void)hipStreamDestroy(p->copy_stream);
         (void)hipEventDestroy(p->copy_ev);
-        for (int h = 0; h < 2; ++h) (void)hipEventDestroy(p->half_done[h]);
     }
+    for (int h = 0; h < 2; ++h)
+        if (p->half_done[h]) (void)hipEventDestroy(p->half_done[h]);
     (void)hipFree(p->dev_desc);
     (void)hipFree(p->dev_desc2);
     if (p->host_desc) (void)hipHostFree(p->host_desc);
