@@ -207,11 +207,11 @@ struct ffs_plan {
     void* host_desc = nullptr;                // pinned
     size_t host_desc_bytes = 0;
     hipEvent_t upload_done = nullptr;
-    // Large run-boundary calls (more than kSmallCallCands candidates) upload their descriptors on a COPY STREAM of the plan
+    // Run-boundary calls that extract lists upload their descriptors on a COPY STREAM (one per device, shared by the plans)
     // into one of TWO device blocks (dev_desc / dev_desc2, alternating): the vector table of call k + 1 goes up while
-    // call k's correlation runs, the candidate descriptors while the extraction of their own call runs -- on one stream
-    // the two uploads sat between the kernels with the device idle (126 + 70 us of a 3.3 ms step of 8192 pairs,
-    // profiles/large_step_timeline.py).  Created on the first such call (a stream per plan makes plan creation slow).
+    // call k's correlation runs, a large call's candidate descriptors while the extraction of their own call runs -- on
+    // one stream the uploads sat between the kernels with the device idle (126 + 70 us of a 3.3 ms step of 8192 pairs,
+    // ~20 us of a 111 us step of 128: profiles/large_step_timeline.py, small_step_timeline.py).
     void* dev_desc2 = nullptr;
     hipStream_t copy_stream = nullptr;
     hipEvent_t copy_ev = nullptr;                 // the vector table of the current call has arrived
@@ -292,14 +292,38 @@ int ensure_desc(ffs_plan* p, size_t bytes) {
     return FFS_OK;
 }
 
-// Copy stream, its events and the second descriptor block (see ffs_plan::dev_desc2).
-int ensure_copy(ffs_plan* p) {
-    if (!p->copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming));
+// The copy stream: ONE per device for every plan of the process, created on first use (the calling thread's current device
+// is `device`) and never destroyed -- a stream per plan made plan creation slow enough to stretch the GPU test suite from
+// 40 s to 7.6 min (round 6, first attempt).  Plans only ever queue their own descriptor uploads on it, each behind an
+// event of their own that has long completed; what they share is the order of those uploads.
+hipStream_t shared_copy_stream(int device) {
+    static std::mutex mu;
+    static hipStream_t streams[64] = {};
+    if (device < 0 || device >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        streams[device] = nullptr;
     }
-    if (!p->dev_desc2) HIP_TRY(hipMalloc(&p->dev_desc2, p->dev_desc_bytes));
-    return FFS_OK;
+    return streams[device];
+}
+// Copy stream, its event and the second descriptor block (see ffs_plan::dev_desc2); false: this call uploads on its own stream.
+bool ensure_copy(ffs_plan* p) {
+    if (!p->copy_stream) {
+        p->copy_stream = shared_copy_stream(p->device);
+        if (!p->copy_stream) return false;
+    }
+    if (!p->copy_ev && hipEventCreateWithFlags(&p->copy_ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        p->copy_ev = nullptr;
+        return false;
+    }
+    if (!p->dev_desc2 && hipMalloc(&p->dev_desc2, p->dev_desc_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        p->dev_desc2 = nullptr;
+        return false;
+    }
+    return true;
 }
 
 // Raise a kernel's dynamic-LDS limit once per plan (tiles above 64 KB need it).
@@ -1201,11 +1225,8 @@ int ffs_plan_destroy(ffs_plan* p) {
     (void)hipFree(p->lvl_buf);
     if (p->runs_flags_host) (void)hipHostFree(p->runs_flags_host);
     if (p->runs_ev) (void)hipEventDestroy(p->runs_ev);
-    if (p->copy_stream) {
-        (void)hipStreamSynchronize(p->copy_stream);
-        (void)hipStreamDestroy(p->copy_stream);
-        (void)hipEventDestroy(p->copy_ev);
-    }
+    if (p->upload_done) (void)hipEventSynchronize(p->upload_done);  // (the shared copy stream may still be reading the pinned block)
+    if (p->copy_ev) (void)hipEventDestroy(p->copy_ev);
     for (int h = 0; h < 2; ++h)
         if (p->half_done[h]) (void)hipEventDestroy(p->half_done[h]);
     (void)hipFree(p->dev_desc);
@@ -1467,8 +1488,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     XformDesc* hx = (XformDesc*)(hb + o_xf);
     RunsRef* hrv = (RunsRef*)(hb + o_rv);
     const bool ml_early = runs_ok && ml;
-    const bool use_copy = runs_ok && need_extract && !ml_early && n_cands > kSmallCallCands && !(p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in);
-    if (use_copy && (rc = ensure_copy(p))) return rc;
+    const bool use_copy = runs_ok && need_extract && !ml_early && !(p->algo == FFS_ALGO_AUTO && p->runs_prev_fft && !lists_in) && ensure_copy(p);
     p->cur_half = use_copy ? 1 - p->cur_half : 0;
     char* db = (char*)(p->cur_half ? p->dev_desc2 : p->dev_desc);
     bool probe_first = false;           // (run-boundary path) a density probe stands in for the extraction so far
@@ -1708,7 +1728,12 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
     if (!runs_ok && (rc = build_xforms())) return rc;
     // one upload when the transforms run anyway; with the run-boundary path [header, candidates] (+ the vector table
     // when no extraction was launched ahead of it)
-    if (runs_ok && (!need_extract || late_extract)) {
+    if (runs_ok && late_extract && use_copy) {  // the whole block on the copy stream: it passes the previous call's kernels
+        if (p->half_used[p->cur_half]) HIP_TRY(hipStreamWaitEvent(p->copy_stream, p->half_done[p->cur_half], 0));
+        HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_rr * sizeof(RunsRef), hipMemcpyHostToDevice, p->copy_stream));
+        HIP_TRY(hipEventRecord(p->upload_done, p->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(st, p->upload_done, 0));
+    } else if (runs_ok && (!need_extract || late_extract)) {
         HIP_TRY(hipMemcpyAsync(db, hb, o_rv + n_rr * sizeof(RunsRef), hipMemcpyHostToDevice, st));
     } else if (runs_ok && use_copy) {  // (beside the extraction of this call)
         HIP_TRY(hipMemcpyAsync(db, hb, o_rv, hipMemcpyHostToDevice, p->copy_stream));
@@ -1718,7 +1743,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         HIP_TRY(hipMemcpyAsync(db, hb, runs_ok ? o_rv : o_xf + n_xf * sizeof(XformDesc), hipMemcpyHostToDevice, st));
     }
     leave.armed = true;
-    if (!(runs_ok && use_copy && need_extract && !late_extract))
+    if (!(runs_ok && use_copy))
         HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
     if (late_extract) {
         ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
