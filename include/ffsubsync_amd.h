@@ -13,7 +13,10 @@
  *   - "_dev" pointers are device (HBM) addresses owned by the caller (e.g. torch tensors'
  *     data_ptr()); all other pointers are host memory.  `hip_stream` is a hipStream_t
  *     (0 = the null stream).  Calls are asynchronous with respect to the host unless stated;
- *     results land in caller-owned device buffers in stream order.
+ *     results land in caller-owned device buffers in stream order.  ffs_align_batch* may copy
+ *     their own descriptors to the device on an internal copy stream (one per device); the kernels
+ *     that read the caller's vectors and write its results run on `hip_stream` only, after the
+ *     stream has waited for those copies.
  *   - a plan owns its twiddle tables and workspace in HBM and may be used by one host thread
  *     at a time; successive calls on different streams are ordered by the library (a call waits
  *     for the plan's previous call before it touches the workspace).
