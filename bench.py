@@ -995,9 +995,12 @@ def main():
             pairs_per_launch = P * steps / n
             entry = {"avg_ms": ms / n, "launches": n, "total_ms": ms, "us_per_pair": 1e3 * ms / (P * steps)}
             if k == "runs_extract" and last_info.get("boundaries_last_call"):
-                # reads every bit-packed vector once, writes two 4-byte entries per boundary (+ the sentinel of each list)
+                # reads every bit-packed vector once, writes one entry per boundary (+ the sentinel of each list): 8 bytes
+                # (position, ones in front) in the reference's list, 4 (position) in the candidates' (RunsRef, ffs_runs.h);
+                # the call's boundary count is split between the lists by their number -- the vectors are equally dense
+                entry_bytes = (8.0 + 4.0 * cands) / (1.0 + cands)
                 per_pair = (last_info["vectors_bytes_per_pair"]
-                            + 8.0 * last_info["boundaries_last_call"] / last_info["pairs_per_call"] + 8.0 * (1 + cands))
+                            + entry_bytes * last_info["boundaries_last_call"] / last_info["pairs_per_call"] + 8.0 + 4.0 * cands)
                 entry["must_move_bytes_per_launch"] = per_pair * pairs_per_launch
                 entry["must_move_GBps"] = entry["must_move_bytes_per_launch"] / (ms / n * 1e-3) / 1e9
                 entry["frac_of_8TBps"] = entry["must_move_GBps"] * 1e9 / HBM_PEAK

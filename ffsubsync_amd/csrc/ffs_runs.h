@@ -52,6 +52,11 @@ static_assert(RUNS_LPT <= 32 && RUNS_LPT % 4 == 0 && RUNS_QCAP % 2 == 0, "one 32
 // One vector of a call as the run-boundary kernels see it.  e[k] = (position of boundary k, ones of the vector in front of
 // it), k < n, sorted; e[n] = (INT32_MAX, all ones); n is even (a run that reaches the end closes at position len).
 // hdr->x = n (>= the list's capacity when it was truncated), hdr->y = ones.
+// A plan-owned list of a CANDIDATE that arrived as bits (bits != null, cap > 0, the vector is not its pair's reference) is
+// COMPACT: e holds 4-byte positions only (nothing reads a candidate's ones-in-front column: k_runs_corr counts the
+// candidate's ones from the positions) -- the 8-byte entry stores are what holds k_runs_extract below the read ceiling, and
+// seven of a pair's eight lists are candidates'.  References, threshold planes and every caller-owned list keep
+// (position, ones in front).
 struct RunsRef {
     const int2* e;
     const int2* hdr;
@@ -167,6 +172,12 @@ constexpr int RUNS_XQ = 256;  // items per wave ring (a group of a sweep adds at
 // 32 KB: a 90 KB vector takes 3 dependent memory round trips instead of 11 -- small calls, where the latency of ONE
 // vector is what the caller waits for).
 template <int NT>
+FFS_DEV void runs_extract_lds(unsigned (*&s_e)[NT / 64 * 2], unsigned (*&s_o)[NT / 64 * 2], uint4 (*&s_q)[RUNS_XQ]) {
+    __shared__ unsigned l_e[2][NT / 64 * 2], l_o[2][NT / 64 * 2];
+    __shared__ __attribute__((aligned(16))) uint4 l_q[NT / 64][RUNS_XQ];
+    s_e = l_e, s_o = l_o, s_q = l_q;
+}
+template <int NT, bool compact = false>
 FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int len, int2* __restrict__ e, int2* __restrict__ hdr,
                                const int cap) {
     constexpr int NWV = NT / 64;                // waves
@@ -176,8 +187,10 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
     const int nw = (len + 31) >> 5;     // words that hold samples
     const int n_proc = (len >> 5) + 1;  // word len/32 holds position `len`, where a run that reaches the end closes
     const unsigned tail = (len & 31) ? ((1u << (len & 31)) - 1u) : 0xffffffffu;  // valid bits of word nw - 1
-    __shared__ unsigned s_e[2][NWV * 2], s_o[2][NWV * 2];
-    __shared__ __attribute__((aligned(16))) uint4 s_q[NWV][RUNS_XQ];
+    // (LDS through a helper that is a template of NT alone: the two instantiations of this body for one NT share it)
+    unsigned(*s_e)[NWV * 2], (*s_o)[NWV * 2];
+    uint4(*s_q)[RUNS_XQ];
+    runs_extract_lds<NT>(s_e, s_o, s_q);
     uint4* const ring = s_q[wave];
     unsigned q_head = 0, q_tail = 0;   // items [head, tail) of this wave's ring are waiting (wave-uniform)
     unsigned n_bound = 0, n_ones = 0;  // boundaries / ones in front of this sweep
@@ -212,8 +225,11 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
                 const int b = __builtin_ctz(eb_k);
                 if (k_out < cap) {  // (scalar list base + 32-bit byte offset: no 64-bit address arithmetic per store)
                     typedef int v2i __attribute__((ext_vector_type(2)));
-                    *(__attribute__((address_space(1))) v2i*)(eb + 8u * (unsigned)k_out) =
-                        (v2i){pos0 + b, (int)it.z + (int)__popc(it.y & ((1u << b) - 1u))};
+                    if (compact)  // positions only (see RunsRef): half the bytes of the stores that cost this kernel most
+                        *(__attribute__((address_space(1))) int*)(eb + 4u * (unsigned)k_out) = pos0 + b;
+                    else
+                        *(__attribute__((address_space(1))) v2i*)(eb + 8u * (unsigned)k_out) =
+                            (v2i){pos0 + b, (int)it.z + (int)__popc(it.y & ((1u << b) - 1u))};
                 }
                 ++k_out;
                 eb_k &= eb_k - 1;
@@ -335,7 +351,12 @@ FFS_DEV void runs_extract_body(const unsigned* __restrict__ w_generic, const int
     while (q_tail != q_head) drain();
     if (tid == 0) {
         *hdr = make_int2((int)n_bound, (int)n_ones);
-        if ((int)n_bound < cap) e[n_bound] = make_int2(INT32_MAX, (int)n_ones);
+        if ((int)n_bound < cap) {
+            if (compact)
+                reinterpret_cast<int*>(e)[n_bound] = INT32_MAX;
+            else
+                e[n_bound] = make_int2(INT32_MAX, (int)n_ones);
+        }
     }
 }
 
@@ -376,31 +397,46 @@ FFS_DEV void runs_extract_zero(int* __restrict__ zero, int zero_words) {
     if (zero && blockIdx.x == 0)
         for (int i = threadIdx.x; i < zero_words; i += blockDim.x) zero[i] = 0;
 }
-__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs, int* __restrict__ zero, int zero_words) {
+// (`cstride`, `n_plain`: vectors v < n_plain with v % cstride != 0 are the CANDIDATES of a call: their plan-owned lists are
+// written compact, see RunsRef; cstride = 0: none)
+FFS_DEV bool runs_compact_vec(int cstride, int n_plain) {
+    return cstride > 0 && (int)blockIdx.x < n_plain && (int)blockIdx.x % cstride != 0;
+}
+__global__ __launch_bounds__(256, 8) void k_runs_extract(const RunsRef* __restrict__ refs, int* __restrict__ zero, int zero_words,
+                                                         int cstride, int n_plain) {
     runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
-    runs_extract_body<256>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    if (runs_compact_vec(cstride, n_plain))
+        runs_extract_body<256, true>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    else
+        runs_extract_body<256, false>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 // The same for calls with few vectors: a vector's latency, not the chip's throughput, is what such a call waits for.  At
 // most 256 vectors: 1024-thread workgroups (one per CU, 3 sweeps per 90 KB vector); at most 768: 512 threads (three per CU,
 // 6 sweeps); more: 256 threads (eight per CU, 11 sweeps -- the wide instantiations need more than 64 registers, so they
 // only pay while every vector of the call is resident at once).  See runs_extract_launch().
 __global__ __launch_bounds__(512, 4) void k_runs_extract_512(const RunsRef* __restrict__ refs, int with_len_cap, int* __restrict__ zero,
-                                                             int zero_words) {
+                                                             int zero_words, int cstride, int n_plain) {
     runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
     if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
-    runs_extract_body<512>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    if (runs_compact_vec(cstride, n_plain))
+        runs_extract_body<512, true>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    else
+        runs_extract_body<512, false>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 __global__ __launch_bounds__(1024, 4) void k_runs_extract_1024(const RunsRef* __restrict__ refs, int with_len_cap, int* __restrict__ zero,
-                                                               int zero_words) {
+                                                               int zero_words, int cstride, int n_plain) {
     runs_extract_zero(zero, zero_words);
     const RunsRef r = refs[blockIdx.x];
     if (!r.bits) return;
     if (with_len_cap && threadIdx.x == 0) const_cast<int2*>(r.hdr)[1] = make_int2(r.len, r.cap);
-    runs_extract_body<1024>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    if (runs_compact_vec(cstride, n_plain))
+        runs_extract_body<1024, true>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
+    else
+        runs_extract_body<1024, false>(r.bits, r.len, const_cast<int2*>(r.e), const_cast<int2*>(r.hdr), r.cap);
 }
 
 // vectors into caller-owned list blocks (ffs_runs_from_bits_batch): the block header also gets (len, cap)
@@ -419,16 +455,18 @@ __global__ __launch_bounds__(1024, 4) void k_runs_extract_one(const unsigned* __
 
 // every vector of `refs` that arrived as bits -> its list, with the workgroup size that suits the number of vectors
 // (`with_len_cap`: caller-owned blocks, whose header also carries (len, cap))
+// (`cstride`, `n_plain`: the plan-owned lists of a call -- candidates compact; never with caller-owned blocks)
 static inline void runs_extract_launch(const RunsRef* refs, size_t n_vec, bool with_len_cap, hipStream_t st, int* zero = nullptr,
-                                       int zero_words = 0) {
+                                       int zero_words = 0, int cstride = 0, int n_plain = 0) {
+    if (with_len_cap) cstride = 0;
     if (n_vec <= 256)
-        hipLaunchKernelGGL(k_runs_extract_1024, dim3((unsigned)n_vec), dim3(1024), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words);
+        hipLaunchKernelGGL(k_runs_extract_1024, dim3((unsigned)n_vec), dim3(1024), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words, cstride, n_plain);
     else if (n_vec <= 768)  // (72 registers: three 512-thread workgroups per CU)
-        hipLaunchKernelGGL(k_runs_extract_512, dim3((unsigned)n_vec), dim3(512), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words);
+        hipLaunchKernelGGL(k_runs_extract_512, dim3((unsigned)n_vec), dim3(512), 0, st, refs, with_len_cap ? 1 : 0, zero, zero_words, cstride, n_plain);
     else if (with_len_cap)
         hipLaunchKernelGGL(k_runs_extract_lists, dim3((unsigned)n_vec), dim3(256), 0, st, refs);
     else
-        hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, refs, zero, zero_words);
+        hipLaunchKernelGGL(k_runs_extract, dim3((unsigned)n_vec), dim3(256), 0, st, refs, zero, zero_words, cstride, n_plain);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -983,6 +1021,11 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
     const int Wt = (cd.d_hi - D0 + 1) < RUNS_T ? (cd.d_hi - D0 + 1) : RUNS_T;
     const GEntries Pe = (GEntries)rs_.e;
     const GWords sbits = (GWords)rs_.bits;
+    // position of the candidate's boundary k = Pc[k << p_sh]: a plan-owned candidate list holds positions only (RunsRef),
+    // every other list (position, ones in front) -- one code path, no branch
+    // (calls with multi-level references keep full candidate lists: k_runs_corr_ml sits at its register budget)
+    const int p_sh = (!ML && rs_.bits != nullptr && rs_.cap > 0) ? 0 : 1;
+    const GInts Pc = (GInts)rs_.e;
     const int n_p = ((GInts)rs_.hdr)[0];
     const int c = tid * RUNS_LPT;  // this thread's lags: D0 + c .. D0 + c + RUNS_LPT - 1
     // the samples that enter (+) and leave (-) the two one-sided counts when the lag grows by one, lag c + i = bit i:
@@ -1130,9 +1173,14 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
             const int i = r0 + (t * RUNS_WAVES + wave) * 64 + lane;
-            v4i se = {0, 0, 0, 0};
-            if (i < r1) se = *(GRunPairs)(Pe + 2 * i);  // (start, ones in front, end, ones in front): one 16-byte load
-            xs2[t] = se.x, xe2[t] = se.z;
+            if (ML) {
+                v4i se = {0, 0, 0, 0};
+                if (i < r1) se = *(GRunPairs)(Pe + 2 * i);  // (start, ones in front, end, ones in front): one 16-byte load
+                xs2[t] = se.x, xe2[t] = se.z;
+            } else {
+                xs2[t] = xe2[t] = 0;
+                if (i < r1) xs2[t] = Pc[(2 * i) << p_sh], xe2[t] = Pc[(2 * i + 1) << p_sh];  // (start, end) of the lane's run
+            }
         }
 #pragma unroll
         for (int t = 0; t < RUNS_TPW; ++t) {
@@ -1238,7 +1286,13 @@ FFS_DEV void runs_corr_body(const CandDesc* __restrict__ cands, int n_cand, cons
         if (!whole) {
             __syncthreads();  // the previous round is done with the staged slice
             if (tid < 128) {
-                const int xq = (tid < 64) ? Pe[2 * r0].pos + D0 : Pe[2 * r1 - 1].pos + D0 + wlim + 1;
+                int xq;
+                if (ML) {
+                    xq = (tid < 64) ? Pe[2 * r0].pos + D0 : Pe[2 * r1 - 1].pos + D0 + wlim + 1;
+                } else {
+                    const int kq = (tid < 64) ? 2 * r0 : 2 * r1 - 1;
+                    xq = Pc[kq << p_sh] + ((tid < 64) ? D0 : D0 + wlim + 1);
+                }
                 const int v = wave_lower_bound_e(Qe, n_q, xq);
                 if ((tid & 63) == 0) s_tmp[0][tid >> 6] = v;
             }

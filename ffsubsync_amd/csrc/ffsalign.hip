@@ -1571,7 +1571,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
             HIP_TRY(hipGetLastError());
             {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                runs_extract_launch((const RunsRef*)(db + o_rv), n_rr, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_rr, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));  // (full lists: see runs_corr_body, p_sh)
                 flags_cleared = true;
             }
             HIP_TRY(hipGetLastError());
@@ -1595,7 +1595,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 hipLaunchKernelGGL(k_runs_probe, dim3((unsigned)((n_vec + 3) / 4)), dim3(256), 0, st, (const RunsRef*)(db + o_rv), (int)n_vec);
             } else {
                 ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+                runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)), (int)stride, (int)n_vec);
                 flags_cleared = true;
             }
             HIP_TRY(hipGetLastError());
@@ -1747,7 +1747,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
         HIP_TRY(hipEventRecord(p->upload_done, st));  // (recorded again should a fallback upload more: the next call waits for the latest)
     if (late_extract) {
         ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-        runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)));
+        runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, p->runs_flags, (int)(flag_bytes / sizeof(int)), (int)stride, (int)n_vec);
         flags_cleared = true;
         HIP_TRY(hipGetLastError());
     }
@@ -1811,7 +1811,7 @@ static int align_impl(ffs_plan* p, int n_pairs, int n_cand, int ref_dt, int dtyp
                 for (int ch = 0; ch < n_chunks; ++ch) skip_runs = skip_runs && p->runs_flags_host[ch] == 1;
                 if (!skip_runs) {  // not (any more) a dense stream: the usual order from here on
                     ProfSpan span(p, st, FFS_K_RUNS_EXTRACT);
-                    runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st);
+                    runs_extract_launch((const RunsRef*)(db + o_rv), n_vec, false, st, nullptr, 0, (int)stride, (int)n_vec);
                 }
                 HIP_TRY(hipGetLastError());
             }
