@@ -1,5 +1,6 @@
+# plan-owned list stride (entries of 8 bytes per slot) by environment: bash profiles/ab_stride.sh "4096 4160 4096 4448 5120 3104"
 cd "$GRAFT_REPO_ROOT"
-for st in 4096 32768 4096 2048; do
+for st in ${1:-4096 32768 4096 2048}; do
   echo -n "stride=$st "
   FFS_RUNS_STRIDE=$st timeout 300 python profiles/runs_quick.py 8192 auto 6000 512 2>/dev/null | python -c "
 import sys,json

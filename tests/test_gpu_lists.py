@@ -231,8 +231,9 @@ def headline(torch):
 
 
 def test_lists_give_the_records_of_the_bits(headline):
-    """configs[2] pairs: the vectors as bits, as lists converted from those bits, and with only the candidates as lists
-    (reference still bits) -- identical records, equal to the unmodified reference's goldens."""
+    """configs[2] pairs: the vectors as bits, as lists converted from those bits, with only the candidates as lists
+    (reference still bits) and with only the reference as a list -- identical records, equal to the unmodified
+    reference's goldens."""
     import test_gpu_headline as th
     from ffsubsync_amd import _native, batch
 
@@ -251,6 +252,13 @@ def test_lists_give_the_records_of_the_bits(headline):
     c, st_c = _solve(both, n_fft, 6000, "auto")
     assert st_c[2] == 0
     _same_records(a, c)
+    # ... and the other way round: the reference's list (caller-owned: position + ones in front) + the candidates' bits,
+    # whose plan-owned lists hold positions only
+    other = batch.DeviceBatch(_torch_cat(db.data, dl.data), np.concatenate([dl.offs[:, :1] + base, db.offs[:, 1:]], axis=1),
+                              db.lens, db.lo, db.hi, _native.FFS_DTYPE_U1, _native.FFS_DTYPE_RUNS)
+    e, st_e = _solve(other, n_fft, 6000, "auto")
+    assert st_e[2] == 0
+    _same_records(a, e)
     # host-known bounds: the call needs nothing back from the device
     n_b = np.zeros(dl.offs.shape, dtype=np.int32)
     for i, o in enumerate(dl.offs.ravel()):
